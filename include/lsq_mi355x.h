@@ -1,0 +1,168 @@
+/*
+ * lsq_mi355x.h -- C-ABI of liblsq_mi355x.so: the MI355X (gfx950) LSQ encoding engine.
+ *
+ * Drop-in boundary for the ILS/ICM encoding hot path of
+ * una-dinosauria/local-search-quantization.  Every entry point cites the reference
+ * interface it replaces (paths relative to the reference repository root).
+ *
+ * Conventions (the reference's own, src/linscan/Linscan.jl:63-69 style):
+ *   - extern "C", plain pointers + integer sizes, no torch/STL types;
+ *   - HOST buffers are the Julia column-major arrays read in place:
+ *       RX/X  d x n  Float32          -> x_i[t]        at  X[i*d + t]
+ *       K     d x (m*h) Float32 = hcat(C...) (encode_icm_cuda.jl:80, Linscan.jl:68)
+ *                                      -> c_{j,a}[t]    at  K[(j*h + a)*d + t]
+ *       B     m x n  Int16, 1-BASED   -> code (i,j)    at  B[i*m + j]
+ *   - DEVICE buffers (the *_dev entry points) use the same X / K layouts and
+ *     uint8 0-BASED codes [n][m] (the layout the reference hands to search,
+ *     demos/demo_lsq_gpu.jl:67);
+ *   - the caller allocates every output (encode_icm_cuda.jl:40-41,275-279) and lends
+ *     pointers for the duration of the call; nothing is retained;
+ *   - every function returns 0 on success, a negative LSQ_E* code otherwise;
+ *     lsq_last_error() returns a thread-local message (the reference has no error
+ *     convention at all: encode_icm_cuda.jl:264 "TODO check that splits >= 1");
+ *   - calls are blocking unless stated; one host thread per lsq_ctx.
+ *
+ * Supported shapes: h == 256 (the reference GPU path hard-codes it:
+ * src/encodings/cuda/cudautils.cu:38,58,155,245), 1 <= m <= 16 (cudautils.cu:38),
+ * any d >= 1, any n >= 0.
+ *
+ * RNG (build-defined; the reference seeds curand with clock(), cudautils.cu:21):
+ * Philox4x32-10 keyed by `seed`, counter = (global vector index, ILS iteration,
+ * domain|block).  `global_offset` is the global index of the first vector of the
+ * buffer, so results do not depend on nsplits / #GPUs / chunking.
+ */
+#ifndef LSQ_MI355X_H
+#define LSQ_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSQ_VERSION 100
+
+#if defined(__GNUC__)
+#define LSQ_API __attribute__((visibility("default")))
+#else
+#define LSQ_API
+#endif
+
+enum {
+    LSQ_OK = 0,
+    LSQ_EINVAL = -1,    /* bad argument (shape, range, null pointer)      */
+    LSQ_EHIP = -2,      /* a HIP runtime call failed (message has details) */
+    LSQ_ENOMEM = -3,    /* device or host allocation failed                */
+    LSQ_ECODE = -4,     /* an input code is outside 1..h                   */
+    LSQ_ENODEV = -5     /* no usable gfx950 device                         */
+};
+
+typedef struct lsq_ctx lsq_ctx;
+
+/* Accumulated device time per kernel class since the last lsq_reset_timings (hipEvent pairs on
+ * the context's stream), only collected while option "profile" is 1. */
+typedef struct lsq_timings {
+    double tables_ms;        /* sqnorms + pairwise tables (get_binaries)            */
+    double unaries_ms;       /* unary build (get_unaries)                            */
+    double perturb_ms;       /* perturbation kernels                                 */
+    double icm_ms;           /* ICM node-update kernels (the dominant kernel)        */
+    double cost_ms;          /* cost + accept (+ objective) kernels                  */
+    double other_ms;         /* layout conversion, snapshots                         */
+    int64_t icm_launches;    /* number of ICM kernel launches inside icm_ms           */
+    int64_t icm_node_updates;/* vector x node updates executed inside icm_ms          */
+} lsq_timings;
+
+LSQ_API const char *lsq_last_error(void);
+LSQ_API int lsq_version(void);
+LSQ_API int lsq_device_count(int *count);
+
+/* Context = device + stream + workspace.  Replaces the per-call CuContext / module load /
+ * destroy! of encode_icm_cuda.jl:59-64,226-228. */
+LSQ_API int lsq_create(lsq_ctx **ctx, int device);
+LSQ_API int lsq_destroy(lsq_ctx *ctx);
+/* Launch on the caller's hipStream_t (e.g. torch's current stream); NULL = the ctx's own. */
+LSQ_API int lsq_set_stream(lsq_ctx *ctx, void *hip_stream);
+/* Options: "chunk" (vectors per resident chunk, default 1048576), "profile" (0/1),
+ *          "schedule" (0 = one launch per node update, 1 = fused per-ILS-iteration sweep). */
+LSQ_API int lsq_set_option(lsq_ctx *ctx, const char *key, int64_t value);
+LSQ_API int lsq_get_timings(lsq_ctx *ctx, lsq_timings *out);
+LSQ_API int lsq_reset_timings(lsq_ctx *ctx);
+LSQ_API int lsq_synchronize(lsq_ctx *ctx);
+
+/* ---- (1) the whole call ------------------------------------------------------------------
+ * Replaces encode_icm_cuda(RX, B, C, ilsiters, icmiter, npert, randord, nsplits, V)
+ *   -> (Bs, objs)      src/encodings/encode_icm_cuda.jl:253-296 (and _single, :22-234);
+ * call site demos/demo_lsq_gpu.jl:50.  Runs max(ilsiters) ILS iterations; snapshot k holds the
+ * codes and the objective (qerror, src/utils.jl:257-285) after ilsiters[k] iterations.
+ * Semantics of each ILS iteration follow the reference CPU path (src/encodings/encode_icm.jl:
+ * 131-189): perturb, icmiter sweeps, accept iff strictly better.
+ *   Bs   : nr x (m x n Int16, 1-based), caller-allocated;   objs : nr Float32.
+ * nsplits is accepted for signature compatibility (the reference needs it for 12 GB GPUs,
+ * demos/demo_lsq_gpu.jl:49); results do not depend on it. */
+LSQ_API int lsq_encode_icm(lsq_ctx *ctx, const float *RX, const int16_t *B, const float *K,
+                   int d, int64_t n, int m, int h,
+                   const int64_t *ilsiters, int nr, int icmiter, int npert, int randord,
+                   int nsplits, uint64_t seed, uint64_t global_offset, int verbose,
+                   int16_t *Bs, float *objs);
+
+/* Same call on DEVICE-resident buffers, asynchronous on the context's stream except for the
+ * final read-back of nr objective sums.  dB0 / dBs: uint8 0-based [n][m] (dBs: nr of them).
+ * obj_sums (host, nr doubles) receives SUM_i cost_i (not the mean) so that a multi-GPU caller
+ * can add shards; objs = obj_sums / n_total.  stats (host, optional, 2*max(ilsiters) int64):
+ * per ILS iteration the number of vectors whose new cost was == / < the previous one
+ * (the two counters the reference prints, encode_icm.jl:180-184). */
+LSQ_API int lsq_encode_icm_dev(lsq_ctx *ctx, const float *dX, const uint8_t *dB0, const float *dK,
+                       int d, int64_t n, int m, int h,
+                       const int64_t *ilsiters, int nr, int icmiter, int npert, int randord,
+                       uint64_t seed, uint64_t global_offset,
+                       uint8_t *dBs, double *obj_sums, int64_t *stats);
+
+/* ---- (2) the CPU-path shaped entry points -------------------------------------------------
+ * encoding_icm(X, oldB, C, niter, randord, npert, V) -> B     src/encodings/encode_icm.jl:131-189
+ * ONE ILS iteration (`it` = its 0-based index, the RNG counter) with the accept rule. */
+LSQ_API int lsq_encoding_icm(lsq_ctx *ctx, const float *X, const int16_t *oldB, const float *K,
+                     int d, int64_t n, int m, int h, int niter, int randord, int npert,
+                     uint64_t seed, uint32_t it, uint64_t global_offset, int16_t *outB);
+
+/* encode_icm_fully!(B, X, C, binaries, cbi, niter, randord, npert, IDX, V)
+ *   src/encodings/encode_icm.jl:4-127 -- the worker: perturb + niter sweeps, in place, NO accept
+ * test.  This is the hook the authors left commented at encode_icm.jl:163 (`encode_icm_cpp!`).
+ * `binaries`/`cbi` are rebuilt on the device from K (cheaper than shipping them);
+ * idx_first = first(IDX), 1-based global column of X[:,1] (keys the RNG). */
+LSQ_API int lsq_encode_icm_fully(lsq_ctx *ctx, int16_t *B, const float *X, const float *K,
+                         int d, int64_t n, int m, int h, int niter, int randord, int npert,
+                         int64_t idx_first, uint64_t seed, uint32_t it);
+
+/* ---- (3) the numeric helpers the path is made of (host buffers) ---------------------------
+ * get_unaries(X, C)   src/utils.jl:94-122  -> U [m][n][h]  (unaries[j] is h x n column-major) */
+LSQ_API int lsq_get_unaries(lsq_ctx *ctx, const float *X, const float *K, int d, int64_t n, int m, int h, float *U);
+/* get_binaries(C)     src/utils.jl:125-144 (+ the transposes of encode_icm.jl:25-28)
+ *   -> T [m][m][h][h], T[j][k][b][a] = 2<c_{j,a}, c_{k,b}>; binaries[idx(i<j)][a + b*h] = T[i][j][b][a] */
+LSQ_API int lsq_get_binaries(lsq_ctx *ctx, const float *K, int d, int m, int h, float *T);
+/* veccost(X, B, C)    src/utils.jl:225-254  -> cost [n] */
+LSQ_API int lsq_veccost(lsq_ctx *ctx, const float *X, const int16_t *B, const float *K,
+                int d, int64_t n, int m, int h, float *cost);
+/* qerror(X, B, C)     src/utils.jl:257-285  -> mean squared error (f64 accumulation) */
+LSQ_API int lsq_qerror(lsq_ctx *ctx, const float *X, const int16_t *B, const float *K,
+               int d, int64_t n, int m, int h, double *out);
+/* perturb kernel      src/encodings/cuda/cudautils.cu:27-80 (host buffers, in place) */
+LSQ_API int lsq_perturb(lsq_ctx *ctx, int16_t *B, int64_t n, int m, int h, int npert,
+                uint64_t seed, uint32_t it, uint64_t global_offset);
+/* randinit(n, m, h)   src/initializations.jl:2-8   (host function, Philox-keyed) */
+LSQ_API int lsq_randinit(uint64_t seed, uint64_t global_offset, int64_t n, int m, int h, int16_t *B);
+/* node visiting order of ILS iteration `it` (randperm of encode_icm.jl:46-49), 0-based */
+LSQ_API int lsq_node_order(uint64_t seed, uint32_t it, int m, int randord, int32_t *order);
+/* splitarray(1:n, nparts)  src/utils.jl:152-177 -> part's [start, start+len) , 0-based */
+LSQ_API int lsq_splitarray(int64_t n, int nparts, int part, int64_t *start, int64_t *len);
+
+/* ---- (4) device-side generators used by the benchmark harness -----------------------------
+ * X[i][t] = float(uniform integer 0..255) (SIFT-like);  codes uniform 0..h-1 (randinit);
+ * codebooks: K[j][a][:] = scale * x_{pick(j,a)} for a Philox-picked synthetic vector. */
+LSQ_API int lsq_synth_data_u8_dev(lsq_ctx *ctx, uint64_t seed, uint64_t global_offset, int64_t n, int d, float *dX);
+LSQ_API int lsq_randinit_dev(lsq_ctx *ctx, uint64_t seed, uint64_t global_offset, int64_t n, int m, int h, uint8_t *dB);
+LSQ_API int lsq_synth_codebooks_dev(lsq_ctx *ctx, uint64_t seed, int m, int h, int d, float *dK);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSQ_MI355X_H */

@@ -1,0 +1,86 @@
+"""ctypes binding of liblsq_mi355x.so -- every symbol include/lsq_mi355x.h declares.
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, an
+exception is raised.  Build it with `python -c "import __graft_entry__ as g; g.build()"`
+(or `make -C local-search-quantization_amd/csrc`).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblsq_mi355x.so")
+
+LSQ_OK, LSQ_EINVAL, LSQ_EHIP, LSQ_ENOMEM, LSQ_ECODE, LSQ_ENODEV = 0, -1, -2, -3, -4, -5
+
+
+class LsqError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("liblsq_mi355x error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Timings(C.Structure):
+    _fields_ = [("tables_ms", C.c_double), ("unaries_ms", C.c_double), ("perturb_ms", C.c_double),
+                ("icm_ms", C.c_double), ("cost_ms", C.c_double), ("other_ms", C.c_double),
+                ("icm_launches", C.c_int64), ("icm_node_updates", C.c_int64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_vp, _i, _i64, _u64, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_uint32
+
+# name -> (restype, argtypes).  Pointers are passed as raw addresses (host or device).
+SIGNATURES = {
+    "lsq_last_error": (C.c_char_p, []),
+    "lsq_version": (_i, []),
+    "lsq_device_count": (_i, [C.POINTER(_i)]),
+    "lsq_create": (_i, [C.POINTER(_vp), _i]),
+    "lsq_destroy": (_i, [_vp]),
+    "lsq_set_stream": (_i, [_vp, _vp]),
+    "lsq_set_option": (_i, [_vp, C.c_char_p, _i64]),
+    "lsq_get_timings": (_i, [_vp, C.POINTER(Timings)]),
+    "lsq_reset_timings": (_i, [_vp]),
+    "lsq_synchronize": (_i, [_vp]),
+    "lsq_encode_icm": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _i, _i, _i, _i, _i, _u64, _u64, _i, _vp, _vp]),
+    "lsq_encode_icm_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _i, _i, _i, _i, _u64, _u64, _vp, _vp, _vp]),
+    "lsq_encoding_icm": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _u64, _u32, _u64, _vp]),
+    "lsq_encode_icm_fully": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _i64, _u64, _u32]),
+    "lsq_get_unaries": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
+    "lsq_get_binaries": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "lsq_veccost": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
+    "lsq_qerror": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, C.POINTER(C.c_double)]),
+    "lsq_perturb": (_i, [_vp, _vp, _i64, _i, _i, _i, _u64, _u32, _u64]),
+    "lsq_randinit": (_i, [_u64, _u64, _i64, _i, _i, _vp]),
+    "lsq_node_order": (_i, [_u64, _u32, _i, _i, _vp]),
+    "lsq_splitarray": (_i, [_i64, _i, _i, C.POINTER(_i64), C.POINTER(_i64)]),
+    "lsq_synth_data_u8_dev": (_i, [_vp, _u64, _u64, _i64, _i, _vp]),
+    "lsq_randinit_dev": (_i, [_vp, _u64, _u64, _i64, _i, _i, _vp]),
+    "lsq_synth_codebooks_dev": (_i, [_vp, _u64, _i, _i, _i, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "%s not found: the HIP extension is not built. Run `python -c \"import __graft_entry__ as g; "
+                "g.build()\"` -- there is no CPU fallback." % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)       # AttributeError if the symbol is missing: loud by design
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != LSQ_OK:
+        msg = load().lsq_last_error()
+        raise LsqError(rc, msg.decode("utf-8", "replace") if msg else "")
+    return rc

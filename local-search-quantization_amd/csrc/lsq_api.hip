@@ -1,0 +1,570 @@
+// lsq_api.hip -- the C-ABI of liblsq_mi355x.so (see include/lsq_mi355x.h for the contract and the
+// reference interfaces each entry point replaces).  Host orchestration only: every numeric step is
+// a HIP kernel in lsq_gemm.hip / lsq_icm.hip.  There is NO CPU fallback: without a gfx950 device
+// every compute entry point fails with LSQ_ENODEV / LSQ_EHIP.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "lsq_internal.h"
+
+// ---- errors -------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void lsq_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *lsq_last_error(void) { return g_err; }
+extern "C" int lsq_version(void) { return LSQ_VERSION; }
+
+extern "C" int lsq_device_count(int *count) {
+    if (!count) { lsq_set_error("lsq_device_count: null pointer"); return LSQ_EINVAL; }
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *count = 0; lsq_set_error("hipGetDeviceCount: %s", hipGetErrorString(e)); return LSQ_ENODEV; }
+    *count = c;
+    return LSQ_OK;
+}
+
+// ---- context ------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return LSQ_OK;
+        if (p) { LSQ_HIP(hipFree(p)); p = nullptr; cap = 0; }
+        if (bytes == 0) return LSQ_OK;
+        LSQ_HIP(hipMalloc(&p, bytes));
+        cap = bytes;
+        return LSQ_OK;
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+enum { CAT_TABLES = 0, CAT_UNARIES, CAT_PERTURB, CAT_ICM, CAT_COST, CAT_OTHER, CAT_COUNT };
+
+struct lsq_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    int64_t chunk = 1 << 20;
+    int profile = 0;
+    int schedule = 0;
+    // workspace
+    DevBuf sci, T, U, recCur, recNew, prev, counters, obj, bad;
+    DevBuf sX, sK, sB16, sOut16, sTight, sF32;    // staging for the host-buffer entry points
+    // timings
+    double cat_ms[CAT_COUNT] = {0, 0, 0, 0, 0, 0};
+    int64_t icm_launches = 0, icm_node_updates = 0;
+    struct Pending { hipEvent_t a, b; int cat; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+};
+
+static int use_device(lsq_ctx *ctx) {
+    if (!ctx) { lsq_set_error("null lsq_ctx"); return LSQ_EINVAL; }
+    LSQ_HIP(hipSetDevice(ctx->device));
+    return LSQ_OK;
+}
+
+struct Timer {        // brackets a group of launches with an event pair when profiling is on
+    lsq_ctx *c; int cat; hipEvent_t a = nullptr, b = nullptr; bool on;
+    Timer(lsq_ctx *ctx, int category) : c(ctx), cat(category), on(ctx->profile != 0) {
+        if (!on) return;
+        a = grab(); b = grab();
+        if (!a || !b) { on = false; return; }
+        (void)hipEventRecord(a, c->stream);
+    }
+    hipEvent_t grab() {
+        if (!c->pool.empty()) { hipEvent_t e = c->pool.back(); c->pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+    ~Timer() {
+        if (!on) return;
+        (void)hipEventRecord(b, c->stream);
+        c->pending.push_back({a, b, cat});
+    }
+};
+
+static int resolve_timings(lsq_ctx *ctx) {
+    for (auto &p : ctx->pending) {
+        LSQ_HIP(hipEventSynchronize(p.b));
+        float ms = 0.f;
+        LSQ_HIP(hipEventElapsedTime(&ms, p.a, p.b));
+        ctx->cat_ms[p.cat] += (double)ms;
+        ctx->pool.push_back(p.a);
+        ctx->pool.push_back(p.b);
+    }
+    ctx->pending.clear();
+    return LSQ_OK;
+}
+
+extern "C" int lsq_create(lsq_ctx **out, int device) {
+    if (!out) { lsq_set_error("lsq_create: null out pointer"); return LSQ_EINVAL; }
+    *out = nullptr;
+    int count = 0;
+    LSQ_TRY(lsq_device_count(&count));
+    if (count <= 0) { lsq_set_error("no HIP device visible (this library has no CPU fallback)"); return LSQ_ENODEV; }
+    if (device < 0 || device >= count) { lsq_set_error("device %d out of range (0..%d)", device, count - 1); return LSQ_EINVAL; }
+    LSQ_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    LSQ_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        lsq_set_error("device %d is %s; this library carries gfx950 (MI355X) code objects only", device, prop.gcnArchName);
+        return LSQ_ENODEV;
+    }
+    lsq_ctx *c = new lsq_ctx();
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; lsq_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return LSQ_EHIP; }
+    c->stream = c->own_stream;
+    *out = c;
+    return LSQ_OK;
+}
+
+extern "C" int lsq_destroy(lsq_ctx *c) {
+    if (!c) return LSQ_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto e : c->pool) (void)hipEventDestroy(e);
+    DevBuf *bufs[] = {&c->sci, &c->T, &c->U, &c->recCur, &c->recNew, &c->prev, &c->counters, &c->obj, &c->bad,
+                      &c->sX, &c->sK, &c->sB16, &c->sOut16, &c->sTight, &c->sF32};
+    for (DevBuf *b : bufs) b->release();
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return LSQ_OK;
+}
+
+extern "C" int lsq_set_stream(lsq_ctx *c, void *hip_stream) {
+    LSQ_TRY(use_device(c));
+    c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return LSQ_OK;
+}
+
+extern "C" int lsq_set_option(lsq_ctx *c, const char *key, int64_t value) {
+    if (!c || !key) { lsq_set_error("lsq_set_option: null argument"); return LSQ_EINVAL; }
+    if (!strcmp(key, "chunk")) {
+        if (value < 1) { lsq_set_error("chunk must be >= 1"); return LSQ_EINVAL; }
+        c->chunk = value;
+    } else if (!strcmp(key, "profile")) c->profile = value != 0;
+    else if (!strcmp(key, "schedule")) {
+        if (value < 0 || value > 1) { lsq_set_error("schedule must be 0 or 1"); return LSQ_EINVAL; }
+        c->schedule = (int)value;
+    } else { lsq_set_error("unknown option '%s'", key); return LSQ_EINVAL; }
+    return LSQ_OK;
+}
+
+extern "C" int lsq_get_timings(lsq_ctx *c, lsq_timings *out) {
+    LSQ_TRY(use_device(c));
+    if (!out) { lsq_set_error("lsq_get_timings: null out"); return LSQ_EINVAL; }
+    LSQ_TRY(resolve_timings(c));
+    out->tables_ms = c->cat_ms[CAT_TABLES];
+    out->unaries_ms = c->cat_ms[CAT_UNARIES];
+    out->perturb_ms = c->cat_ms[CAT_PERTURB];
+    out->icm_ms = c->cat_ms[CAT_ICM];
+    out->cost_ms = c->cat_ms[CAT_COST];
+    out->other_ms = c->cat_ms[CAT_OTHER];
+    out->icm_launches = c->icm_launches;
+    out->icm_node_updates = c->icm_node_updates;
+    return LSQ_OK;
+}
+
+extern "C" int lsq_reset_timings(lsq_ctx *c) {
+    LSQ_TRY(use_device(c));
+    LSQ_TRY(resolve_timings(c));
+    for (double &v : c->cat_ms) v = 0.0;
+    c->icm_launches = c->icm_node_updates = 0;
+    return LSQ_OK;
+}
+
+extern "C" int lsq_synchronize(lsq_ctx *c) {
+    LSQ_TRY(use_device(c));
+    LSQ_HIP(hipStreamSynchronize(c->stream));
+    return LSQ_OK;
+}
+
+// ---- host-side pieces of the path -----------------------------------------------------------------
+extern "C" int lsq_node_order(uint64_t seed, uint32_t it, int m, int randord, int32_t *order) {
+    if (!order || m < 1 || m > LSQ_MAX_M) { lsq_set_error("lsq_node_order: bad arguments"); return LSQ_EINVAL; }
+    for (int p = 0; p < m; ++p) order[p] = p;
+    if (!randord) return LSQ_OK;
+    for (int p = m - 1; p >= 1; --p) {        // Fisher-Yates on Philox words of domain PERM
+        const uint32_t r = lsq_rng_word(seed, 0, it, LSQ_DOM_PERM, (uint32_t)(m - 1 - p));
+        const int q = (int)lsq_mulhi32(r, (uint32_t)(p + 1));
+        std::swap(order[p], order[q]);
+    }
+    return LSQ_OK;
+}
+
+extern "C" int lsq_splitarray(int64_t n, int nparts, int part, int64_t *start, int64_t *len) {
+    if (n < 0 || nparts < 1 || part < 0 || part >= nparts || !start || !len) { lsq_set_error("lsq_splitarray: bad arguments"); return LSQ_EINVAL; }
+    const int64_t per = n / nparts, xtra = n % nparts;      // first `xtra` parts get one more (utils.jl:152-177)
+    *start = part < xtra ? part * (per + 1) : xtra * (per + 1) + (part - xtra) * per;
+    *len = part < xtra ? per + 1 : per;
+    return LSQ_OK;
+}
+
+extern "C" int lsq_randinit(uint64_t seed, uint64_t global_offset, int64_t n, int m, int h, int16_t *B) {
+    if (n < 0 || m < 1 || h < 1 || h > 32767 || (!B && n > 0)) { lsq_set_error("lsq_randinit: bad arguments"); return LSQ_EINVAL; }
+    for (int64_t i = 0; i < n; ++i)
+        for (int j = 0; j < m; ++j)
+            B[i * m + j] = (int16_t)(1 + lsq_mulhi32(lsq_rng_word(seed, global_offset + (uint64_t)i, 0, LSQ_DOM_INIT, (uint32_t)j), (uint32_t)h));
+    return LSQ_OK;
+}
+
+static int check_shape(const char *fn, int d, int64_t n, int m, int h) {
+    if (d < 1 || n < 0 || m < 1 || m > LSQ_MAX_M) { lsq_set_error("%s: bad shape d=%d n=%lld m=%d (need d>=1, n>=0, 1<=m<=16)", fn, d, (long long)n, m); return LSQ_EINVAL; }
+    if (h != LSQ_H) { lsq_set_error("%s: h=%d unsupported; this engine (like the reference GPU path) needs h == 256", fn, h); return LSQ_EINVAL; }
+    return LSQ_OK;
+}
+
+// ---- device core ----------------------------------------------------------------------------------
+static int prepare_tables(lsq_ctx *c, const float *dK, int d, int m) {
+    Timer t(c, CAT_TABLES);
+    const int mh = m * LSQ_H;
+    LSQ_TRY(c->sci.ensure(sizeof(float) * (size_t)mh));
+    LSQ_TRY(c->T.ensure(sizeof(float) * (size_t)mh * mh));
+    LSQ_TRY(lsq_launch_sqnorms(c->stream, dK, mh, d, c->sci.as<float>()));
+    // rows r = (k,b), cols c = (j,a):  T[((j*m + k)*h + b)*h + a] = chain(K[k,b][t] * 2 K[j,a][t])
+    LSQ_TRY(lsq_launch_chain_gemm(c->stream, dK, dK, nullptr, 2.0f, mh, mh, d, LSQ_H, (int64_t)m * LSQ_H * LSQ_H, LSQ_H, c->T.as<float>()));
+    return LSQ_OK;
+}
+
+static int build_unaries(lsq_ctx *c, const float *dX, const float *dK, int d, int64_t cn, int m) {
+    Timer t(c, CAT_UNARIES);
+    LSQ_TRY(c->U.ensure(sizeof(float) * (size_t)m * (size_t)cn * LSQ_H));
+    // U[(j*cn + i)*h + a] = chain(x_i[t] * -2 K[j,a][t]) + sci[j,a]
+    return lsq_launch_chain_gemm(c->stream, dX, dK, c->sci.as<float>(), -2.0f, cn, m * LSQ_H, d, LSQ_H, cn * (int64_t)LSQ_H, LSQ_H, c->U.as<float>());
+}
+
+static int run_sweeps(lsq_ctx *c, uint8_t *rec, int64_t cn, int m, const int32_t *order, int nsweeps) {
+    Timer t(c, CAT_ICM);
+    if (c->schedule == 1) {
+        LSQ_TRY(lsq_launch_icm_fused(c->stream, c->U.as<float>(), c->T.as<float>(), rec, cn, m, order, nsweeps));
+        c->icm_launches += 1;
+    } else {
+        for (int sw = 0; sw < nsweeps; ++sw)
+            for (int q = 0; q < m; ++q) {
+                const int j = order[q];
+                LSQ_TRY(lsq_launch_icm_node(c->stream, c->U.as<float>() + (int64_t)j * cn * LSQ_H, c->T.as<float>(), rec, cn, m, j));
+            }
+        c->icm_launches += (int64_t)nsweeps * m;
+    }
+    c->icm_node_updates += cn * (int64_t)nsweeps * m;
+    return LSQ_OK;
+}
+
+struct EncodeParams {
+    int d, m;
+    const int64_t *ilsiters; int nr;
+    int icmiter, npert, randord;
+    uint64_t seed; uint32_t it0;
+};
+
+// One resident chunk: recCur holds the chunk's codes on entry; snapshots are emitted through `snap`.
+template <class Snap>
+static int encode_chunk(lsq_ctx *c, const float *dXc, const float *dK, int64_t cn, uint64_t goff, const EncodeParams &P, int64_t I, Snap snap) {
+    const int cs = lsq_code_stride(P.m);
+    LSQ_TRY(build_unaries(c, dXc, dK, P.d, cn, P.m));
+    LSQ_TRY(c->recNew.ensure((size_t)cn * cs));
+    LSQ_TRY(c->prev.ensure(sizeof(float) * (size_t)cn));
+    uint8_t *cur = c->recCur.as<uint8_t>(), *nw = c->recNew.as<uint8_t>();
+    float *prev = c->prev.as<float>();
+    unsigned long long *counters = c->counters.as<unsigned long long>();
+    {
+        Timer t(c, CAT_COST);
+        LSQ_TRY(lsq_launch_cost(c->stream, dXc, dK, cur, cur, prev, counters, cn, P.d, P.m, 0));   // encode_icm.jl:149
+    }
+    for (int64_t it = 0; it < I; ++it) {
+        int32_t order[LSQ_MAX_M];
+        LSQ_TRY(lsq_node_order(P.seed, P.it0 + (uint32_t)it, P.m, P.randord, order));
+        {
+            Timer t(c, CAT_PERTURB);
+            LSQ_TRY(lsq_launch_perturb(c->stream, cur, nw, cn, P.m, P.npert, P.seed, P.it0 + (uint32_t)it, goff));
+        }
+        LSQ_TRY(run_sweeps(c, nw, cn, P.m, order, P.icmiter));
+        {
+            Timer t(c, CAT_COST);
+            LSQ_TRY(lsq_launch_cost(c->stream, dXc, dK, nw, cur, prev, counters + 2 * it, cn, P.d, P.m, 1));
+        }
+        for (int r = 0; r < P.nr; ++r)
+            if (P.ilsiters[r] == it + 1) {
+                Timer t(c, CAT_OTHER);
+                LSQ_TRY(lsq_launch_sum_f64(c->stream, prev, cn, c->obj.as<double>() + r));
+                LSQ_TRY(snap(r, cur));
+            }
+    }
+    return LSQ_OK;
+}
+
+static int validate_encode(const char *fn, int d, int64_t n, int m, int h, const int64_t *ilsiters, int nr, int icmiter, int npert, int64_t *I) {
+    LSQ_TRY(check_shape(fn, d, n, m, h));
+    if (!ilsiters || nr < 1) { lsq_set_error("%s: ilsiters must hold at least one entry", fn); return LSQ_EINVAL; }
+    if (icmiter < 0 || npert < 0) { lsq_set_error("%s: icmiter and npert must be >= 0", fn); return LSQ_EINVAL; }
+    *I = 0;
+    for (int r = 0; r < nr; ++r) {
+        if (ilsiters[r] < 1) { lsq_set_error("%s: ilsiters[%d] = %lld must be >= 1", fn, r, (long long)ilsiters[r]); return LSQ_EINVAL; }
+        *I = std::max<int64_t>(*I, ilsiters[r]);
+    }
+    return LSQ_OK;
+}
+
+static int begin_call(lsq_ctx *c, int64_t I, int nr) {
+    LSQ_TRY(c->counters.ensure(sizeof(unsigned long long) * 2 * (size_t)std::max<int64_t>(I, 1)));
+    LSQ_TRY(c->obj.ensure(sizeof(double) * (size_t)std::max(nr, 1)));
+    LSQ_TRY(c->bad.ensure(sizeof(int)));
+    LSQ_HIP(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long) * 2 * (size_t)std::max<int64_t>(I, 1), c->stream));
+    LSQ_HIP(hipMemsetAsync(c->obj.p, 0, sizeof(double) * (size_t)std::max(nr, 1), c->stream));
+    LSQ_HIP(hipMemsetAsync(c->bad.p, 0, sizeof(int), c->stream));
+    return LSQ_OK;
+}
+
+static int finish_call(lsq_ctx *c, int64_t I, int nr, double *obj_sums, int64_t *stats) {
+    std::vector<unsigned long long> cnt(2 * (size_t)std::max<int64_t>(I, 1));
+    LSQ_HIP(hipMemcpyAsync(obj_sums, c->obj.p, sizeof(double) * (size_t)nr, hipMemcpyDeviceToHost, c->stream));
+    LSQ_HIP(hipMemcpyAsync(cnt.data(), c->counters.p, sizeof(unsigned long long) * cnt.size(), hipMemcpyDeviceToHost, c->stream));
+    LSQ_HIP(hipStreamSynchronize(c->stream));
+    if (stats) for (int64_t q = 0; q < 2 * I; ++q) stats[q] = (int64_t)cnt[(size_t)q];
+    return LSQ_OK;
+}
+
+extern "C" int lsq_encode_icm_dev(lsq_ctx *c, const float *dX, const uint8_t *dB0, const float *dK, int d, int64_t n, int m, int h,
+                                  const int64_t *ilsiters, int nr, int icmiter, int npert, int randord, uint64_t seed,
+                                  uint64_t global_offset, uint8_t *dBs, double *obj_sums, int64_t *stats) {
+    LSQ_TRY(use_device(c));
+    int64_t I = 0;
+    LSQ_TRY(validate_encode("lsq_encode_icm_dev", d, n, m, h, ilsiters, nr, icmiter, npert, &I));
+    if (!dK || !obj_sums || (n > 0 && (!dX || !dB0 || !dBs))) { lsq_set_error("lsq_encode_icm_dev: null pointer"); return LSQ_EINVAL; }
+    LSQ_TRY(begin_call(c, I, nr));
+    LSQ_TRY(prepare_tables(c, dK, d, m));
+    const EncodeParams P{d, m, ilsiters, nr, icmiter, npert, randord, seed, 0u};
+    const int cs = lsq_code_stride(m);
+    for (int64_t off = 0; off < n; off += c->chunk) {
+        const int64_t cn = std::min<int64_t>(c->chunk, n - off);
+        LSQ_TRY(c->recCur.ensure((size_t)cn * cs));
+        {
+            Timer t(c, CAT_OTHER);
+            LSQ_TRY(lsq_launch_codes_expand(c->stream, dB0 + off * m, cn, m, c->recCur.as<uint8_t>()));
+        }
+        auto snap = [&](int r, const uint8_t *cur) {
+            return lsq_launch_codes_compact(c->stream, cur, cn, m, dBs + ((int64_t)r * n + off) * m);
+        };
+        LSQ_TRY(encode_chunk(c, dX + off * d, dK, cn, global_offset + (uint64_t)off, P, I, snap));
+    }
+    return finish_call(c, I, nr, obj_sums, stats);
+}
+
+// host-buffer core shared by lsq_encode_icm / lsq_encoding_icm
+static int encode_host(lsq_ctx *c, const char *fn, const float *X, const int16_t *B, const float *K, int d, int64_t n, int m, int h,
+                       const int64_t *ilsiters, int nr, int icmiter, int npert, int randord, uint64_t seed, uint32_t it0,
+                       uint64_t global_offset, int verbose, int16_t *Bs, float *objs) {
+    LSQ_TRY(use_device(c));
+    int64_t I = 0;
+    LSQ_TRY(validate_encode(fn, d, n, m, h, ilsiters, nr, icmiter, npert, &I));
+    if (!K || !objs || (n > 0 && (!X || !B || !Bs))) { lsq_set_error("%s: null pointer", fn); return LSQ_EINVAL; }
+    LSQ_TRY(begin_call(c, I, nr));
+    const size_t kbytes = sizeof(float) * (size_t)m * LSQ_H * d;
+    LSQ_TRY(c->sK.ensure(kbytes));
+    LSQ_HIP(hipMemcpyAsync(c->sK.p, K, kbytes, hipMemcpyHostToDevice, c->stream));
+    const float *dK = c->sK.as<float>();
+    LSQ_TRY(prepare_tables(c, dK, d, m));
+    const EncodeParams P{d, m, ilsiters, nr, icmiter, npert, randord, seed, it0};
+    const int cs = lsq_code_stride(m);
+    for (int64_t off = 0; off < n; off += c->chunk) {
+        const int64_t cn = std::min<int64_t>(c->chunk, n - off);
+        LSQ_TRY(c->sX.ensure(sizeof(float) * (size_t)cn * d));
+        LSQ_TRY(c->sB16.ensure(sizeof(int16_t) * (size_t)cn * m));
+        LSQ_TRY(c->sOut16.ensure(sizeof(int16_t) * (size_t)cn * m * nr));
+        LSQ_TRY(c->recCur.ensure((size_t)cn * cs));
+        LSQ_HIP(hipMemcpyAsync(c->sX.p, X + off * d, sizeof(float) * (size_t)cn * d, hipMemcpyHostToDevice, c->stream));
+        LSQ_HIP(hipMemcpyAsync(c->sB16.p, B + off * m, sizeof(int16_t) * (size_t)cn * m, hipMemcpyHostToDevice, c->stream));
+        LSQ_TRY(lsq_launch_codes_from_i16(c->stream, c->sB16.as<int16_t>(), cn, m, h, c->recCur.as<uint8_t>(), c->bad.as<int>()));
+        auto snap = [&](int r, const uint8_t *cur) {
+            return lsq_launch_codes_to_i16(c->stream, cur, cn, m, c->sOut16.as<int16_t>() + (int64_t)r * cn * m);
+        };
+        LSQ_TRY(encode_chunk(c, c->sX.as<float>(), dK, cn, global_offset + (uint64_t)off, P, I, snap));
+        for (int r = 0; r < nr; ++r)
+            LSQ_HIP(hipMemcpyAsync(Bs + ((int64_t)r * n + off) * m, c->sOut16.as<int16_t>() + (int64_t)r * cn * m,
+                                   sizeof(int16_t) * (size_t)cn * m, hipMemcpyDeviceToHost, c->stream));
+        LSQ_HIP(hipStreamSynchronize(c->stream));      // staging buffers are reused by the next chunk
+    }
+    std::vector<double> sums((size_t)nr, 0.0);
+    std::vector<int64_t> stats(2 * (size_t)I, 0);
+    int bad = 0;
+    LSQ_HIP(hipMemcpyAsync(&bad, c->bad.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    LSQ_TRY(finish_call(c, I, nr, sums.data(), stats.data()));
+    if (bad) { lsq_set_error("%s: input codes must lie in 1..%d", fn, h); return LSQ_ECODE; }
+    for (int r = 0; r < nr; ++r) objs[r] = (float)(n > 0 ? sums[(size_t)r] / (double)n : 0.0);
+    if (verbose)
+        for (int64_t it = 0; it < I; ++it)      // the two counters the reference prints (encode_icm_cuda.jl:199-204)
+            printf(" ILS iteration %lld/%lld done. %5.2f%% new codes are equal. %5.2f%% new codes are better.\n", (long long)(it + 1),
+                   (long long)I, n ? 100.0 * (double)stats[2 * it] / (double)n : 0.0, n ? 100.0 * (double)stats[2 * it + 1] / (double)n : 0.0);
+    return LSQ_OK;
+}
+
+extern "C" int lsq_encode_icm(lsq_ctx *c, const float *RX, const int16_t *B, const float *K, int d, int64_t n, int m, int h,
+                              const int64_t *ilsiters, int nr, int icmiter, int npert, int randord, int nsplits, uint64_t seed,
+                              uint64_t global_offset, int verbose, int16_t *Bs, float *objs) {
+    if (nsplits < 1) { lsq_set_error("lsq_encode_icm: nsplits must be >= 1"); return LSQ_EINVAL; }
+    return encode_host(c, "lsq_encode_icm", RX, B, K, d, n, m, h, ilsiters, nr, icmiter, npert, randord, seed, 0u, global_offset, verbose, Bs, objs);
+}
+
+extern "C" int lsq_encoding_icm(lsq_ctx *c, const float *X, const int16_t *oldB, const float *K, int d, int64_t n, int m, int h,
+                                int niter, int randord, int npert, uint64_t seed, uint32_t it, uint64_t global_offset, int16_t *outB) {
+    const int64_t one = 1;
+    float obj = 0.f;
+    return encode_host(c, "lsq_encoding_icm", X, oldB, K, d, n, m, h, &one, 1, niter, npert, randord, seed, it, global_offset, 0, outB, &obj);
+}
+
+// upload helpers for the fine-grained entry points
+static int upload_xk(lsq_ctx *c, const float *X, const float *K, int d, int64_t n, int m) {
+    const size_t kbytes = sizeof(float) * (size_t)m * LSQ_H * d;
+    LSQ_TRY(c->sK.ensure(kbytes));
+    LSQ_HIP(hipMemcpyAsync(c->sK.p, K, kbytes, hipMemcpyHostToDevice, c->stream));
+    if (X) {
+        LSQ_TRY(c->sX.ensure(sizeof(float) * (size_t)std::max<int64_t>(n, 1) * d));
+        if (n > 0) LSQ_HIP(hipMemcpyAsync(c->sX.p, X, sizeof(float) * (size_t)n * d, hipMemcpyHostToDevice, c->stream));
+    }
+    return LSQ_OK;
+}
+
+static int upload_codes(lsq_ctx *c, const int16_t *B, int64_t n, int m, int h, DevBuf &rec) {
+    LSQ_TRY(c->sB16.ensure(sizeof(int16_t) * (size_t)std::max<int64_t>(n, 1) * m));
+    LSQ_TRY(rec.ensure((size_t)std::max<int64_t>(n, 1) * lsq_code_stride(m)));
+    LSQ_TRY(c->bad.ensure(sizeof(int)));
+    LSQ_HIP(hipMemsetAsync(c->bad.p, 0, sizeof(int), c->stream));
+    if (n > 0) {
+        LSQ_HIP(hipMemcpyAsync(c->sB16.p, B, sizeof(int16_t) * (size_t)n * m, hipMemcpyHostToDevice, c->stream));
+        LSQ_TRY(lsq_launch_codes_from_i16(c->stream, c->sB16.as<int16_t>(), n, m, h, rec.as<uint8_t>(), c->bad.as<int>()));
+    }
+    int bad = 0;
+    LSQ_HIP(hipMemcpyAsync(&bad, c->bad.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    LSQ_HIP(hipStreamSynchronize(c->stream));
+    if (bad) { lsq_set_error("input codes must lie in 1..%d", h); return LSQ_ECODE; }
+    return LSQ_OK;
+}
+
+extern "C" int lsq_encode_icm_fully(lsq_ctx *c, int16_t *B, const float *X, const float *K, int d, int64_t n, int m, int h, int niter,
+                                    int randord, int npert, int64_t idx_first, uint64_t seed, uint32_t it) {
+    LSQ_TRY(use_device(c));
+    LSQ_TRY(check_shape("lsq_encode_icm_fully", d, n, m, h));
+    if (!K || niter < 0 || npert < 0 || idx_first < 1 || (n > 0 && (!B || !X))) { lsq_set_error("lsq_encode_icm_fully: bad arguments"); return LSQ_EINVAL; }
+    if (n == 0) return LSQ_OK;
+    if (n > c->chunk) { lsq_set_error("lsq_encode_icm_fully: n = %lld exceeds the resident chunk (%lld); raise option \"chunk\"", (long long)n, (long long)c->chunk); return LSQ_EINVAL; }
+    LSQ_TRY(upload_xk(c, X, K, d, n, m));
+    LSQ_TRY(upload_codes(c, B, n, m, h, c->recCur));
+    LSQ_TRY(prepare_tables(c, c->sK.as<float>(), d, m));
+    LSQ_TRY(build_unaries(c, c->sX.as<float>(), c->sK.as<float>(), d, n, m));
+    LSQ_TRY(c->recNew.ensure((size_t)n * lsq_code_stride(m)));
+    int32_t order[LSQ_MAX_M];
+    LSQ_TRY(lsq_node_order(seed, it, m, randord, order));
+    LSQ_TRY(lsq_launch_perturb(c->stream, c->recCur.as<uint8_t>(), c->recNew.as<uint8_t>(), n, m, npert, seed, it, (uint64_t)(idx_first - 1)));
+    LSQ_TRY(run_sweeps(c, c->recNew.as<uint8_t>(), n, m, order, niter));
+    LSQ_TRY(lsq_launch_codes_to_i16(c->stream, c->recNew.as<uint8_t>(), n, m, c->sB16.as<int16_t>()));
+    LSQ_HIP(hipMemcpyAsync(B, c->sB16.p, sizeof(int16_t) * (size_t)n * m, hipMemcpyDeviceToHost, c->stream));
+    LSQ_HIP(hipStreamSynchronize(c->stream));
+    return LSQ_OK;
+}
+
+extern "C" int lsq_get_unaries(lsq_ctx *c, const float *X, const float *K, int d, int64_t n, int m, int h, float *U) {
+    LSQ_TRY(use_device(c));
+    LSQ_TRY(check_shape("lsq_get_unaries", d, n, m, h));
+    if (!K || (n > 0 && (!X || !U))) { lsq_set_error("lsq_get_unaries: null pointer"); return LSQ_EINVAL; }
+    if (n == 0) return LSQ_OK;
+    LSQ_TRY(upload_xk(c, X, K, d, n, m));
+    LSQ_TRY(c->sci.ensure(sizeof(float) * (size_t)m * LSQ_H));
+    LSQ_TRY(lsq_launch_sqnorms(c->stream, c->sK.as<float>(), m * LSQ_H, d, c->sci.as<float>()));
+    LSQ_TRY(build_unaries(c, c->sX.as<float>(), c->sK.as<float>(), d, n, m));
+    LSQ_HIP(hipMemcpyAsync(U, c->U.p, sizeof(float) * (size_t)m * n * LSQ_H, hipMemcpyDeviceToHost, c->stream));
+    LSQ_HIP(hipStreamSynchronize(c->stream));
+    return LSQ_OK;
+}
+
+extern "C" int lsq_get_binaries(lsq_ctx *c, const float *K, int d, int m, int h, float *T) {
+    LSQ_TRY(use_device(c));
+    LSQ_TRY(check_shape("lsq_get_binaries", d, 0, m, h));
+    if (!K || !T) { lsq_set_error("lsq_get_binaries: null pointer"); return LSQ_EINVAL; }
+    LSQ_TRY(upload_xk(c, nullptr, K, d, 0, m));
+    LSQ_TRY(prepare_tables(c, c->sK.as<float>(), d, m));
+    LSQ_HIP(hipMemcpyAsync(T, c->T.p, sizeof(float) * (size_t)m * m * LSQ_H * LSQ_H, hipMemcpyDeviceToHost, c->stream));
+    LSQ_HIP(hipStreamSynchronize(c->stream));
+    return LSQ_OK;
+}
+
+extern "C" int lsq_veccost(lsq_ctx *c, const float *X, const int16_t *B, const float *K, int d, int64_t n, int m, int h, float *cost) {
+    LSQ_TRY(use_device(c));
+    LSQ_TRY(check_shape("lsq_veccost", d, n, m, h));
+    if (!K || (n > 0 && (!X || !B || !cost))) { lsq_set_error("lsq_veccost: null pointer"); return LSQ_EINVAL; }
+    if (n == 0) return LSQ_OK;
+    LSQ_TRY(upload_xk(c, X, K, d, n, m));
+    LSQ_TRY(upload_codes(c, B, n, m, h, c->recCur));
+    LSQ_TRY(c->prev.ensure(sizeof(float) * (size_t)n));
+    LSQ_TRY(lsq_launch_cost(c->stream, c->sX.as<float>(), c->sK.as<float>(), c->recCur.as<uint8_t>(), c->recCur.as<uint8_t>(),
+                            c->prev.as<float>(), nullptr, n, d, m, 0));
+    LSQ_HIP(hipMemcpyAsync(cost, c->prev.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    LSQ_HIP(hipStreamSynchronize(c->stream));
+    return LSQ_OK;
+}
+
+extern "C" int lsq_qerror(lsq_ctx *c, const float *X, const int16_t *B, const float *K, int d, int64_t n, int m, int h, double *out) {
+    LSQ_TRY(use_device(c));
+    LSQ_TRY(check_shape("lsq_qerror", d, n, m, h));
+    if (!out || !K || (n > 0 && (!X || !B))) { lsq_set_error("lsq_qerror: null pointer"); return LSQ_EINVAL; }
+    *out = 0.0;
+    if (n == 0) return LSQ_OK;
+    LSQ_TRY(upload_xk(c, X, K, d, n, m));
+    LSQ_TRY(upload_codes(c, B, n, m, h, c->recCur));
+    LSQ_TRY(c->prev.ensure(sizeof(float) * (size_t)n));
+    LSQ_TRY(c->obj.ensure(sizeof(double)));
+    LSQ_HIP(hipMemsetAsync(c->obj.p, 0, sizeof(double), c->stream));
+    LSQ_TRY(lsq_launch_cost(c->stream, c->sX.as<float>(), c->sK.as<float>(), c->recCur.as<uint8_t>(), c->recCur.as<uint8_t>(),
+                            c->prev.as<float>(), nullptr, n, d, m, 0));
+    LSQ_TRY(lsq_launch_sum_f64(c->stream, c->prev.as<float>(), n, c->obj.as<double>()));
+    double sum = 0.0;
+    LSQ_HIP(hipMemcpyAsync(&sum, c->obj.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    LSQ_HIP(hipStreamSynchronize(c->stream));
+    *out = sum / (double)n;
+    return LSQ_OK;
+}
+
+extern "C" int lsq_perturb(lsq_ctx *c, int16_t *B, int64_t n, int m, int h, int npert, uint64_t seed, uint32_t it, uint64_t global_offset) {
+    LSQ_TRY(use_device(c));
+    LSQ_TRY(check_shape("lsq_perturb", 1, n, m, h));
+    if (npert < 0 || (n > 0 && !B)) { lsq_set_error("lsq_perturb: bad arguments"); return LSQ_EINVAL; }
+    if (n == 0) return LSQ_OK;
+    LSQ_TRY(upload_codes(c, B, n, m, h, c->recCur));
+    LSQ_TRY(c->recNew.ensure((size_t)n * lsq_code_stride(m)));
+    LSQ_TRY(lsq_launch_perturb(c->stream, c->recCur.as<uint8_t>(), c->recNew.as<uint8_t>(), n, m, npert, seed, it, global_offset));
+    LSQ_TRY(lsq_launch_codes_to_i16(c->stream, c->recNew.as<uint8_t>(), n, m, c->sB16.as<int16_t>()));
+    LSQ_HIP(hipMemcpyAsync(B, c->sB16.p, sizeof(int16_t) * (size_t)n * m, hipMemcpyDeviceToHost, c->stream));
+    LSQ_HIP(hipStreamSynchronize(c->stream));
+    return LSQ_OK;
+}
+
+// ---- device-side generators ---------------------------------------------------------------------
+extern "C" int lsq_synth_data_u8_dev(lsq_ctx *c, uint64_t seed, uint64_t global_offset, int64_t n, int d, float *dX) {
+    LSQ_TRY(use_device(c));
+    if (n < 0 || d < 1 || (n > 0 && !dX)) { lsq_set_error("lsq_synth_data_u8_dev: bad arguments"); return LSQ_EINVAL; }
+    return lsq_launch_synth_data_u8(c->stream, seed, global_offset, n, d, dX);
+}
+extern "C" int lsq_randinit_dev(lsq_ctx *c, uint64_t seed, uint64_t global_offset, int64_t n, int m, int h, uint8_t *dB) {
+    LSQ_TRY(use_device(c));
+    if (n < 0 || m < 1 || h < 1 || h > 256 || (n > 0 && !dB)) { lsq_set_error("lsq_randinit_dev: bad arguments"); return LSQ_EINVAL; }
+    return lsq_launch_randinit(c->stream, seed, global_offset, n, m, h, dB);
+}
+extern "C" int lsq_synth_codebooks_dev(lsq_ctx *c, uint64_t seed, int m, int h, int d, float *dK) {
+    LSQ_TRY(use_device(c));
+    if (m < 1 || h < 1 || d < 1 || !dK) { lsq_set_error("lsq_synth_codebooks_dev: bad arguments"); return LSQ_EINVAL; }
+    return lsq_launch_synth_codebooks(c->stream, seed, m, h, d, dK);
+}

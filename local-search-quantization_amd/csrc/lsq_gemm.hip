@@ -1,0 +1,160 @@
+// lsq_gemm.hip -- chain-exact fp32 contraction on the gfx950 matrix cores.
+//
+// Serves the two table builds of the hot path:
+//   get_unaries  (reference src/utils.jl:94-122):  U_j = (-2 C_j') X + ||c||^2
+//   get_binaries (reference src/utils.jl:125-144): Bin = 2 C_i' C_j   (all ordered pairs)
+//
+// Numerics contract (oracle/lsq_oracle.c [build-defined 1]): every output element is the
+// k-ASCENDING fmaf chain from +0 of its d products, then (optionally) one rounded add.
+// v_mfma_f32_32x32x2_f32 computes exactly that chain (two k per instruction, k0 then k1, one
+// rounding per product, no wider accumulation), so stepping k in ascending order through one
+// accumulator reproduces the oracle bit for bit.  fp32 MFMA runs at the fp32 vector rate
+// (157 TF peak) -- this is the right unit for an exact-f32 contraction; nothing is reshaped into
+// a lower precision.
+//
+// Tiling: 256 threads = 4 waves (2x2), block tile 128 rows x 128 cols, K chunk 32 staged in LDS
+// (row stride 33 floats -> the per-k column reads are bank-conflict-free).  Each wave owns a
+// 64x64 sub-tile = 2x2 MFMA 32x32 accumulators (64 VGPRs).  The MFMA M dimension carries the
+// ROWS of A (vectors) and N the candidates, so for a fixed accumulator register a wave stores
+// two 128-byte runs of consecutive candidates -- full-line writes of the 8 KB/vector unary rows.
+// Block -> tile mapping is XCD-aware: the col tiles that share one 128-row A panel run on the
+// same XCD (block b sits on XCD b % 8), so the panel is fetched from HBM once and re-served by
+// that XCD's L2.
+#include "lsq_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32, LD = BK + 1;
+
+template <bool VEC4>
+__device__ inline void stage_tile(const float *__restrict__ src, int64_t rows_total, int64_t row0, int Kd, int k0,
+                                  float scale, float *__restrict__ dst, int tid) {
+    // 128 rows x 32 k -> 1024 float4 slots, 4 per thread
+#pragma unroll
+    for (int e = tid; e < BM * BK / 4; e += 256) {
+        const int r = e >> 3, q = e & 7;
+        const int64_t gr = row0 + r;
+        const int kk = k0 + 4 * q;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        if (gr < rows_total) {
+            const float *p = src + gr * (int64_t)Kd + kk;
+            if (VEC4 && kk + 3 < Kd) {
+                const float4 v = *reinterpret_cast<const float4 *>(p);
+                v0 = v.x; v1 = v.y; v2 = v.z; v3 = v.w;
+            } else {
+                if (kk + 0 < Kd) v0 = p[0];
+                if (kk + 1 < Kd) v1 = p[1];
+                if (kk + 2 < Kd) v2 = p[2];
+                if (kk + 3 < Kd) v3 = p[3];
+            }
+        }
+        float *o = dst + r * LD + 4 * q;
+        o[0] = v0 * scale; o[1] = v1 * scale; o[2] = v2 * scale; o[3] = v3 * scale;   // scale is +-2 or 1: exact
+    }
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void chain_gemm_kernel(const float *__restrict__ A, const float *__restrict__ Bm,
+                                                         const float *__restrict__ addv, float alpha, int64_t M, int N,
+                                                         int Kd, int h, int64_t plane_stride, int64_t row_stride,
+                                                         float *__restrict__ D, int64_t row_tiles, int col_tiles) {
+    __shared__ float As[BM * LD];
+    __shared__ float Bs[BN * LD];
+
+    const int64_t b = blockIdx.x;
+    const int xcd = (int)(b & 7);
+    const int64_t s = b >> 3;
+    const int64_t rt = (s / col_tiles) * 8 + xcd;
+    const int ct = (int)(s % col_tiles);
+    if (rt >= row_tiles) return;
+    const int64_t row0 = rt * BM;
+    const int col0 = ct * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wy = wave >> 1, wx = wave & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    for (int k0 = 0; k0 < Kd; k0 += BK) {
+        stage_tile<VEC4>(A, M, row0, Kd, k0, 1.0f, As, tid);
+        stage_tile<VEC4>(Bm, N, col0, Kd, k0, alpha, Bs, tid);
+        __syncthreads();
+        const int kend = (Kd - k0 < BK) ? ((Kd - k0 + 1) & ~1) : BK;   // odd tail: one zero product appended
+        const float *ap = As + (wy * 64 + l31) * LD + lhi;
+        const float *bp = Bs + (wx * 64 + l31) * LD + lhi;
+        for (int kk = 0; kk < kend; kk += 2) {
+            const float a0 = ap[kk], a1 = ap[32 * LD + kk];
+            const float b0 = bp[kk], b1 = bp[32 * LD + kk];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+        const int c = col0 + wx * 64 + tj * 32 + l31;
+        if (c >= N) continue;
+        const float add = addv ? addv[c] : 0.0f;
+        const int64_t coff = (int64_t)(c / h) * plane_stride + (c % h);
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = row0 + wy * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (row < M) {
+                    float v = acc[ti][tj][r];
+                    if (addv) v = v + add;           // one rounded add (utils.jl:112-118)
+                    D[coff + row * row_stride] = v;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void sqnorms_kernel(const float *__restrict__ Kb, int rows, int d, float *__restrict__ sci) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float *p = Kb + (int64_t)r * d;
+    float acc = 0.0f;
+    for (int t = 0; t < d; ++t) acc = fmaf(p[t], p[t], acc);
+    sci[r] = acc;
+}
+
+}  // namespace
+
+int lsq_launch_chain_gemm(hipStream_t s, const float *A, const float *Bm, const float *addv, float alpha, int64_t M,
+                          int N, int Kd, int h, int64_t plane_stride, int64_t row_stride, float *D) {
+    if (M <= 0 || N <= 0) return LSQ_OK;
+    const int64_t row_tiles = (M + BM - 1) / BM;
+    const int col_tiles = (N + BN - 1) / BN;
+    const int64_t blocks = ((row_tiles + 7) / 8) * 8 * col_tiles;
+    if (blocks > 0x7fffffffLL) { lsq_set_error("chain_gemm: grid too large"); return LSQ_EINVAL; }
+    const bool vec4 = (Kd % 4 == 0) && (((uintptr_t)A | (uintptr_t)Bm) % 16 == 0);
+    if (vec4)
+        hipLaunchKernelGGL(chain_gemm_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
+                           plane_stride, row_stride, D, row_tiles, col_tiles);
+    else
+        hipLaunchKernelGGL(chain_gemm_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
+                           plane_stride, row_stride, D, row_tiles, col_tiles);
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}
+
+int lsq_launch_sqnorms(hipStream_t s, const float *Kb, int rows, int d, float *sci) {
+    if (rows <= 0) return LSQ_OK;
+    hipLaunchKernelGGL(sqnorms_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, Kb, rows, d, sci);
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}

@@ -1,0 +1,452 @@
+// lsq_icm.hip -- the ILS/ICM encoder kernels for gfx950 (wave64, one wave per vector).
+//
+// Replaces (does NOT translate) the reference's CUDA kernels src/encodings/cuda/cudautils.cu:
+//   condition_icm3 (:236-339)  -> icm_node_kernel / icm_fused_kernel
+//   perturb        (:27-80)    -> perturb_kernel   (Philox counter RNG, no state buffer)
+//   veccost2       (:145-183)  -> cost_kernel      (fused with the accept rule)
+//   setup_kernel / vec_add     -> gone (counter-based RNG; ||c||^2 is the GEMM epilogue)
+// Semantics follow the reference CPU path (src/encodings/encode_icm.jl), restated in
+// oracle/lsq_oracle.c: conditioning adds in ascending k (plain f32 adds), argmin = LOWEST index
+// of the minimum (the reference CUDA tree reduction is not -- SURVEY 2b), accept iff strictly
+// better.
+//
+// Data layout in HBM:
+//   U   [m][n][256] f32   unary rows; U_j[i] is one 1 KiB wave load (float4 per lane)
+//   T   [m][m][256][256] f32; T[j][k][b][:] = the 1 KiB column added to node j when codebook k
+//       holds code b.  Block-row j (all k, b) is ONE contiguous 256 KiB*m region, so the live set
+//       of a node-j launch is (m-1) x 256 KiB, L2-resident per XCD (1.75 MiB at m = 8).
+//   rec [n][cs] u8        code records, cs = 8 (m <= 8) or 16: one aligned 8/16-byte load
+//   X   [n][d] f32,  K [m*256][d] f32  (the Julia buffers, read in place)
+//
+// One wave = one vector: lane l owns candidates 4l..4l+3; a table column or unary row is exactly
+// one coalesced `global_load_dwordx4`.  The wave-level argmin is a 6-step DPP min + one ballot.
+#include "lsq_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// ---- wave64 cross-lane helpers (DPP; no LDS traffic) -------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ inline float dpp_self(float v) {          // disabled lanes keep their own value
+    const int iv = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(iv, iv, CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ inline float dpp_zero(float v) {          // disabled lanes receive +0
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+
+enum { DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140, DPP_BCAST15 = 0x142, DPP_BCAST31 = 0x143 };
+
+// minimum over the 64 lanes (NaN-ignoring, like the reference's strict-< scan), wave-uniform result
+__device__ inline float wave_min(float v) {
+    v = fminf(v, dpp_self<DPP_XOR1, 0xf>(v));
+    v = fminf(v, dpp_self<DPP_XOR2, 0xf>(v));
+    v = fminf(v, dpp_self<DPP_HALF_MIRROR, 0xf>(v));
+    v = fminf(v, dpp_self<DPP_MIRROR, 0xf>(v));
+    v = fminf(v, dpp_self<DPP_BCAST15, 0xa>(v));
+    v = fminf(v, dpp_self<DPP_BCAST31, 0xc>(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// sum over the 64 lanes as a balanced pairwise tree, adjacent pairs first -- the exact order
+// of oracle cost_one() ([build-defined 2]); f32 add is commutative so the mirrored DPP sources
+// give the same bits.  Result valid in lane 63, returned wave-uniform.
+__device__ inline float wave_sum_tree(float v) {
+    v = v + dpp_self<DPP_XOR1, 0xf>(v);
+    v = v + dpp_self<DPP_XOR2, 0xf>(v);
+    v = v + dpp_self<DPP_HALF_MIRROR, 0xf>(v);
+    v = v + dpp_self<DPP_MIRROR, 0xf>(v);
+    v = v + dpp_zero<DPP_BCAST15, 0xa>(v);
+    v = v + dpp_zero<DPP_BCAST31, 0xc>(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+__device__ inline uint64_t readfirstlane64(uint64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+struct CodeRec {           // wave-uniform code record (lives in SGPRs)
+    uint64_t lo, hi;
+    __device__ inline uint32_t get(int k) const { return (uint32_t)((k < 8 ? lo >> (8 * k) : hi >> (8 * (k - 8))) & 0xffu); }
+    __device__ inline void set(int k, uint32_t v) {
+        if (k < 8) lo = (lo & ~(0xffull << (8 * k))) | ((uint64_t)v << (8 * k));
+        else       hi = (hi & ~(0xffull << (8 * (k - 8)))) | ((uint64_t)v << (8 * (k - 8)));
+    }
+};
+
+template <int CS>
+__device__ inline CodeRec load_rec(const uint8_t *rec, int64_t i) {
+    CodeRec r;
+    const uint64_t *p = reinterpret_cast<const uint64_t *>(rec + i * CS);
+    r.lo = readfirstlane64(p[0]);
+    r.hi = (CS == 16) ? readfirstlane64(p[1]) : 0ull;
+    return r;
+}
+
+// lowest index of the minimum of the wave's 256 conditioned values (encode_icm.jl:105-119)
+__device__ inline int wave_first_argmin(f32x4 s, int lane) {
+    const float lm = fminf(fminf(s.x, s.y), fminf(s.z, s.w));
+    const float wm = wave_min(lm);
+    const int inl = (s.x == wm) ? 0 : (s.y == wm) ? 1 : (s.z == wm) ? 2 : 3;
+    const uint64_t mask = __ballot(lm == wm);
+    int best = 0;
+    if (mask != 0) {
+        const int L = __builtin_ctzll(mask);
+        best = 4 * L + __builtin_amdgcn_readlane(inl, L);
+    }
+    // strict '<' scan semantics: if s[0] is NaN nothing ever replaces it
+    const float s0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s.x)));
+    if (s0 != s0) best = 0;
+    (void)lane;
+    return best;
+}
+
+// ---- ICM node update, one launch per node (schedule 0) -----------------------------------------
+// Streams U_j (1 KiB/vector, non-temporal) from HBM, gathers (M-1) 1 KiB columns of block-row j
+// from L2, writes one code byte.  encode_icm.jl:76-119 for all vectors of the chunk.
+template <int M>
+__global__ __launch_bounds__(256) void icm_node_kernel(const float *__restrict__ Uj, const float *__restrict__ Tj,
+                                                       uint8_t *__restrict__ rec, int64_t n, int j) {
+    constexpr int CS = (M <= 8) ? 8 : 16;
+    const int lane = threadIdx.x & 63;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    int64_t i = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    for (; i < n; i += nwaves) {
+        const CodeRec cr = load_rec<CS>(rec, i);
+        f32x4 s = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(Uj + i * LSQ_H) + lane);
+        f32x4 c[M > 1 ? M - 1 : 1];
+#pragma unroll
+        for (int kk = 0; kk < M - 1; ++kk) {
+            const int k = kk + (kk >= j ? 1 : 0);
+            const float *col = Tj + ((int64_t)(k * LSQ_H) + cr.get(k)) * LSQ_H;
+            c[kk] = reinterpret_cast<const f32x4 *>(col)[lane];
+        }
+#pragma unroll
+        for (int kk = 0; kk < M - 1; ++kk) s = s + c[kk];      // ascending k, plain f32 adds
+        const int best = wave_first_argmin(s, lane);
+        if (lane == 0) rec[i * CS + j] = (uint8_t)best;
+    }
+}
+
+// ---- fused sweeps (schedule 1): unaries register-resident, all nsweeps*M node updates ---------
+struct NodeOrder { int v[LSQ_MAX_M]; };
+
+template <int M, int J>
+__device__ inline void fused_node(const f32x4 (&u)[M], const float *__restrict__ T, CodeRec &cr, int lane) {
+    f32x4 s = u[J];
+    f32x4 c[M > 1 ? M - 1 : 1];
+    const float *Tj = T + (int64_t)J * M * LSQ_H * LSQ_H;
+#pragma unroll
+    for (int kk = 0; kk < M - 1; ++kk) {
+        constexpr int dummy = 0; (void)dummy;
+        const int k = kk + (kk >= J ? 1 : 0);
+        const float *col = Tj + ((int64_t)(k * LSQ_H) + cr.get(k)) * LSQ_H;
+        c[kk] = reinterpret_cast<const f32x4 *>(col)[lane];
+    }
+#pragma unroll
+    for (int kk = 0; kk < M - 1; ++kk) s = s + c[kk];
+    cr.set(J, (uint32_t)wave_first_argmin(s, lane));
+}
+
+template <int M, int J>
+struct FusedDispatch {
+    __device__ static inline void run(int j, const f32x4 (&u)[M], const float *T, CodeRec &cr, int lane) {
+        if (j == J) fused_node<M, J>(u, T, cr, lane);
+        else FusedDispatch<M, J + 1>::run(j, u, T, cr, lane);
+    }
+};
+template <int M>
+struct FusedDispatch<M, M> {
+    __device__ static inline void run(int, const f32x4 (&)[M], const float *, CodeRec &, int) {}
+};
+
+template <int M>
+__global__ __launch_bounds__(256) void icm_fused_kernel(const float *__restrict__ U, const float *__restrict__ T,
+                                                        uint8_t *__restrict__ rec, int64_t n, NodeOrder order, int nsweeps) {
+    constexpr int CS = (M <= 8) ? 8 : 16;
+    const int lane = threadIdx.x & 63;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    int64_t i = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    for (; i < n; i += nwaves) {
+        CodeRec cr = load_rec<CS>(rec, i);
+        f32x4 u[M];
+#pragma unroll
+        for (int j = 0; j < M; ++j)
+            u[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(U + ((int64_t)j * n + i) * LSQ_H) + lane);
+        for (int sw = 0; sw < nsweeps; ++sw)
+#pragma unroll 1
+            for (int q = 0; q < M; ++q) FusedDispatch<M, 0>::run(order.v[q], u, T, cr, lane);
+        if (lane == 0) {
+            uint64_t *p = reinterpret_cast<uint64_t *>(rec + i * CS);
+            p[0] = cr.lo;
+            if (CS == 16) p[1] = cr.hi;
+        }
+    }
+}
+
+// ---- perturbation (cudautils.cu:27-80 / encode_icm.jl:55-70), one thread per vector ------------
+template <int CS>
+__global__ __launch_bounds__(256) void perturb_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int64_t n,
+                                                      int m, int npert, uint64_t seed, uint32_t it, uint64_t goff) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t w[2];
+    const uint64_t *p = reinterpret_cast<const uint64_t *>(src + i * CS);
+    w[0] = p[0];
+    w[1] = (CS == 16) ? p[1] : 0ull;
+    int need = npert < m ? npert : m;
+    const uint64_t gi = goff + (uint64_t)i;
+    lsq_u32x4 sel = {{0, 0, 0, 0}};
+    for (int pp = 0; pp < m && need > 0; ++pp) {
+        if ((pp & 3) == 0) sel = lsq_rng_block(seed, gi, it, LSQ_DOM_PERTURB, (uint32_t)(pp >> 2));
+        const uint32_t r = sel.v[pp & 3];
+        if (lsq_mulhi32(r, (uint32_t)(m - pp)) < (uint32_t)need) {
+            const uint32_t rv = lsq_rng_word(seed, gi, it, LSQ_DOM_PERTURB, (uint32_t)(16 + pp));
+            const uint64_t val = lsq_mulhi32(rv, LSQ_H);
+            const int sh = 8 * (pp & 7);
+            w[pp >> 3] = (w[pp >> 3] & ~(0xffull << sh)) | (val << sh);
+            --need;
+        }
+    }
+    uint64_t *q = reinterpret_cast<uint64_t *>(dst + i * CS);
+    q[0] = w[0];
+    if (CS == 16) q[1] = w[1];
+}
+
+// ---- cost (+ accept) ----------------------------------------------------------------------------
+// utils.jl:225-254 per vector, reduction order = oracle cost_one(); mode 1 applies
+// encode_icm.jl:178-186 (keep the new codes iff strictly better) and counts ==/< .
+template <int CS>
+__global__ __launch_bounds__(256) void cost_kernel(const float *__restrict__ X, const float *__restrict__ K,
+                                                   const uint8_t *__restrict__ rec, uint8_t *__restrict__ cur,
+                                                   float *__restrict__ prev, unsigned long long *__restrict__ counters,
+                                                   int64_t n, int d, int m, int mode) {
+    const int lane = threadIdx.x & 63;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    int64_t i = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    unsigned n_eq = 0, n_lt = 0;
+    for (; i < n; i += nwaves) {
+        const CodeRec cr = load_rec<CS>(rec, i);
+        const float *x = X + i * (int64_t)d;
+        float part = 0.0f;
+        for (int t = lane; t < d; t += 64) {
+            float cb = 0.0f;
+            for (int k = 0; k < m; ++k) cb = cb + K[((int64_t)(k * LSQ_H) + cr.get(k)) * d + t];
+            const float r = cb - x[t];
+            const float sq = r * r;
+            part = part + sq;
+        }
+        const float cost = wave_sum_tree(part);
+        if (mode == 0) {
+            if (lane == 0) prev[i] = cost;
+        } else {
+            const float pc = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(prev[i])));
+            n_eq += (cost == pc);
+            if (cost < pc) {
+                ++n_lt;
+                if (lane == 0) {
+                    prev[i] = cost;
+                    uint64_t *q = reinterpret_cast<uint64_t *>(cur + i * CS);
+                    q[0] = cr.lo;
+                    if (CS == 16) q[1] = cr.hi;
+                }
+            }
+        }
+    }
+    if (mode == 1 && lane == 0 && (n_eq | n_lt)) {
+        if (n_eq) atomicAdd(&counters[0], (unsigned long long)n_eq);
+        if (n_lt) atomicAdd(&counters[1], (unsigned long long)n_lt);
+    }
+}
+
+__global__ __launch_bounds__(256) void sum_f64_kernel(const float *__restrict__ v, int64_t n, double *__restrict__ sum) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) acc += (double)v[i];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(sum, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+// ---- layout conversion ---------------------------------------------------------------------------
+template <int CS>
+__global__ __launch_bounds__(256) void codes_expand_kernel(const uint8_t *__restrict__ tight, int64_t n, int m, uint8_t *__restrict__ rec) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t w[2] = {0ull, 0ull};
+    for (int j = 0; j < m; ++j) w[j >> 3] |= (uint64_t)tight[i * m + j] << (8 * (j & 7));
+    uint64_t *q = reinterpret_cast<uint64_t *>(rec + i * CS);
+    q[0] = w[0];
+    if (CS == 16) q[1] = w[1];
+}
+template <int CS>
+__global__ __launch_bounds__(256) void codes_compact_kernel(const uint8_t *__restrict__ rec, int64_t n, int m, uint8_t *__restrict__ tight) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int j = 0; j < m; ++j) tight[i * m + j] = rec[i * CS + j];
+}
+template <int CS>
+__global__ __launch_bounds__(256) void codes_from_i16_kernel(const int16_t *__restrict__ B, int64_t n, int m, int h,
+                                                             uint8_t *__restrict__ rec, int *__restrict__ bad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t w[2] = {0ull, 0ull};
+    for (int j = 0; j < m; ++j) {
+        const int v = (int)B[i * m + j];
+        if (v < 1 || v > h) { *bad = 1; continue; }
+        w[j >> 3] |= (uint64_t)(v - 1) << (8 * (j & 7));
+    }
+    uint64_t *q = reinterpret_cast<uint64_t *>(rec + i * CS);
+    q[0] = w[0];
+    if (CS == 16) q[1] = w[1];
+}
+template <int CS>
+__global__ __launch_bounds__(256) void codes_to_i16_kernel(const uint8_t *__restrict__ rec, int64_t n, int m, int16_t *__restrict__ B) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int j = 0; j < m; ++j) B[i * m + j] = (int16_t)(rec[i * CS + j] + 1);
+}
+
+// ---- synthetic generators (benchmark harness; mirrored by the oracle) -----------------------------
+__global__ __launch_bounds__(256) void synth_data_u8_kernel(uint64_t seed, uint64_t goff, int64_t n, int d, float *__restrict__ X) {
+    // one thread per 4 consecutive t (one Philox block)
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int d4 = (d + 3) >> 2;
+    if (q >= n * d4) return;
+    const int64_t i = q / d4;
+    const int t0 = (int)(q % d4) * 4;
+    const lsq_u32x4 r = lsq_rng_block(seed, goff + (uint64_t)i, (uint32_t)(t0 >> 10), LSQ_DOM_DATA, (uint32_t)((t0 & 1023) >> 2));
+    for (int e = 0; e < 4 && t0 + e < d; ++e) X[i * (int64_t)d + t0 + e] = (float)(r.v[e] >> 24);
+}
+__global__ __launch_bounds__(256) void randinit_kernel(uint64_t seed, uint64_t goff, int64_t n, int m, int h, uint8_t *__restrict__ tight) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int j = 0; j < m; ++j)
+        tight[i * m + j] = (uint8_t)lsq_mulhi32(lsq_rng_word(seed, goff + (uint64_t)i, 0, LSQ_DOM_INIT, (uint32_t)j), (uint32_t)h);
+}
+__global__ __launch_bounds__(256) void synth_codebooks_kernel(uint64_t seed, int m, int h, int d, float *__restrict__ K) {
+    // codeword (j,a) = (1/m) * synthetic data vector number pick(j,a) of the stream (seed ^ 0x5bd1e995)
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (int64_t)m * h * d) return;
+    const int64_t row = q / d;
+    const int t = (int)(q % d);
+    const uint64_t pick = lsq_rng_word(seed, (uint64_t)row, 0, LSQ_DOM_CODEBOOK, 0);
+    const uint32_t w = lsq_rng_word(seed ^ 0x5bd1e995ull, pick, (uint32_t)(t >> 10), LSQ_DOM_DATA, (uint32_t)(t & 1023));
+    K[q] = (float)(w >> 24) / (float)m;
+}
+
+inline unsigned wave_grid(int64_t n) {      // persistent grid: 4 waves per block, <= 8 blocks per CU on 256 CUs
+    int64_t blocks = (n + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+inline unsigned thread_grid(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+#define LSQ_DISPATCH_M(m, EXPR)                                                              \
+    switch (m) {                                                                             \
+        case 1: { constexpr int M_ = 1; EXPR; } break;   case 2: { constexpr int M_ = 2; EXPR; } break;   \
+        case 3: { constexpr int M_ = 3; EXPR; } break;   case 4: { constexpr int M_ = 4; EXPR; } break;   \
+        case 5: { constexpr int M_ = 5; EXPR; } break;   case 6: { constexpr int M_ = 6; EXPR; } break;   \
+        case 7: { constexpr int M_ = 7; EXPR; } break;   case 8: { constexpr int M_ = 8; EXPR; } break;   \
+        case 9: { constexpr int M_ = 9; EXPR; } break;   case 10: { constexpr int M_ = 10; EXPR; } break; \
+        case 11: { constexpr int M_ = 11; EXPR; } break; case 12: { constexpr int M_ = 12; EXPR; } break; \
+        case 13: { constexpr int M_ = 13; EXPR; } break; case 14: { constexpr int M_ = 14; EXPR; } break; \
+        case 15: { constexpr int M_ = 15; EXPR; } break; case 16: { constexpr int M_ = 16; EXPR; } break; \
+        default: lsq_set_error("m = %d out of range 1..16", m); return LSQ_EINVAL;          \
+    }
+
+int lsq_launch_icm_node(hipStream_t s, const float *Uj, const float *T, uint8_t *rec, int64_t n, int m, int j) {
+    if (n <= 0) return LSQ_OK;
+    const float *Tj = T + (int64_t)j * m * LSQ_H * LSQ_H;
+    LSQ_DISPATCH_M(m, hipLaunchKernelGGL(icm_node_kernel<M_>, dim3(wave_grid(n)), dim3(256), 0, s, Uj, Tj, rec, n, j));
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}
+
+int lsq_launch_icm_fused(hipStream_t s, const float *U, const float *T, uint8_t *rec, int64_t n, int m,
+                         const int32_t *order_host, int nsweeps) {
+    if (n <= 0) return LSQ_OK;
+    NodeOrder o;
+    for (int q = 0; q < LSQ_MAX_M; ++q) o.v[q] = q < m ? order_host[q] : 0;
+    LSQ_DISPATCH_M(m, hipLaunchKernelGGL(icm_fused_kernel<M_>, dim3(wave_grid(n)), dim3(256), 0, s, U, T, rec, n, o, nsweeps));
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}
+
+#define LSQ_CS_LAUNCH(m, KERNEL, GRID, ...)                                                        \
+    do {                                                                                           \
+        if (lsq_code_stride(m) == 8) hipLaunchKernelGGL(KERNEL<8>, dim3(GRID), dim3(256), 0, s, __VA_ARGS__);  \
+        else hipLaunchKernelGGL(KERNEL<16>, dim3(GRID), dim3(256), 0, s, __VA_ARGS__);             \
+        LSQ_HIP(hipGetLastError());                                                                \
+    } while (0)
+
+int lsq_launch_perturb(hipStream_t s, const uint8_t *src, uint8_t *dst, int64_t n, int m, int npert, uint64_t seed,
+                       uint32_t it, uint64_t global_offset) {
+    if (n <= 0) return LSQ_OK;
+    LSQ_CS_LAUNCH(m, perturb_kernel, thread_grid(n), src, dst, n, m, npert, seed, it, global_offset);
+    return LSQ_OK;
+}
+
+int lsq_launch_cost(hipStream_t s, const float *X, const float *K, const uint8_t *rec, uint8_t *cur, float *prev,
+                    unsigned long long *counters, int64_t n, int d, int m, int mode) {
+    if (n <= 0) return LSQ_OK;
+    LSQ_CS_LAUNCH(m, cost_kernel, wave_grid(n), X, K, rec, cur, prev, counters, n, d, m, mode);
+    return LSQ_OK;
+}
+
+int lsq_launch_sum_f64(hipStream_t s, const float *v, int64_t n, double *sum) {
+    if (n <= 0) return LSQ_OK;
+    unsigned g = thread_grid(n);
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(sum_f64_kernel, dim3(g), dim3(256), 0, s, v, n, sum);
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}
+
+int lsq_launch_codes_expand(hipStream_t s, const uint8_t *tight, int64_t n, int m, uint8_t *rec) {
+    if (n <= 0) return LSQ_OK;
+    LSQ_CS_LAUNCH(m, codes_expand_kernel, thread_grid(n), tight, n, m, rec);
+    return LSQ_OK;
+}
+int lsq_launch_codes_compact(hipStream_t s, const uint8_t *rec, int64_t n, int m, uint8_t *tight) {
+    if (n <= 0) return LSQ_OK;
+    LSQ_CS_LAUNCH(m, codes_compact_kernel, thread_grid(n), rec, n, m, tight);
+    return LSQ_OK;
+}
+int lsq_launch_codes_from_i16(hipStream_t s, const int16_t *B, int64_t n, int m, int h, uint8_t *rec, int *bad_flag) {
+    if (n <= 0) return LSQ_OK;
+    LSQ_CS_LAUNCH(m, codes_from_i16_kernel, thread_grid(n), B, n, m, h, rec, bad_flag);
+    return LSQ_OK;
+}
+int lsq_launch_codes_to_i16(hipStream_t s, const uint8_t *rec, int64_t n, int m, int16_t *B) {
+    if (n <= 0) return LSQ_OK;
+    LSQ_CS_LAUNCH(m, codes_to_i16_kernel, thread_grid(n), rec, n, m, B);
+    return LSQ_OK;
+}
+
+int lsq_launch_synth_data_u8(hipStream_t s, uint64_t seed, uint64_t global_offset, int64_t n, int d, float *X) {
+    if (n <= 0) return LSQ_OK;
+    const int64_t items = n * ((d + 3) >> 2);
+    hipLaunchKernelGGL(synth_data_u8_kernel, dim3(thread_grid(items)), dim3(256), 0, s, seed, global_offset, n, d, X);
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}
+int lsq_launch_randinit(hipStream_t s, uint64_t seed, uint64_t global_offset, int64_t n, int m, int h, uint8_t *tight) {
+    if (n <= 0) return LSQ_OK;
+    hipLaunchKernelGGL(randinit_kernel, dim3(thread_grid(n)), dim3(256), 0, s, seed, global_offset, n, m, h, tight);
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}
+int lsq_launch_synth_codebooks(hipStream_t s, uint64_t seed, int m, int h, int d, float *K) {
+    hipLaunchKernelGGL(synth_codebooks_kernel, dim3(thread_grid((int64_t)m * h * d)), dim3(256), 0, s, seed, m, h, d, K);
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}

@@ -1,0 +1,102 @@
+// lsq_internal.h -- shared internals of liblsq_mi355x.so (gfx950 only; not a public header).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/lsq_mi355x.h"
+
+#define LSQ_H 256          // candidates per codebook: one wave x float4 per lane
+#define LSQ_MAX_M 16
+
+// ---- error plumbing ---------------------------------------------------------------------
+void lsq_set_error(const char *fmt, ...);
+
+#define LSQ_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            lsq_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return (e_ == hipErrorOutOfMemory) ? LSQ_ENOMEM : LSQ_EHIP;                        \
+        }                                                                                      \
+    } while (0)
+
+#define LSQ_TRY(expr)                  \
+    do {                               \
+        int rc_ = (expr);              \
+        if (rc_ != LSQ_OK) return rc_; \
+    } while (0)
+
+// ---- Philox4x32-10 (Random123; Salmon et al. SC'11), shared by host and device -----------
+// Stream layout (build-defined, mirrored by oracle/lsq_oracle.c):
+//   counter = (idx_lo, idx_hi, it, (domain << 16) | (word >> 2)),  key = (seed_lo, seed_hi),
+//   word w of the stream = output[w & 3].
+enum { LSQ_DOM_PERTURB = 1, LSQ_DOM_PERM = 2, LSQ_DOM_INIT = 3, LSQ_DOM_DATA = 4, LSQ_DOM_CODEBOOK = 5 };
+
+struct lsq_u32x4 { uint32_t v[4]; };
+
+__host__ __device__ inline lsq_u32x4 lsq_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                       uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    lsq_u32x4 o;
+    o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+    return o;
+}
+
+__host__ __device__ inline lsq_u32x4 lsq_rng_block(uint64_t seed, uint64_t idx, uint32_t it, uint32_t domain, uint32_t block) {
+    return lsq_philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), it, (domain << 16) | block,
+                             (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+__host__ __device__ inline uint32_t lsq_rng_word(uint64_t seed, uint64_t idx, uint32_t it, uint32_t domain, uint32_t w) {
+    return lsq_rng_block(seed, idx, it, domain, w >> 2).v[w & 3];
+}
+
+__host__ __device__ inline uint32_t lsq_mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+
+// ---- kernel launchers (implemented in the .hip files) ------------------------------------
+// All pointers are device pointers; all launch on `s` and return immediately.
+
+// D[off(r,c)] = chain_t( A[r][t] * (alpha * Bm[c][t]) ) (+ addv[c]);  r<M, c<N, t<Kd.
+// off(r,c) = (c / h) * plane_stride + (c % h) + r * row_stride.   Chain = k-ascending fmaf from +0.
+int lsq_launch_chain_gemm(hipStream_t s, const float *A, const float *Bm, const float *addv, float alpha,
+                          int64_t M, int N, int Kd, int h, int64_t plane_stride, int64_t row_stride, float *D);
+// sci[r] = chain_t(Kb[r][t]^2)
+int lsq_launch_sqnorms(hipStream_t s, const float *Kb, int rows, int d, float *sci);
+
+// Internal code records: cs bytes per vector (8 for m<=8, 16 for m<=16), byte j = code of codebook j.
+static inline int lsq_code_stride(int m) { return m <= 8 ? 8 : 16; }
+
+int lsq_launch_codes_expand(hipStream_t s, const uint8_t *tight, int64_t n, int m, uint8_t *rec);      // [n][m] -> [n][cs]
+int lsq_launch_codes_compact(hipStream_t s, const uint8_t *rec, int64_t n, int m, uint8_t *tight);     // [n][cs] -> [n][m]
+int lsq_launch_codes_from_i16(hipStream_t s, const int16_t *B, int64_t n, int m, int h, uint8_t *rec, int *bad_flag);
+int lsq_launch_codes_to_i16(hipStream_t s, const uint8_t *rec, int64_t n, int m, int16_t *B);
+
+int lsq_launch_perturb(hipStream_t s, const uint8_t *src, uint8_t *dst, int64_t n, int m, int npert,
+                       uint64_t seed, uint32_t it, uint64_t global_offset);
+// one ICM node update of node j for all n vectors: Uj = U + j*n*256, T = full table [m][m][256][256]
+int lsq_launch_icm_node(hipStream_t s, const float *Uj, const float *T, uint8_t *rec, int64_t n, int m, int j);
+// fused: for every vector, all `nsweeps` sweeps in `order` with register-resident unaries
+int lsq_launch_icm_fused(hipStream_t s, const float *U, const float *T, uint8_t *rec, int64_t n, int m,
+                         const int32_t *order_host, int nsweeps);
+// cost of `rec`; mode 0: prev[i] = cost.  mode 1 (accept): if cost < prev[i] { cur[i] = rec[i]; prev[i] = cost }
+// and counters[0] += (#cost == prev), counters[1] += (#cost < prev)   (counters: 2 x uint64 on device)
+int lsq_launch_cost(hipStream_t s, const float *X, const float *K, const uint8_t *rec, uint8_t *cur, float *prev,
+                    unsigned long long *counters, int64_t n, int d, int m, int mode);
+// *sum += SUM_i v[i]  (f64)
+int lsq_launch_sum_f64(hipStream_t s, const float *v, int64_t n, double *sum);
+
+int lsq_launch_synth_data_u8(hipStream_t s, uint64_t seed, uint64_t global_offset, int64_t n, int d, float *X);
+int lsq_launch_randinit(hipStream_t s, uint64_t seed, uint64_t global_offset, int64_t n, int m, int h, uint8_t *tight);
+int lsq_launch_synth_codebooks(hipStream_t s, uint64_t seed, int m, int h, int d, float *K);

@@ -1,0 +1,237 @@
+"""Engine: thin, typed Python handle on the C-ABI context (one per process / per GPU).
+
+Row-major conventions (the Julia buffers seen from numpy, see include/lsq_mi355x.h):
+    X (n, d) float32 | K (m*h, d) float32 | B (n, m) int16 1-based (host) / uint8 0-based (device)
+torch is used only as the owner of device memory and streams; every computation happens inside
+liblsq_mi355x.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+H = 256
+
+
+def _np(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a
+
+
+class Engine:
+    def __init__(self, device=0, chunk=None, profile=False, schedule=None):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._L.lsq_create(C.byref(h), int(device)))
+        self._h = h
+        self.device = int(device)
+        if chunk is not None:
+            self.set_option("chunk", int(chunk))
+        if schedule is not None:
+            self.set_option("schedule", int(schedule))
+        if profile:
+            self.set_option("profile", 1)
+
+    # -- lifetime -------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.lsq_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- options / timing -----------------------------------------------------------------
+    def set_option(self, key, value):
+        _lib.check(self._L.lsq_set_option(self._h, key.encode(), int(value)))
+
+    def set_stream(self, hip_stream_ptr):
+        _lib.check(self._L.lsq_set_stream(self._h, C.c_void_p(hip_stream_ptr or 0)))
+
+    def use_torch_stream(self):
+        import torch
+        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def synchronize(self):
+        _lib.check(self._L.lsq_synchronize(self._h))
+
+    def timings(self):
+        t = _lib.Timings()
+        _lib.check(self._L.lsq_get_timings(self._h, C.byref(t)))
+        return t.as_dict()
+
+    def reset_timings(self):
+        _lib.check(self._L.lsq_reset_timings(self._h))
+
+    # -- (1) whole call, host buffers -------------------------------------------------------
+    def encode_icm(self, X, B, K, m, ilsiters, icmiter, npert, randord, seed=0, nsplits=1, global_offset=0,
+                   verbose=False, h=H):
+        """-> Bs (nr, n, m) int16 1-based, objs (nr,) float32   [lsq_encode_icm]"""
+        X, K, B = _np(X, np.float32), _np(K, np.float32), _np(B, np.int16)
+        n, d = X.shape
+        self._check_shapes(X, K, B, m, h)
+        ils = _np(ilsiters, np.int64).reshape(-1)
+        nr = ils.shape[0]
+        Bs = np.empty((nr, n, m), dtype=np.int16)
+        objs = np.zeros(nr, dtype=np.float32)
+        _lib.check(self._L.lsq_encode_icm(self._h, X.ctypes.data, B.ctypes.data, K.ctypes.data, d, n, m, h,
+                                          ils.ctypes.data, nr, int(icmiter), int(npert), int(bool(randord)),
+                                          int(nsplits), int(seed), int(global_offset), int(bool(verbose)),
+                                          Bs.ctypes.data, objs.ctypes.data))
+        return Bs, objs
+
+    # -- (1b) whole call, device-resident torch tensors -------------------------------------
+    def encode_icm_dev(self, dX, dB0, dK, m, ilsiters, icmiter, npert, randord, seed=0, global_offset=0,
+                       out=None, h=H):
+        """dX (n,d) f32, dB0 (n,m) u8 0-based, dK (m*h,d) f32: CUDA/HIP torch tensors.
+        -> dBs (nr, n, m) uint8 tensor, obj_sums (nr,) float64 numpy (SUM of costs), stats (I, 2) int64."""
+        import torch
+        assert dX.is_cuda and dB0.is_cuda and dK.is_cuda, "device tensors required"
+        assert dX.dtype == torch.float32 and dK.dtype == torch.float32 and dB0.dtype == torch.uint8
+        assert dX.is_contiguous() and dB0.is_contiguous() and dK.is_contiguous()
+        n, d = dX.shape
+        if dB0.shape != (n, m) or dK.shape != (m * h, d):
+            raise ValueError("shape mismatch: X %s B %s K %s m=%d h=%d" % (tuple(dX.shape), tuple(dB0.shape), tuple(dK.shape), m, h))
+        ils = _np(ilsiters, np.int64).reshape(-1)
+        nr = ils.shape[0]
+        I = int(ils.max())
+        dBs = out if out is not None else torch.empty((nr, n, m), dtype=torch.uint8, device=dX.device)
+        obj = np.zeros(nr, dtype=np.float64)
+        stats = np.zeros((I, 2), dtype=np.int64)
+        self.use_torch_stream()
+        _lib.check(self._L.lsq_encode_icm_dev(self._h, dX.data_ptr(), dB0.data_ptr(), dK.data_ptr(), d, n, m, h,
+                                              ils.ctypes.data, nr, int(icmiter), int(npert), int(bool(randord)),
+                                              int(seed), int(global_offset), dBs.data_ptr(), obj.ctypes.data,
+                                              stats.ctypes.data))
+        return dBs, obj, stats
+
+    # -- (2) CPU-path shaped ---------------------------------------------------------------
+    def encoding_icm(self, X, oldB, K, m, niter, randord, npert, seed=0, it=0, global_offset=0, h=H):
+        X, K, oldB = _np(X, np.float32), _np(K, np.float32), _np(oldB, np.int16)
+        n, d = X.shape
+        self._check_shapes(X, K, oldB, m, h)
+        out = np.empty((n, m), dtype=np.int16)
+        _lib.check(self._L.lsq_encoding_icm(self._h, X.ctypes.data, oldB.ctypes.data, K.ctypes.data, d, n, m, h,
+                                            int(niter), int(bool(randord)), int(npert), int(seed), int(it),
+                                            int(global_offset), out.ctypes.data))
+        return out
+
+    def encode_icm_fully(self, B, X, K, m, niter, randord, npert, idx_first=1, seed=0, it=0, h=H):
+        """In place on B (n, m) int16 (must be C-contiguous int16)."""
+        X, K = _np(X, np.float32), _np(K, np.float32)
+        if B.dtype != np.int16 or not B.flags["C_CONTIGUOUS"]:
+            raise ValueError("B must be a C-contiguous int16 (n, m) array (it is updated in place)")
+        n, d = X.shape
+        self._check_shapes(X, K, B, m, h)
+        _lib.check(self._L.lsq_encode_icm_fully(self._h, B.ctypes.data, X.ctypes.data, K.ctypes.data, d, n, m, h,
+                                                int(niter), int(bool(randord)), int(npert), int(idx_first), int(seed), int(it)))
+        return B
+
+    # -- (3) helpers -----------------------------------------------------------------------
+    def get_unaries(self, X, K, m, h=H):
+        X, K = _np(X, np.float32), _np(K, np.float32)
+        n, d = X.shape
+        U = np.empty((m, n, h), dtype=np.float32)
+        _lib.check(self._L.lsq_get_unaries(self._h, X.ctypes.data, K.ctypes.data, d, n, m, h, U.ctypes.data))
+        return U
+
+    def get_binaries(self, K, m, h=H):
+        K = _np(K, np.float32)
+        d = K.shape[1]
+        T = np.empty((m, m, h, h), dtype=np.float32)
+        _lib.check(self._L.lsq_get_binaries(self._h, K.ctypes.data, d, m, h, T.ctypes.data))
+        return T
+
+    def veccost(self, X, B, K, m, h=H):
+        X, K, B = _np(X, np.float32), _np(K, np.float32), _np(B, np.int16)
+        n, d = X.shape
+        self._check_shapes(X, K, B, m, h)
+        out = np.empty(n, dtype=np.float32)
+        _lib.check(self._L.lsq_veccost(self._h, X.ctypes.data, B.ctypes.data, K.ctypes.data, d, n, m, h, out.ctypes.data))
+        return out
+
+    def qerror(self, X, B, K, m, h=H):
+        X, K, B = _np(X, np.float32), _np(K, np.float32), _np(B, np.int16)
+        n, d = X.shape
+        self._check_shapes(X, K, B, m, h)
+        out = C.c_double(0.0)
+        _lib.check(self._L.lsq_qerror(self._h, X.ctypes.data, B.ctypes.data, K.ctypes.data, d, n, m, h, C.byref(out)))
+        return float(out.value)
+
+    def perturb(self, B, npert, seed=0, it=0, global_offset=0, h=H):
+        B = _np(B, np.int16).copy()
+        n, m = B.shape
+        _lib.check(self._L.lsq_perturb(self._h, B.ctypes.data, n, m, h, int(npert), int(seed), int(it), int(global_offset)))
+        return B
+
+    # -- (4) device generators -------------------------------------------------------------
+    def synth_data_u8_dev(self, seed, n, d, device=None, global_offset=0):
+        import torch
+        X = torch.empty((n, d), dtype=torch.float32, device=device or ("cuda:%d" % self.device))
+        self.use_torch_stream()
+        _lib.check(self._L.lsq_synth_data_u8_dev(self._h, int(seed), int(global_offset), n, d, X.data_ptr()))
+        return X
+
+    def randinit_dev(self, seed, n, m, device=None, global_offset=0, h=H):
+        import torch
+        B = torch.empty((n, m), dtype=torch.uint8, device=device or ("cuda:%d" % self.device))
+        self.use_torch_stream()
+        _lib.check(self._L.lsq_randinit_dev(self._h, int(seed), int(global_offset), n, m, h, B.data_ptr()))
+        return B
+
+    def synth_codebooks_dev(self, seed, m, d, device=None, h=H):
+        import torch
+        K = torch.empty((m * h, d), dtype=torch.float32, device=device or ("cuda:%d" % self.device))
+        self.use_torch_stream()
+        _lib.check(self._L.lsq_synth_codebooks_dev(self._h, int(seed), m, h, d, K.data_ptr()))
+        return K
+
+    @staticmethod
+    def _check_shapes(X, K, B, m, h):
+        n, d = X.shape
+        if K.shape != (m * h, d):
+            raise ValueError("K must be (m*h, d) = (%d, %d), got %s" % (m * h, d, K.shape))
+        if B.shape != (n, m):
+            raise ValueError("B must be (n, m) = (%d, %d), got %s" % (n, m, B.shape))
+
+
+# -- host-only pieces of the path (no GPU needed) ---------------------------------------------
+
+def randinit(n, m, h=H, seed=0, global_offset=0):
+    """initializations.jl:2-8 -> (n, m) int16 1-based (Philox-keyed, shard-invariant)."""
+    B = np.empty((n, m), dtype=np.int16)
+    _lib.check(_lib.load().lsq_randinit(int(seed), int(global_offset), n, m, h, B.ctypes.data))
+    return B
+
+
+def node_order(seed, it, m, randord=True):
+    o = np.empty(m, dtype=np.int32)
+    _lib.check(_lib.load().lsq_node_order(int(seed), int(it), m, int(bool(randord)), o.ctypes.data))
+    return o
+
+
+def splitarray(n, nparts):
+    """utils.jl:152-177 -> list of (start, stop) 0-based half-open ranges."""
+    L = _lib.load()
+    out = []
+    for p in range(nparts):
+        s, ln = C.c_int64(), C.c_int64()
+        _lib.check(L.lsq_splitarray(n, nparts, p, C.byref(s), C.byref(ln)))
+        out.append((s.value, s.value + ln.value))
+    return out
+
+
+def device_count():
+    c = C.c_int(0)
+    rc = _lib.load().lsq_device_count(C.byref(c))
+    return c.value if rc == 0 else 0

@@ -1,0 +1,184 @@
+"""GPU parity: the HIP path (through the C-ABI) vs the CPU oracle on the same seeded inputs.
+
+Bar (north_star): integer codes BIT-EXACT; float tables bit-exact too (the kernels are built to
+reproduce the oracle's canonical fp32 operation order); objective within 1e-5 relative.
+"""
+import numpy as np
+import pytest
+
+from conftest import make_problem
+
+pytestmark = pytest.mark.gpu
+
+H = 256
+
+
+def _same_f32(a, b):
+    """bitwise equality up to the sign of zero (np.array_equal: -0 == +0, NaN != NaN)."""
+    return a.shape == b.shape and np.array_equal(a, b)
+
+
+# ---- tables -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("d,m,kind", [(16, 4, "gauss"), (128, 8, "sift"), (100, 3, "gauss"), (33, 2, "gauss")])
+def test_binaries_bit_exact(engine, oracle, d, m, kind):
+    _, K, _ = make_problem(d, 4, m, seed=d + m, kind=kind)
+    T = engine.get_binaries(K, m)
+    Tref = oracle.tables(K, m, H)
+    assert _same_f32(T, Tref), "max abs diff %g" % np.abs(T - Tref).max()
+
+
+@pytest.mark.parametrize("d,n,m,kind", [(16, 64, 4, "gauss"), (128, 300, 8, "sift"), (128, 129, 7, "gauss"),
+                                        (960, 40, 8, "gauss"), (100, 77, 3, "gauss"), (128, 64, 16, "sift"), (5, 10, 1, "gauss")])
+def test_unaries_bit_exact(engine, oracle, d, n, m, kind):
+    X, K, _ = make_problem(d, n, m, seed=n, kind=kind)
+    U = engine.get_unaries(X, K, m)
+    Uref = oracle.unaries(X, K, m, H)
+    assert _same_f32(U, Uref), "max abs diff %g" % np.abs(U - Uref).max()
+
+
+@pytest.mark.parametrize("d,n,m,kind", [(16, 64, 4, "gauss"), (128, 1000, 8, "sift"), (960, 33, 8, "gauss"),
+                                        (100, 77, 3, "gauss"), (128, 64, 16, "sift"), (7, 5, 2, "gauss")])
+def test_veccost_bit_exact(engine, oracle, d, n, m, kind):
+    X, K, B0 = make_problem(d, n, m, seed=d, kind=kind)
+    c = engine.veccost(X, B0, K, m)
+    cref = oracle.veccost(X, K, (B0 - 1).astype(np.uint8), H)
+    assert _same_f32(c, cref)
+    q = engine.qerror(X, B0, K, m)
+    assert abs(q - oracle.qerror(X, B0, K, m, H)) <= 1e-6 * abs(q)
+
+
+@pytest.mark.parametrize("m,npert", [(8, 4), (7, 4), (16, 4), (4, 2), (3, 3), (5, 0), (2, 9)])
+def test_perturb_exact(engine, oracle, m, npert):
+    n = 500
+    B0 = oracle.randinit(11, n, m, H)
+    out = engine.perturb(B0, npert, seed=77, it=3, global_offset=1000)
+    ref = np.stack([oracle.perturb(77, 1000 + i, 3, (B0[i] - 1).astype(np.uint8), H, npert) for i in range(n)]).astype(np.int16) + 1
+    assert np.array_equal(out, ref)
+
+
+# ---- the whole call ---------------------------------------------------------------------------
+CONFIGS = [
+    # d, n, m, ilsiters, J, npert, randord, seed, kind
+    (16, 64, 4, [1, 2], 4, 2, True, 1, "gauss"),
+    (128, 64, 7, [2], 4, 4, True, 2, "sift"),
+    (128, 256, 8, [1, 2, 4], 4, 4, True, 3, "sift"),
+    (128, 48, 16, [2], 4, 4, True, 4, "sift"),
+    (960, 16, 8, [1], 4, 4, False, 5, "gauss"),
+    (128, 1, 8, [3], 2, 4, True, 6, "gauss"),        # single vector
+    (32, 300, 2, [2], 3, 1, True, 7, "gauss"),
+    (64, 100, 5, [1, 3], 1, 5, False, 8, "gauss"),
+    (128, 200, 8, [2], 4, 0, True, 9, "sift"),        # no perturbation
+    (24, 90, 1, [2], 2, 1, True, 10, "gauss"),        # one codebook: argmin of the unary
+]
+
+
+@pytest.mark.parametrize("schedule", [0, 1])
+@pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: "d%d_n%d_m%d" % (c[0], c[1], c[2]))
+def test_encode_icm_matches_oracle(lsq, oracle, cfg, schedule):
+    d, n, m, ils, J, npert, randord, seed, kind = cfg
+    X, K, B0 = make_problem(d, n, m, seed=seed, kind=kind)
+    Bs_ref, objs_ref, st_ref = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, randord, seed, want_stats=True)
+    with lsq.Engine(0, schedule=schedule) as eng:
+        Bs, objs = eng.encode_icm(X, B0, K, m, ils, J, npert, randord, seed=seed)
+    assert np.array_equal(Bs, Bs_ref), "%d of %d codes differ" % ((Bs != Bs_ref).sum(), Bs.size)
+    assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0)
+
+
+def test_device_api_chunking_and_offsets(lsq, oracle):
+    """Results must not depend on the resident chunk size nor on how the caller shards (P8):
+    encode [0,n) in one call == two calls on halves with global_offset."""
+    import torch
+    d, n, m, ils, J, npert, seed = 128, 1000, 8, [1, 3], 4, 4, 21
+    X, K, B0 = make_problem(d, n, m, seed=seed)
+    Bs_ref, objs_ref, st_ref = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, True, seed, want_stats=True)
+    dX, dK = torch.from_numpy(X).cuda(), torch.from_numpy(K).cuda()
+    dB = torch.from_numpy((B0 - 1).astype(np.uint8)).cuda()
+    with lsq.Engine(0, chunk=192) as eng:           # 6 chunks, ragged tail
+        dBs, sums, stats = eng.encode_icm_dev(dX, dB, dK, m, ils, J, npert, True, seed=seed)
+        got = dBs.cpu().numpy().astype(np.int16) + 1
+        assert np.array_equal(got, Bs_ref)
+        assert np.allclose(sums / n, objs_ref, rtol=1e-5, atol=0)
+        assert np.array_equal(stats, st_ref.astype(np.int64))
+        # two shards with offsets
+        h1 = 437
+        a, sa, _ = eng.encode_icm_dev(dX[:h1].contiguous(), dB[:h1].contiguous(), dK, m, ils, J, npert, True, seed=seed, global_offset=0)
+        b, sb, _ = eng.encode_icm_dev(dX[h1:].contiguous(), dB[h1:].contiguous(), dK, m, ils, J, npert, True, seed=seed, global_offset=h1)
+        both = torch.cat([a, b], dim=1).cpu().numpy().astype(np.int16) + 1
+        assert np.array_equal(both, Bs_ref)
+        assert np.allclose((sa + sb) / n, objs_ref, rtol=1e-5, atol=0)
+
+
+def test_reference_shaped_api(lsq, oracle):
+    """The Julia-shaped mirror: encode_icm_cuda / encoding_icm / encode_icm_fully / helpers."""
+    d, n, m, seed = 128, 200, 8, 33
+    X, K, B0 = make_problem(d, n, m, seed=seed)
+    C = [np.ascontiguousarray(K[j * H:(j + 1) * H].T) for j in range(m)]      # list of (d, h)
+    RX, B = np.asfortranarray(X.T), np.asfortranarray(B0.T)                    # Julia shapes
+    Bs, objs = lsq.encode_icm_cuda(RX, B, C, [2, 4], 4, 4, True, 2, False, seed=seed)
+    Bs_ref, objs_ref = oracle.encode_icm(X, B0, K, m, H, [2, 4], 4, 4, True, seed)
+    assert len(Bs) == 2 and Bs[0].shape == (m, n) and Bs[0].dtype == np.int16
+    assert np.array_equal(Bs[1].T, Bs_ref[1]) and np.array_equal(Bs[0].T, Bs_ref[0])
+    assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0)
+    # encoding_icm chained == the reference demo loop `for i=1:ilsiter B = encoding_icm(...)` (demo_lsq.jl:48-51)
+    Bc = B.copy()
+    for it in range(4):
+        Bc = lsq.encoding_icm(RX, Bc, C, 4, True, 4, False, seed=seed, it=it)
+    assert np.array_equal(Bc.T, Bs_ref[1])
+    # the worker without the accept test
+    Bw = np.array(B, dtype=np.int16, order="F")
+    lsq.encode_icm_fully(Bw, RX, C, None, None, 4, True, 4, (1, n), False, seed=seed, it=0)
+    ref_w = oracle.encoding_icm_faithful(X, B0, K, m, H, 4, True, 4, seed, 0)    # accept applied on top
+    cost_w = lsq.veccost(RX, Bw, C)
+    cost_0 = lsq.veccost(RX, B, C)
+    expect = np.where((cost_w < cost_0)[:, None], Bw.T, B0)
+    assert np.array_equal(expect, ref_w)
+    # helpers
+    un = lsq.get_unaries(RX, C)
+    assert len(un) == m and un[0].shape == (H, n)
+    assert np.array_equal(np.stack([u.T for u in un]), oracle.unaries(X, K, m, H))
+    bins, cbi = lsq.get_binaries(C)
+    assert len(bins) == m * (m - 1) // 2 and cbi.shape == (2, len(bins))
+    T = oracle.tables(K, m, H)
+    assert np.array_equal(bins[0], T[0, 1].T) and tuple(cbi[:, 0]) == (1, 2)
+    assert abs(lsq.qerror(RX, Bs[1], C) - objs_ref[1]) <= 1e-5 * objs_ref[1]
+
+
+def test_ties_pick_lowest_index(lsq, oracle):
+    """Duplicate codewords create exact ties; the node update must return the LOWEST index (P3),
+    which the reference CUDA tree reduction does not guarantee."""
+    d, n, m, seed = 32, 128, 4, 55
+    X, K, B0 = make_problem(d, n, m, seed=seed, kind="gauss")
+    K = K.reshape(m, H, d).copy()
+    K[:, 1::2] = K[:, 0::2]            # every codeword appears twice (indices 2a and 2a+1)
+    K[1, 200:] = K[1, 3]               # and a long run of copies
+    K = K.reshape(m * H, d)
+    Bs_ref, _ = oracle.encode_icm(X, B0, K, m, H, [2], 4, 2, True, seed)
+    with lsq.Engine(0) as eng:
+        Bs, _ = eng.encode_icm(X, B0, K, m, [2], 4, 2, True, seed=seed)
+    assert np.array_equal(Bs, Bs_ref)
+    changed = Bs[0] != B0
+    assert ((Bs[0][changed] - 1) % 2 == 0).all(), "a tie was resolved to the higher duplicate"
+
+
+def test_generators_match_oracle(engine, oracle):
+    X = engine.synth_data_u8_dev(1234, 300, 128, global_offset=17).cpu().numpy()
+    assert np.array_equal(X, oracle.synth_data_u8(1234, 300, 128, global_offset=17))
+    X2 = engine.synth_data_u8_dev(5, 10, 1030).cpu().numpy()
+    assert np.array_equal(X2, oracle.synth_data_u8(5, 10, 1030))
+    B = engine.randinit_dev(9, 1000, 7, global_offset=5).cpu().numpy()
+    assert np.array_equal(B.astype(np.int16) + 1, oracle.randinit(9, 1000, 7, H, global_offset=5))
+
+
+def test_errors_are_loud(lsq, engine):
+    X = np.zeros((4, 8), np.float32)
+    K = np.zeros((2 * 256, 8), np.float32)
+    B = np.ones((4, 2), np.int16)
+    with pytest.raises(lsq._lib.LsqError):
+        engine.encode_icm(X, B * 300, K, 2, [1], 1, 1, True)          # code out of range
+    with pytest.raises(lsq._lib.LsqError):
+        engine.encode_icm(X, B, K, 2, [0], 1, 1, True)                # ilsiters < 1
+    with pytest.raises(lsq._lib.LsqError):
+        engine.get_unaries(X, np.zeros((2 * 128, 8), np.float32), 2, h=128)   # h != 256
+    # empty input is fine
+    Bs, objs = engine.encode_icm(np.zeros((0, 8), np.float32), np.zeros((0, 2), np.int16), K, 2, [1], 1, 1, True)
+    assert Bs.shape == (1, 0, 2)
