@@ -44,7 +44,7 @@ def parse():
     p.add_argument("--ils", type=int, default=16)
     p.add_argument("--icmiter", type=int, default=4)
     p.add_argument("--npert", type=int, default=4)
-    p.add_argument("--schedule", type=int, default=int(os.environ.get("LSQ_SCHEDULE", "0")))
+    p.add_argument("--schedule", type=int, default=int(os.environ.get("LSQ_SCHEDULE", "2")))
     p.add_argument("--chunk", type=int, default=int(os.environ.get("LSQ_CHUNK", "0")))
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline budget")
@@ -145,7 +145,7 @@ def main():
         avg_launch_s = tm["icm_ms"] * 1e-3 / launches
         node_updates_per_launch = tm["icm_node_updates"] / launches
         cs = 8 if m <= 8 else 16
-        if args.schedule == 0:
+        if args.schedule != 1:
             # per vector per node-update launch: U_j row (4h B) + code record read + 1 code byte written
             hbm_bytes = node_updates_per_launch * (4 * h + cs + 1)
         else:
@@ -162,12 +162,12 @@ def main():
                 "workload": "BASELINE configs[1]: SIFT1M-shaped base encode, %d x %d f32 per GPU, m=%d, h=%d, %d ILS iters x %d ICM sweeps, "
                             "npert=%d, randord, seed=42; inputs resident in HBM; lsq_encode_icm_dev" % (n, d, m, h, args.ils, args.icmiter, args.npert),
                 "vectors_per_gpu": n, "d": d, "m": m, "h": h, "ils_iters": args.ils, "icm_iters": args.icmiter, "npert": args.npert,
-                "schedule": "per-node launches (M2 data-flow)" if args.schedule == 0 else "fused sweeps per ILS iteration (M1 data-flow)",
+                "schedule": {0: "per-node launches, L2 gathers (M2 data-flow)", 1: "fused sweeps per ILS iteration (M1 data-flow)", 2: "per-node launches, LDS-staged table slices, slice-major U stream (M2 data-flow)"}[args.schedule],
                 "parallelism": "%d x independent shards, RCCL broadcast of codebooks" % world,
             },
             "objective": float(sums[0] / n), "last_ils_pct_better": float(100.0 * stats[-1, 1] / n),
             "roofline": {
-                "kernel": "icm_node_kernel<%d>" % m if args.schedule == 0 else "icm_fused_kernel<%d>" % m,
+                "kernel": {0: "icm_node_kernel<%d>", 1: "icm_fused_kernel<%d>", 2: "icm_slice_kernel<%d,SL> + icm_combine_kernel"}[args.schedule] % m,
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
                 "avg_launch_us": avg_launch_s * 1e6, "launches": int(tm["icm_launches"]),

@@ -80,10 +80,14 @@ LSQ_API int lsq_device_count(int *count);
  * destroy! of encode_icm_cuda.jl:59-64,226-228. */
 LSQ_API int lsq_create(lsq_ctx **ctx, int device);
 LSQ_API int lsq_destroy(lsq_ctx *ctx);
-/* Launch on the caller's hipStream_t (e.g. torch's current stream); NULL = the ctx's own. */
+/* Launch on the caller's hipStream_t (e.g. torch's current stream).  NULL = HIP's default (null)
+ * stream; option "own_stream" switches back to the context's private non-blocking stream. */
 LSQ_API int lsq_set_stream(lsq_ctx *ctx, void *hip_stream);
-/* Options: "chunk" (vectors per resident chunk, default 1048576), "profile" (0/1),
- *          "schedule" (0 = one launch per node update, 1 = fused per-ILS-iteration sweep). */
+/* Options: "chunk" (vectors per resident chunk, default 1048576), "profile" (0/1), "own_stream",
+ *          "schedule": 2 (default) = one launch per node update, table slices staged in LDS, unaries
+ *                          streamed slice-major from HBM;
+ *                      0 = one launch per node update, table columns gathered through L2;
+ *                      1 = fused sweeps, unaries register-resident (all three give identical codes). */
 LSQ_API int lsq_set_option(lsq_ctx *ctx, const char *key, int64_t value);
 LSQ_API int lsq_get_timings(lsq_ctx *ctx, lsq_timings *out);
 LSQ_API int lsq_reset_timings(lsq_ctx *ctx);

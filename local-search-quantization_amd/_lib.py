@@ -70,6 +70,15 @@ def load():
             raise RuntimeError(
                 "%s not found: the HIP extension is not built. Run `python -c \"import __graft_entry__ as g; "
                 "g.build()\"` -- there is no CPU fallback." % LIB_PATH)
+        # torch bundles its own libamdhip64.so / libhsa-runtime64.so (SONAME libamdhip64.so.7).  Two HIP
+        # runtimes in one process cannot both own the GPU ("No HIP GPUs are available" in whichever
+        # initialises second), so when torch is installed it must be loaded FIRST: our DT_NEEDED
+        # libamdhip64.so.7 then resolves to the copy already in the process.  A pure-C consumer (the
+        # Julia ccall shim of INTEGRATION.md) simply gets /opt/rocm's runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)       # AttributeError if the symbol is missing: loud by design

@@ -57,9 +57,9 @@ struct lsq_ctx {
     hipStream_t stream = nullptr;
     int64_t chunk = 1 << 20;
     int profile = 0;
-    int schedule = 0;
+    int schedule = 2;        // 0: per-node gather kernel, 1: fused sweeps, 2: per-node LDS-slice kernel (default)
     // workspace
-    DevBuf sci, T, U, recCur, recNew, prev, counters, obj, bad;
+    DevBuf sci, T, U, part, recCur, recNew, prev, counters, obj, bad;
     DevBuf sX, sK, sB16, sOut16, sTight, sF32;    // staging for the host-buffer entry points
     // timings
     double cat_ms[CAT_COUNT] = {0, 0, 0, 0, 0, 0};
@@ -138,7 +138,7 @@ extern "C" int lsq_destroy(lsq_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : c->pool) (void)hipEventDestroy(e);
-    DevBuf *bufs[] = {&c->sci, &c->T, &c->U, &c->recCur, &c->recNew, &c->prev, &c->counters, &c->obj, &c->bad,
+    DevBuf *bufs[] = {&c->sci, &c->T, &c->U, &c->part, &c->recCur, &c->recNew, &c->prev, &c->counters, &c->obj, &c->bad,
                       &c->sX, &c->sK, &c->sB16, &c->sOut16, &c->sTight, &c->sF32};
     for (DevBuf *b : bufs) b->release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -148,7 +148,7 @@ extern "C" int lsq_destroy(lsq_ctx *c) {
 
 extern "C" int lsq_set_stream(lsq_ctx *c, void *hip_stream) {
     LSQ_TRY(use_device(c));
-    c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+    c->stream = reinterpret_cast<hipStream_t>(hip_stream);      // NULL = HIP's default (null) stream, e.g. torch's default
     return LSQ_OK;
 }
 
@@ -158,8 +158,9 @@ extern "C" int lsq_set_option(lsq_ctx *c, const char *key, int64_t value) {
         if (value < 1) { lsq_set_error("chunk must be >= 1"); return LSQ_EINVAL; }
         c->chunk = value;
     } else if (!strcmp(key, "profile")) c->profile = value != 0;
+    else if (!strcmp(key, "own_stream")) c->stream = c->own_stream;
     else if (!strcmp(key, "schedule")) {
-        if (value < 0 || value > 1) { lsq_set_error("schedule must be 0 or 1"); return LSQ_EINVAL; }
+        if (value < 0 || value > 2) { lsq_set_error("schedule must be 0, 1 or 2"); return LSQ_EINVAL; }
         c->schedule = (int)value;
     } else { lsq_set_error("unknown option '%s'", key); return LSQ_EINVAL; }
     return LSQ_OK;
@@ -237,15 +238,16 @@ static int prepare_tables(lsq_ctx *c, const float *dK, int d, int m) {
     LSQ_TRY(c->T.ensure(sizeof(float) * (size_t)mh * mh));
     LSQ_TRY(lsq_launch_sqnorms(c->stream, dK, mh, d, c->sci.as<float>()));
     // rows r = (k,b), cols c = (j,a):  T[((j*m + k)*h + b)*h + a] = chain(K[k,b][t] * 2 K[j,a][t])
-    LSQ_TRY(lsq_launch_chain_gemm(c->stream, dK, dK, nullptr, 2.0f, mh, mh, d, LSQ_H, (int64_t)m * LSQ_H * LSQ_H, LSQ_H, c->T.as<float>()));
+    LSQ_TRY(lsq_launch_chain_gemm(c->stream, dK, dK, nullptr, 2.0f, mh, mh, d, LSQ_H, (int64_t)m * LSQ_H * LSQ_H, LSQ_H, c->T.as<float>(), 0));
     return LSQ_OK;
 }
 
-static int build_unaries(lsq_ctx *c, const float *dX, const float *dK, int d, int64_t cn, int m) {
+static int build_unaries(lsq_ctx *c, const float *dX, const float *dK, int d, int64_t cn, int m, int slice) {
     Timer t(c, CAT_UNARIES);
     LSQ_TRY(c->U.ensure(sizeof(float) * (size_t)m * (size_t)cn * LSQ_H));
-    // U[(j*cn + i)*h + a] = chain(x_i[t] * -2 K[j,a][t]) + sci[j,a]
-    return lsq_launch_chain_gemm(c->stream, dX, dK, c->sci.as<float>(), -2.0f, cn, m * LSQ_H, d, LSQ_H, cn * (int64_t)LSQ_H, LSQ_H, c->U.as<float>());
+    // row-major  (slice == 0): U[(j*cn + i)*h + a]                      = chain(x_i[t] * -2 K[j,a][t]) + sci[j,a]
+    // slice-major (slice = SL): U[j*cn*h + ((a/SL)*cn + i)*SL + a%SL]   (same values, LDS-slice schedule)
+    return lsq_launch_chain_gemm(c->stream, dX, dK, c->sci.as<float>(), -2.0f, cn, m * LSQ_H, d, LSQ_H, cn * (int64_t)LSQ_H, LSQ_H, c->U.as<float>(), slice);
 }
 
 static int run_sweeps(lsq_ctx *c, uint8_t *rec, int64_t cn, int m, const int32_t *order, int nsweeps) {
@@ -253,6 +255,14 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, int64_t cn, int m, const int32_t
     if (c->schedule == 1) {
         LSQ_TRY(lsq_launch_icm_fused(c->stream, c->U.as<float>(), c->T.as<float>(), rec, cn, m, order, nsweeps));
         c->icm_launches += 1;
+    } else if (c->schedule == 2) {
+        LSQ_TRY(c->part.ensure(sizeof(float2) * (size_t)cn * (LSQ_H / lsq_slice_width(m))));
+        for (int sw = 0; sw < nsweeps; ++sw)
+            for (int q = 0; q < m; ++q) {
+                const int j = order[q];
+                LSQ_TRY(lsq_launch_icm_slice(c->stream, c->U.as<float>() + (int64_t)j * cn * LSQ_H, c->T.as<float>(), rec, c->part.as<float2>(), cn, m, j));
+            }
+        c->icm_launches += (int64_t)nsweeps * m;
     } else {
         for (int sw = 0; sw < nsweeps; ++sw)
             for (int q = 0; q < m; ++q) {
@@ -276,7 +286,7 @@ struct EncodeParams {
 template <class Snap>
 static int encode_chunk(lsq_ctx *c, const float *dXc, const float *dK, int64_t cn, uint64_t goff, const EncodeParams &P, int64_t I, Snap snap) {
     const int cs = lsq_code_stride(P.m);
-    LSQ_TRY(build_unaries(c, dXc, dK, P.d, cn, P.m));
+    LSQ_TRY(build_unaries(c, dXc, dK, P.d, cn, P.m, c->schedule == 2 ? lsq_slice_width(P.m) : 0));
     LSQ_TRY(c->recNew.ensure((size_t)cn * cs));
     LSQ_TRY(c->prev.ensure(sizeof(float) * (size_t)cn));
     uint8_t *cur = c->recCur.as<uint8_t>(), *nw = c->recNew.as<uint8_t>();
@@ -465,7 +475,7 @@ extern "C" int lsq_encode_icm_fully(lsq_ctx *c, int16_t *B, const float *X, cons
     LSQ_TRY(upload_xk(c, X, K, d, n, m));
     LSQ_TRY(upload_codes(c, B, n, m, h, c->recCur));
     LSQ_TRY(prepare_tables(c, c->sK.as<float>(), d, m));
-    LSQ_TRY(build_unaries(c, c->sX.as<float>(), c->sK.as<float>(), d, n, m));
+    LSQ_TRY(build_unaries(c, c->sX.as<float>(), c->sK.as<float>(), d, n, m, c->schedule == 2 ? lsq_slice_width(m) : 0));
     LSQ_TRY(c->recNew.ensure((size_t)n * lsq_code_stride(m)));
     int32_t order[LSQ_MAX_M];
     LSQ_TRY(lsq_node_order(seed, it, m, randord, order));
@@ -485,7 +495,7 @@ extern "C" int lsq_get_unaries(lsq_ctx *c, const float *X, const float *K, int d
     LSQ_TRY(upload_xk(c, X, K, d, n, m));
     LSQ_TRY(c->sci.ensure(sizeof(float) * (size_t)m * LSQ_H));
     LSQ_TRY(lsq_launch_sqnorms(c->stream, c->sK.as<float>(), m * LSQ_H, d, c->sci.as<float>()));
-    LSQ_TRY(build_unaries(c, c->sX.as<float>(), c->sK.as<float>(), d, n, m));
+    LSQ_TRY(build_unaries(c, c->sX.as<float>(), c->sK.as<float>(), d, n, m, 0));
     LSQ_HIP(hipMemcpyAsync(U, c->U.p, sizeof(float) * (size_t)m * n * LSQ_H, hipMemcpyDeviceToHost, c->stream));
     LSQ_HIP(hipStreamSynchronize(c->stream));
     return LSQ_OK;

@@ -59,7 +59,7 @@ template <bool VEC4>
 __global__ __launch_bounds__(256) void chain_gemm_kernel(const float *__restrict__ A, const float *__restrict__ Bm,
                                                          const float *__restrict__ addv, float alpha, int64_t M, int N,
                                                          int Kd, int h, int64_t plane_stride, int64_t row_stride,
-                                                         float *__restrict__ D, int64_t row_tiles, int col_tiles) {
+                                                         float *__restrict__ D, int64_t row_tiles, int col_tiles, int slice) {
     __shared__ float As[BM * LD];
     __shared__ float Bs[BN * LD];
 
@@ -107,7 +107,12 @@ __global__ __launch_bounds__(256) void chain_gemm_kernel(const float *__restrict
         const int c = col0 + wx * 64 + tj * 32 + l31;
         if (c >= N) continue;
         const float add = addv ? addv[c] : 0.0f;
-        const int64_t coff = (int64_t)(c / h) * plane_stride + (c % h);
+        // row-major planes: off = (c/h)*plane + (c%h) + r*row_stride
+        // slice-major planes (slice = SL > 0): off = (c/h)*plane + ((c%h)/SL)*(M*SL) + (c%h)%SL + r*SL
+        const int a = c % h;
+        const int64_t coff = slice ? (int64_t)(c / h) * plane_stride + (int64_t)(a / slice) * (M * slice) + (a % slice)
+                                   : (int64_t)(c / h) * plane_stride + a;
+        const int64_t rstride = slice ? (int64_t)slice : row_stride;
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
 #pragma unroll
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(256) void chain_gemm_kernel(const float *__restrict
                 if (row < M) {
                     float v = acc[ti][tj][r];
                     if (addv) v = v + add;           // one rounded add (utils.jl:112-118)
-                    D[coff + row * row_stride] = v;
+                    D[coff + row * rstride] = v;
                 }
             }
         }
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(256) void sqnorms_kernel(const float *__restrict__ 
 }  // namespace
 
 int lsq_launch_chain_gemm(hipStream_t s, const float *A, const float *Bm, const float *addv, float alpha, int64_t M,
-                          int N, int Kd, int h, int64_t plane_stride, int64_t row_stride, float *D) {
+                          int N, int Kd, int h, int64_t plane_stride, int64_t row_stride, float *D, int slice) {
     if (M <= 0 || N <= 0) return LSQ_OK;
     const int64_t row_tiles = (M + BM - 1) / BM;
     const int col_tiles = (N + BN - 1) / BN;
@@ -144,10 +149,10 @@ int lsq_launch_chain_gemm(hipStream_t s, const float *A, const float *Bm, const 
     const bool vec4 = (Kd % 4 == 0) && (((uintptr_t)A | (uintptr_t)Bm) % 16 == 0);
     if (vec4)
         hipLaunchKernelGGL(chain_gemm_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                           plane_stride, row_stride, D, row_tiles, col_tiles);
+                           plane_stride, row_stride, D, row_tiles, col_tiles, slice);
     else
         hipLaunchKernelGGL(chain_gemm_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                           plane_stride, row_stride, D, row_tiles, col_tiles);
+                           plane_stride, row_stride, D, row_tiles, col_tiles, slice);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }

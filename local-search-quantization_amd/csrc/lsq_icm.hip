@@ -188,6 +188,133 @@ __global__ __launch_bounds__(256) void icm_fused_kernel(const float *__restrict_
     }
 }
 
+// ---- LDS-slice schedule (schedule 2) ---------------------------------------------------------------
+// Why: on gfx950 the HBM-miss stream of U_j and the L2-hit table gathers of icm_node_kernel do not
+// overlap -- their times ADD (measured: 164 us + 240 us -> 470 us per 10^6-vector launch; tools/
+// ubench_icm.hip).  So the vector-memory path is given to the U stream alone and the
+// table columns come from LDS:
+//   * a 1024-thread block owns one SLICE of SL candidates (16 for m <= 10, 8 above) of node j and
+//     stages T_j[k][b][a0..a0+SL) for all k != j, b into LDS: (m-1)*256*SL*4 B (112 KiB at m = 8);
+//   * U_j is stored slice-major, Us[slice][i][SL], so one wave load = 1 KiB contiguous = 64/(SL/4)
+//     vectors x SL candidates (lane = (SL/4)*v + q: candidates 4q..4q+3 of vector v);
+//   * per vector the block emits the partial (min, index-in-slice) of its SL candidates; a second
+//     tiny kernel (icm_combine_kernel) takes the lowest-index global minimum over the 256/SL slices.
+// Conditioning order, plain f32 adds and first-index argmin are exactly those of icm_node_kernel.
+template <int M, int SL>
+__global__ __launch_bounds__(1024) void icm_slice_kernel(const float *__restrict__ Usj, const float *__restrict__ Tj,
+                                                         const uint8_t *__restrict__ rec, float2 *__restrict__ part,
+                                                         int64_t n, int j, int nranges) {
+    constexpr int CS = (M <= 8) ? 8 : 16;
+    constexpr int NS = LSQ_H / SL;          // slices
+    constexpr int LPV = SL / 4;             // lanes per vector
+    constexpr int VPW = 64 / LPV;           // vectors per wave iteration
+    constexpr int CW = (M - 1 + 3) / 4;     // compacted code words (conditioning codes in ascending k, j skipped)
+    constexpr int RW = CS / 4;              // record words
+    extern __shared__ f32x4 lds_tab[];      // [(M-1)*256][LPV]
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int slice = blockIdx.x % NS, range = blockIdx.x / NS;
+
+    for (int e = threadIdx.x; e < (M - 1) * LSQ_H * LPV; e += 1024) {
+        const int q = e % LPV, eb = e / LPV, kk = eb >> 8, b = eb & 255;
+        const int k = kk + (kk >= j ? 1 : 0);
+        lds_tab[e] = *reinterpret_cast<const f32x4 *>(Tj + ((int64_t)(k * LSQ_H) + b) * LSQ_H + slice * SL + q * 4);
+    }
+    // v_perm_b32 selectors: compact word w takes bytes k(4w..4w+3) - 4w (0..4) of record words (w, w+1)
+    uint32_t sel[CW > 0 ? CW : 1];
+#pragma unroll
+    for (int w = 0; w < CW; ++w) {
+        uint32_t sv = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int kk = 4 * w + t;
+            const int k = kk + (kk >= j ? 1 : 0);
+            sv |= (uint32_t)((kk < M - 1 ? k - 4 * w : 0) & 7) << (8 * t);
+        }
+        sel[w] = sv;
+    }
+    __syncthreads();
+
+    const int64_t per = (n + nranges - 1) / nranges;
+    const int64_t lo = range * per, hi = (lo + per < n) ? lo + per : n;
+    const int v = lane / LPV, q = lane % LPV;
+    const float *Ub = Usj + (int64_t)slice * n * SL;
+    const int64_t step = 16 * VPW;
+
+    struct Item { f32x4 u; uint32_t r[RW]; };
+    auto load_item = [&](int64_t i0, Item &it) {
+        const int64_t i = i0 + v;
+        if (i < hi) {
+            it.u = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(Ub + i * SL) + q);
+            const uint32_t *rp = reinterpret_cast<const uint32_t *>(rec + i * CS);
+#pragma unroll
+            for (int w = 0; w < RW; ++w) it.r[w] = rp[w];
+        } else {
+            it.u = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < RW; ++w) it.r[w] = 0u;
+        }
+    };
+
+    int64_t i0 = lo + (int64_t)wave * VPW;
+    Item a, b;
+    load_item(i0, a);
+    load_item(i0 + step, b);
+    for (; i0 < hi; i0 += step) {
+        const Item cur = a;
+        a = b;
+        load_item(i0 + 2 * step, b);          // two iterations of U in flight per wave
+
+        f32x4 s = cur.u;
+#pragma unroll
+        for (int w = 0; w < CW; ++w) {
+            const uint32_t hiw = (w + 1 < RW) ? cur.r[w + 1] : 0u;
+            const uint32_t cw = __builtin_amdgcn_perm(hiw, cur.r[w], sel[w]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int kk = 4 * w + t;
+                if (kk < M - 1) {
+                    const uint32_t code = (cw >> (8 * t)) & 0xffu;
+                    s = s + lds_tab[(kk * LSQ_H + code) * LPV + q];      // ascending k, plain f32 add
+                }
+            }
+        }
+        // partial first-argmin over this vector's SL candidates: in-lane 4, then across its LPV lanes
+        float lm = fminf(fminf(s.x, s.y), fminf(s.z, s.w));
+        int li = ((s.x == lm) ? 0 : (s.y == lm) ? 1 : (s.z == lm) ? 2 : 3) + 4 * q;
+        if (lm != lm) { lm = __builtin_inff(); li = 1000; }              // all-NaN lane: never wins
+        if (slice == 0 && q == 0 && s.x != s.x) { lm = -__builtin_inff(); li = 0; }   // s[0] NaN: strict-< scan keeps index 0
+        {
+            float ov = dpp_self<DPP_XOR1, 0xf>(lm);
+            int oi = __builtin_amdgcn_update_dpp(li, li, DPP_XOR1, 0xf, 0xf, false);
+            if (ov < lm || (ov == lm && oi < li)) { lm = ov; li = oi; }
+            if (LPV == 4) {
+                ov = dpp_self<DPP_XOR2, 0xf>(lm);
+                oi = __builtin_amdgcn_update_dpp(li, li, DPP_XOR2, 0xf, 0xf, false);
+                if (ov < lm || (ov == lm && oi < li)) { lm = ov; li = oi; }
+            }
+        }
+        if (q == 0 && i0 + v < hi) part[(int64_t)slice * n + i0 + v] = make_float2(lm, __int_as_float(li));
+    }
+}
+
+template <int SL>
+__global__ __launch_bounds__(256) void icm_combine_kernel(const float2 *__restrict__ part, uint8_t *__restrict__ rec, int64_t n, int cs, int j) {
+    constexpr int NS = LSQ_H / SL;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float2 p = part[i];
+    float best = p.x;
+    int bi = __float_as_int(p.y);
+#pragma unroll
+    for (int sl = 1; sl < NS; ++sl) {
+        p = part[(int64_t)sl * n + i];
+        if (p.x < best) { best = p.x; bi = SL * sl + __float_as_int(p.y); }      // strict <: lowest slice wins ties
+    }
+    rec[i * cs + j] = (uint8_t)(bi > 255 ? 0 : bi);
+}
+
 // ---- perturbation (cudautils.cu:27-80 / encode_icm.jl:55-70), one thread per vector ------------
 template <int CS>
 __global__ __launch_bounds__(256) void perturb_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int64_t n,
@@ -381,7 +508,55 @@ int lsq_launch_icm_fused(hipStream_t s, const float *U, const float *T, uint8_t 
     return LSQ_OK;
 }
 
-#define LSQ_CS_LAUNCH(m, KERNEL, GRID, ...)                                                        \
+template <int M, int SL>
+static int launch_slice_t(hipStream_t s, const float *Usj, const float *Tj, uint8_t *rec, float2 *part, int64_t n, int j) {
+    constexpr int NS = LSQ_H / SL;
+    constexpr int LDS_BYTES = (M - 1) * LSQ_H * SL * 4;
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    LSQ_HIP(hipGetDevice(&dev));
+    if (dev < 64 && !attr_set[dev]) {      // > 64 KiB of dynamic LDS needs the opt-in (per device)
+        LSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&icm_slice_kernel<M, SL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_set[dev] = true;
+    }
+    const int64_t per_iter = 16 * (64 / (SL / 4));            // vectors per block iteration
+    int64_t nranges = (n + 4 * per_iter - 1) / (4 * per_iter);
+    const int64_t max_ranges = 512 / NS;                       // ~2 blocks per CU over the launch (1 resident: LDS)
+    if (nranges > max_ranges) nranges = max_ranges;
+    if (nranges < 1) nranges = 1;
+    hipLaunchKernelGGL((icm_slice_kernel<M, SL>), dim3((unsigned)(NS * nranges)), dim3(1024), LDS_BYTES, s, Usj, Tj, rec, part, n, j, (int)nranges);
+    LSQ_HIP(hipGetLastError());
+    const int cs = (M <= 8) ? 8 : 16;
+    hipLaunchKernelGGL((icm_combine_kernel<SL>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, rec, n, cs, j);
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}
+
+int lsq_launch_icm_slice(hipStream_t s, const float *Usj, const float *T, uint8_t *rec, float2 *part, int64_t n, int m, int j) {
+    if (n <= 0) return LSQ_OK;
+    const float *Tj = T + (int64_t)j * m * LSQ_H * LSQ_H;
+    switch (m) {
+        case 1: return launch_slice_t<1, 16>(s, Usj, Tj, rec, part, n, j);
+        case 2: return launch_slice_t<2, 16>(s, Usj, Tj, rec, part, n, j);
+        case 3: return launch_slice_t<3, 16>(s, Usj, Tj, rec, part, n, j);
+        case 4: return launch_slice_t<4, 16>(s, Usj, Tj, rec, part, n, j);
+        case 5: return launch_slice_t<5, 16>(s, Usj, Tj, rec, part, n, j);
+        case 6: return launch_slice_t<6, 16>(s, Usj, Tj, rec, part, n, j);
+        case 7: return launch_slice_t<7, 16>(s, Usj, Tj, rec, part, n, j);
+        case 8: return launch_slice_t<8, 16>(s, Usj, Tj, rec, part, n, j);
+        case 9: return launch_slice_t<9, 16>(s, Usj, Tj, rec, part, n, j);
+        case 10: return launch_slice_t<10, 16>(s, Usj, Tj, rec, part, n, j);
+        case 11: return launch_slice_t<11, 8>(s, Usj, Tj, rec, part, n, j);
+        case 12: return launch_slice_t<12, 8>(s, Usj, Tj, rec, part, n, j);
+        case 13: return launch_slice_t<13, 8>(s, Usj, Tj, rec, part, n, j);
+        case 14: return launch_slice_t<14, 8>(s, Usj, Tj, rec, part, n, j);
+        case 15: return launch_slice_t<15, 8>(s, Usj, Tj, rec, part, n, j);
+        case 16: return launch_slice_t<16, 8>(s, Usj, Tj, rec, part, n, j);
+        default: lsq_set_error("m = %d out of range 1..16", m); return LSQ_EINVAL;
+    }
+}
+
+#define LSQ_CS_LAUNCH(m, KERNEL, GRID, ...)                                                       \
     do {                                                                                           \
         if (lsq_code_stride(m) == 8) hipLaunchKernelGGL(KERNEL<8>, dim3(GRID), dim3(256), 0, s, __VA_ARGS__);  \
         else hipLaunchKernelGGL(KERNEL<16>, dim3(GRID), dim3(256), 0, s, __VA_ARGS__);             \

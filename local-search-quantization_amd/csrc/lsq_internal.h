@@ -69,9 +69,11 @@ __host__ __device__ inline uint32_t lsq_mulhi32(uint32_t a, uint32_t b) { return
 // All pointers are device pointers; all launch on `s` and return immediately.
 
 // D[off(r,c)] = chain_t( A[r][t] * (alpha * Bm[c][t]) ) (+ addv[c]);  r<M, c<N, t<Kd.
-// off(r,c) = (c / h) * plane_stride + (c % h) + r * row_stride.   Chain = k-ascending fmaf from +0.
+// off(r,c) = (c / h) * plane_stride + (c % h) + r * row_stride            (slice == 0, row-major planes)
+//          = (c / h) * plane_stride + ((c % h) / slice) * (M * slice) + (c % h) % slice + r * slice   (slice-major)
+// Chain = k-ascending fmaf from +0.
 int lsq_launch_chain_gemm(hipStream_t s, const float *A, const float *Bm, const float *addv, float alpha,
-                          int64_t M, int N, int Kd, int h, int64_t plane_stride, int64_t row_stride, float *D);
+                          int64_t M, int N, int Kd, int h, int64_t plane_stride, int64_t row_stride, float *D, int slice);
 // sci[r] = chain_t(Kb[r][t]^2)
 int lsq_launch_sqnorms(hipStream_t s, const float *Kb, int rows, int d, float *sci);
 
@@ -90,6 +92,9 @@ int lsq_launch_icm_node(hipStream_t s, const float *Uj, const float *T, uint8_t 
 // fused: for every vector, all `nsweeps` sweeps in `order` with register-resident unaries
 int lsq_launch_icm_fused(hipStream_t s, const float *U, const float *T, uint8_t *rec, int64_t n, int m,
                          const int32_t *order_host, int nsweeps);
+// LDS-slice schedule: U plane j is slice-major [256/SL][n][SL]; part = [256/SL][n] (min, local idx) scratch
+static inline int lsq_slice_width(int m) { return m <= 10 ? 16 : 8; }
+int lsq_launch_icm_slice(hipStream_t s, const float *Usj, const float *T, uint8_t *rec, float2 *part, int64_t n, int m, int j);
 // cost of `rec`; mode 0: prev[i] = cost.  mode 1 (accept): if cost < prev[i] { cur[i] = rec[i]; prev[i] = cost }
 // and counters[0] += (#cost == prev), counters[1] += (#cost < prev)   (counters: 2 x uint64 on device)
 int lsq_launch_cost(hipStream_t s, const float *X, const float *K, const uint8_t *rec, uint8_t *cur, float *prev,
