@@ -347,39 +347,65 @@ __global__ __launch_bounds__(256) void perturb_kernel(const uint8_t *__restrict_
 // ---- cost (+ accept) ----------------------------------------------------------------------------
 // utils.jl:225-254 per vector, reduction order = oracle cost_one(); mode 1 applies
 // encode_icm.jl:178-186 (keep the new codes iff strictly better) and counts ==/< .
-template <int CS>
+template <int M>
 __global__ __launch_bounds__(256) void cost_kernel(const float *__restrict__ X, const float *__restrict__ K,
-                                                   const uint8_t *__restrict__ rec, uint8_t *__restrict__ cur,
-                                                   float *__restrict__ prev, unsigned long long *__restrict__ counters,
-                                                   int64_t n, int d, int m, int mode) {
+                                                   const uint8_t *rec, uint8_t *cur, float *__restrict__ prev,
+                                                   unsigned long long *__restrict__ counters, int64_t n, int d, int mode) {
+    constexpr int CS = (M <= 8) ? 8 : 16;
+    constexpr int NV = 2;                     // vectors in flight per wave (memory-level parallelism)
     const int lane = threadIdx.x & 63;
     const int64_t nwaves = (int64_t)gridDim.x * 4;
-    int64_t i = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int64_t w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     unsigned n_eq = 0, n_lt = 0;
-    for (; i < n; i += nwaves) {
-        const CodeRec cr = load_rec<CS>(rec, i);
-        const float *x = X + i * (int64_t)d;
-        float part = 0.0f;
-        for (int t = lane; t < d; t += 64) {
-            float cb = 0.0f;
-            for (int k = 0; k < m; ++k) cb = cb + K[((int64_t)(k * LSQ_H) + cr.get(k)) * d + t];
-            const float r = cb - x[t];
-            const float sq = r * r;
-            part = part + sq;
+    for (int64_t i0 = w * NV; i0 < n; i0 += nwaves * NV) {
+        CodeRec cr[NV];
+        int64_t ii[NV];
+        float pcv[NV], part[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {        // every independent load is issued up front
+            ii[v] = (i0 + v < n) ? i0 + v : n - 1;
+            cr[v] = load_rec<CS>(rec, ii[v]);
+            pcv[v] = (mode == 1) ? prev[ii[v]] : 0.0f;
+            part[v] = 0.0f;
         }
-        const float cost = wave_sum_tree(part);
-        if (mode == 0) {
-            if (lane == 0) prev[i] = cost;
-        } else {
-            const float pc = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(prev[i])));
-            n_eq += (cost == pc);
-            if (cost < pc) {
-                ++n_lt;
-                if (lane == 0) {
-                    prev[i] = cost;
-                    uint64_t *q = reinterpret_cast<uint64_t *>(cur + i * CS);
-                    q[0] = cr.lo;
-                    if (CS == 16) q[1] = cr.hi;
+        for (int t0 = 0; t0 < d; t0 += 64) {
+            const int t = t0 + lane;
+            const bool valid = t < d;
+            const int tt = valid ? t : 0;
+            float xv[NV], kv[NV][M];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                xv[v] = X[ii[v] * (int64_t)d + tt];
+#pragma unroll
+                for (int k = 0; k < M; ++k) kv[v][k] = K[((int64_t)(k * LSQ_H) + cr[v].get(k)) * d + tt];
+            }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                float cb = 0.0f;
+#pragma unroll
+                for (int k = 0; k < M; ++k) cb = cb + kv[v][k];          // k ascending from 0 (utils.jl:238-244)
+                const float r = cb - xv[v];
+                const float sq = r * r;                                   // never fused (-ffp-contract=off)
+                part[v] = part[v] + (valid ? sq : 0.0f);                  // lane partial: t = lane + 64 q, q ascending
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const float cost = wave_sum_tree(part[v]);
+            if (i0 + v >= n) continue;
+            if (mode == 0) {
+                if (lane == 0) prev[ii[v]] = cost;
+            } else {
+                const float pc = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pcv[v])));
+                n_eq += (cost == pc);
+                if (cost < pc) {                                          // strict improvement only (encode_icm.jl:183-186)
+                    ++n_lt;
+                    if (lane == 0) {
+                        prev[ii[v]] = cost;
+                        uint64_t *q = reinterpret_cast<uint64_t *>(cur + ii[v] * CS);
+                        q[0] = cr[v].lo;
+                        if (CS == 16) q[1] = cr[v].hi;
+                    }
                 }
             }
         }
@@ -573,7 +599,8 @@ int lsq_launch_perturb(hipStream_t s, const uint8_t *src, uint8_t *dst, int64_t 
 int lsq_launch_cost(hipStream_t s, const float *X, const float *K, const uint8_t *rec, uint8_t *cur, float *prev,
                     unsigned long long *counters, int64_t n, int d, int m, int mode) {
     if (n <= 0) return LSQ_OK;
-    LSQ_CS_LAUNCH(m, cost_kernel, wave_grid(n), X, K, rec, cur, prev, counters, n, d, m, mode);
+    LSQ_DISPATCH_M(m, hipLaunchKernelGGL(cost_kernel<M_>, dim3(wave_grid((n + 1) / 2)), dim3(256), 0, s, X, K, rec, cur, prev, counters, n, d, mode));
+    LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }
 

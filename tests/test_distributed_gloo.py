@@ -1,0 +1,91 @@
+"""world_size = 2 on CPU (gloo): the sharded-encode logic of local-search-quantization_amd/distributed.py
+-- splitarray sharding, codebook broadcast from rank 0, all-reduce of objective sums and counters,
+padded gather of ragged shards -- with an ORACLE-backed shard encoder injected (tests only; the
+product's default shard encoder is the HIP engine and refuses to run without a GPU)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+H = 256
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _oracle_shard_encoder(X, B0, K, m, ilsiters, icmiter, npert, randord, seed, global_offset):
+    import oracle as O
+    Bs, objs, stats = O.encode_icm(X.numpy(), B0.numpy().astype(np.int16) + 1, K.numpy(), m, H, ilsiters, icmiter, npert,
+                                   randord, seed, global_offset=global_offset, want_stats=True)
+    n = X.shape[0]
+    return torch.from_numpy((Bs - 1).astype(np.uint8)), objs.astype(np.float64) * n, stats
+
+
+def _worker(rank, world, port, n, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import importlib
+    from conftest import make_problem
+    lsq = importlib.import_module("local-search-quantization_amd")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        d, m = 32, 4
+        X, K, B0 = make_problem(d, n, m, seed=77, kind="gauss")
+        s, e = lsq.distributed.shard_range(n, world, rank)
+        Kt = torch.from_numpy(K.copy()) if rank == 0 else torch.zeros((m * H, d), dtype=torch.float32)   # only rank 0 has C
+        codes, objs, stats, gathered = lsq.distributed.encode_sharded(
+            torch.from_numpy(X[s:e].copy()), torch.from_numpy((B0[s:e] - 1).astype(np.uint8)), Kt, m, [1, 3], 2, 2, True, 5,
+            n_total=n, shard_start=s, shard_encoder=_oracle_shard_encoder, gather_codes=True)
+        assert torch.equal(Kt, torch.from_numpy(K)), "codebooks were not broadcast"
+        q.put((rank, (s, e), codes.numpy(), objs, stats, None if gathered is None else gathered.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [101, 64])
+def test_two_rank_sharded_encode_equals_single_process(oracle, n):
+    from conftest import make_problem
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r = q.get(timeout=180)
+        res[r[0]] = r
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    X, K, B0 = make_problem(32, n, 4, seed=77, kind="gauss")
+    Bs_ref, objs_ref, st_ref = oracle.encode_icm(X, B0, K, 4, H, [1, 3], 2, 2, True, 5, want_stats=True)
+    # ranges are splitarray(1:n, 2): first n mod 2 shards one longer
+    assert res[0][1] == (0, (n + 1) // 2) and res[1][1] == ((n + 1) // 2, n)
+    both = np.concatenate([res[0][2], res[1][2]], axis=1).astype(np.int16) + 1
+    assert np.array_equal(both, Bs_ref)                                   # P8: sharding-invariant codes
+    for r in (0, 1):
+        assert np.allclose(res[r][3], objs_ref, rtol=1e-6)                # all-reduced objective, same on every rank
+        assert np.array_equal(res[r][4], st_ref.astype(np.int64))
+    assert res[1][5] is None
+    assert np.array_equal(res[0][5].astype(np.int16) + 1, Bs_ref)         # padded gather of ragged shards on rank 0
+
+
+def test_product_shard_encoder_refuses_cpu(lsq):
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        lsq.distributed.encode_sharded(torch.zeros(4, 8), torch.zeros(4, 2, dtype=torch.uint8), torch.zeros(512, 8), 2, [1], 1, 1,
+                                       True, 0, n_total=4, shard_start=0)
