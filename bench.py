@@ -44,8 +44,10 @@ def parse():
     p.add_argument("--ils", type=int, default=16)
     p.add_argument("--icmiter", type=int, default=4)
     p.add_argument("--npert", type=int, default=4)
-    p.add_argument("--schedule", type=int, default=int(os.environ.get("LSQ_SCHEDULE", "2")))
+    p.add_argument("--schedule", type=int, default=int(os.environ.get("LSQ_SCHEDULE", "3")))
     p.add_argument("--chunk", type=int, default=int(os.environ.get("LSQ_CHUNK", "0")))
+    p.add_argument("--skip", type=int, default=int(os.environ.get("LSQ_SKIP", "1")),
+                   help="schedule 3: exact memoisation of node updates whose inputs did not change (1) or recompute everything (0)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline budget")
     return p.parse_args()
@@ -104,6 +106,7 @@ def main():
 
     n, d, m, h = args.n, args.d, args.m, 256
     eng = lsq.Engine(local_rank, profile=True, schedule=args.schedule, chunk=(args.chunk or None))
+    eng.set_option("skip", args.skip)
     goff = rank * n
     dX = eng.synth_data_u8_dev(1234, n, d, global_offset=goff)
     dB0 = eng.randinit_dev(7, n, m, global_offset=goff)
@@ -162,12 +165,12 @@ def main():
                 "workload": "BASELINE configs[1]: SIFT1M-shaped base encode, %d x %d f32 per GPU, m=%d, h=%d, %d ILS iters x %d ICM sweeps, "
                             "npert=%d, randord, seed=42; inputs resident in HBM; lsq_encode_icm_dev" % (n, d, m, h, args.ils, args.icmiter, args.npert),
                 "vectors_per_gpu": n, "d": d, "m": m, "h": h, "ils_iters": args.ils, "icm_iters": args.icmiter, "npert": args.npert,
-                "schedule": {0: "per-node launches, L2 gathers (M2 data-flow)", 1: "fused sweeps per ILS iteration (M1 data-flow)", 2: "per-node launches, LDS-staged table slices, slice-major U stream (M2 data-flow)"}[args.schedule],
+                "schedule": {0: "per-node launches, L2 gathers (M2 data-flow)", 1: "fused sweeps per ILS iteration (M1 data-flow)", 2: "per-node launches, LDS-staged table slices, slice-major U stream (M2 data-flow)", 3: "per-node launches, one block walks all LDS-staged slices (no partials), slice-major U stream (M2 data-flow)"}[args.schedule],
                 "parallelism": "%d x independent shards, RCCL broadcast of codebooks" % world,
             },
             "objective": float(sums[0] / n), "last_ils_pct_better": float(100.0 * stats[-1, 1] / n),
             "roofline": {
-                "kernel": {0: "icm_node_kernel<%d>", 1: "icm_fused_kernel<%d>", 2: "icm_slice_kernel<%d,SL> + icm_combine_kernel"}[args.schedule] % m,
+                "kernel": {0: "icm_node_kernel<%d>", 1: "icm_fused_kernel<%d>", 2: "icm_slice_kernel<%d,SL> + icm_combine_kernel", 3: "icm_walk_kernel<%d,SL>"}[args.schedule] % m,
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
                 "avg_launch_us": avg_launch_s * 1e6, "launches": int(tm["icm_launches"]),

@@ -57,9 +57,10 @@ struct lsq_ctx {
     hipStream_t stream = nullptr;
     int64_t chunk = 1 << 20;
     int profile = 0;
-    int schedule = 2;        // 0: per-node gather kernel, 1: fused sweeps, 2: per-node LDS-slice kernel (default)
+    int schedule = 3;        // 0: per-node L2-gather kernel, 1: fused sweeps, 2: LDS-slice + combine, 3: LDS-walk (default)
+    int skip = 1;            // schedule 3: skip node updates whose inputs did not change (exact memoisation)
     // workspace
-    DevBuf sci, T, U, part, recCur, recNew, prev, counters, obj, bad;
+    DevBuf sci, T, Ts, U, part, vCur, vNew, active, recCur, recNew, prev, counters, obj, bad;
     DevBuf sX, sK, sB16, sOut16, sTight, sF32;    // staging for the host-buffer entry points
     // timings
     double cat_ms[CAT_COUNT] = {0, 0, 0, 0, 0, 0};
@@ -138,7 +139,7 @@ extern "C" int lsq_destroy(lsq_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : c->pool) (void)hipEventDestroy(e);
-    DevBuf *bufs[] = {&c->sci, &c->T, &c->U, &c->part, &c->recCur, &c->recNew, &c->prev, &c->counters, &c->obj, &c->bad,
+    DevBuf *bufs[] = {&c->sci, &c->T, &c->Ts, &c->U, &c->part, &c->vCur, &c->vNew, &c->active, &c->recCur, &c->recNew, &c->prev, &c->counters, &c->obj, &c->bad,
                       &c->sX, &c->sK, &c->sB16, &c->sOut16, &c->sTight, &c->sF32};
     for (DevBuf *b : bufs) b->release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -159,8 +160,9 @@ extern "C" int lsq_set_option(lsq_ctx *c, const char *key, int64_t value) {
         c->chunk = value;
     } else if (!strcmp(key, "profile")) c->profile = value != 0;
     else if (!strcmp(key, "own_stream")) c->stream = c->own_stream;
+    else if (!strcmp(key, "skip")) c->skip = value != 0;
     else if (!strcmp(key, "schedule")) {
-        if (value < 0 || value > 2) { lsq_set_error("schedule must be 0, 1 or 2"); return LSQ_EINVAL; }
+        if (value < 0 || value > 3) { lsq_set_error("schedule must be 0..3"); return LSQ_EINVAL; }
         c->schedule = (int)value;
     } else { lsq_set_error("unknown option '%s'", key); return LSQ_EINVAL; }
     return LSQ_OK;
@@ -231,6 +233,10 @@ static int check_shape(const char *fn, int d, int64_t n, int m, int h) {
 }
 
 // ---- device core ----------------------------------------------------------------------------------
+static int u_slice_width(const lsq_ctx *c, int m) {      // layout of the unary planes for the active schedule
+    return c->schedule == 2 ? lsq_slice_width(m) : c->schedule == 3 ? lsq_walk_slice_width(m) : 0;
+}
+
 static int prepare_tables(lsq_ctx *c, const float *dK, int d, int m) {
     Timer t(c, CAT_TABLES);
     const int mh = m * LSQ_H;
@@ -239,6 +245,10 @@ static int prepare_tables(lsq_ctx *c, const float *dK, int d, int m) {
     LSQ_TRY(lsq_launch_sqnorms(c->stream, dK, mh, d, c->sci.as<float>()));
     // rows r = (k,b), cols c = (j,a):  T[((j*m + k)*h + b)*h + a] = chain(K[k,b][t] * 2 K[j,a][t])
     LSQ_TRY(lsq_launch_chain_gemm(c->stream, dK, dK, nullptr, 2.0f, mh, mh, d, LSQ_H, (int64_t)m * LSQ_H * LSQ_H, LSQ_H, c->T.as<float>(), 0));
+    if (c->schedule == 3 && m > 1) {        // slice-major copy for the LDS-walk kernel's contiguous staging
+        LSQ_TRY(c->Ts.ensure(sizeof(float) * (size_t)m * (m - 1) * LSQ_H * LSQ_H));
+        LSQ_TRY(lsq_launch_tables_to_slices(c->stream, c->T.as<float>(), c->Ts.as<float>(), m, lsq_walk_slice_width(m)));
+    }
     return LSQ_OK;
 }
 
@@ -250,11 +260,19 @@ static int build_unaries(lsq_ctx *c, const float *dX, const float *dK, int d, in
     return lsq_launch_chain_gemm(c->stream, dX, dK, c->sci.as<float>(), -2.0f, cn, m * LSQ_H, d, LSQ_H, cn * (int64_t)LSQ_H, LSQ_H, c->U.as<float>(), slice);
 }
 
-static int run_sweeps(lsq_ctx *c, uint8_t *rec, int64_t cn, int m, const int32_t *order, int nsweeps) {
+static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t cn, int m, const int32_t *order, int nsweeps) {
     Timer t(c, CAT_ICM);
     if (c->schedule == 1) {
         LSQ_TRY(lsq_launch_icm_fused(c->stream, c->U.as<float>(), c->T.as<float>(), rec, cn, m, order, nsweeps));
         c->icm_launches += 1;
+    } else if (c->schedule == 3) {
+        for (int sw = 0; sw < nsweeps; ++sw)
+            for (int q = 0; q < m; ++q) {
+                const int j = order[q];
+                LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>() + (int64_t)j * cn * LSQ_H, c->Ts.as<float>(), rec, valid, cn, m, j, c->skip,
+                                            c->active.as<unsigned long long>()));
+            }
+        c->icm_launches += (int64_t)nsweeps * m;
     } else if (c->schedule == 2) {
         LSQ_TRY(c->part.ensure(sizeof(float2) * (size_t)cn * (LSQ_H / lsq_slice_width(m))));
         for (int sw = 0; sw < nsweeps; ++sw)
@@ -271,7 +289,7 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, int64_t cn, int m, const int32_t
             }
         c->icm_launches += (int64_t)nsweeps * m;
     }
-    c->icm_node_updates += cn * (int64_t)nsweeps * m;
+    if (c->schedule != 3) c->icm_node_updates += cn * (int64_t)nsweeps * m;      // schedule 3 counts on the device (skips)
     return LSQ_OK;
 }
 
@@ -286,27 +304,31 @@ struct EncodeParams {
 template <class Snap>
 static int encode_chunk(lsq_ctx *c, const float *dXc, const float *dK, int64_t cn, uint64_t goff, const EncodeParams &P, int64_t I, Snap snap) {
     const int cs = lsq_code_stride(P.m);
-    LSQ_TRY(build_unaries(c, dXc, dK, P.d, cn, P.m, c->schedule == 2 ? lsq_slice_width(P.m) : 0));
+    LSQ_TRY(build_unaries(c, dXc, dK, P.d, cn, P.m, u_slice_width(c, P.m)));
     LSQ_TRY(c->recNew.ensure((size_t)cn * cs));
     LSQ_TRY(c->prev.ensure(sizeof(float) * (size_t)cn));
+    LSQ_TRY(c->vCur.ensure(sizeof(unsigned short) * (size_t)cn));
+    LSQ_TRY(c->vNew.ensure(sizeof(unsigned short) * (size_t)cn));
+    LSQ_HIP(hipMemsetAsync(c->vCur.p, 0, sizeof(unsigned short) * (size_t)cn, c->stream));      // nothing is known to be an argmin yet
+    unsigned short *vcur = c->vCur.as<unsigned short>(), *vnew = c->vNew.as<unsigned short>();
     uint8_t *cur = c->recCur.as<uint8_t>(), *nw = c->recNew.as<uint8_t>();
     float *prev = c->prev.as<float>();
     unsigned long long *counters = c->counters.as<unsigned long long>();
     {
         Timer t(c, CAT_COST);
-        LSQ_TRY(lsq_launch_cost(c->stream, dXc, dK, cur, cur, prev, counters, cn, P.d, P.m, 0));   // encode_icm.jl:149
+        LSQ_TRY(lsq_launch_cost(c->stream, dXc, dK, cur, cur, prev, counters, cn, P.d, P.m, 0, nullptr, nullptr));   // encode_icm.jl:149
     }
     for (int64_t it = 0; it < I; ++it) {
         int32_t order[LSQ_MAX_M];
         LSQ_TRY(lsq_node_order(P.seed, P.it0 + (uint32_t)it, P.m, P.randord, order));
         {
             Timer t(c, CAT_PERTURB);
-            LSQ_TRY(lsq_launch_perturb(c->stream, cur, nw, cn, P.m, P.npert, P.seed, P.it0 + (uint32_t)it, goff));
+            LSQ_TRY(lsq_launch_perturb(c->stream, cur, nw, cn, P.m, P.npert, P.seed, P.it0 + (uint32_t)it, goff, vcur, vnew));
         }
-        LSQ_TRY(run_sweeps(c, nw, cn, P.m, order, P.icmiter));
+        LSQ_TRY(run_sweeps(c, nw, vnew, cn, P.m, order, P.icmiter));
         {
             Timer t(c, CAT_COST);
-            LSQ_TRY(lsq_launch_cost(c->stream, dXc, dK, nw, cur, prev, counters + 2 * it, cn, P.d, P.m, 1));
+            LSQ_TRY(lsq_launch_cost(c->stream, dXc, dK, nw, cur, prev, counters + 2 * it, cn, P.d, P.m, 1, vnew, vcur));
         }
         for (int r = 0; r < P.nr; ++r)
             if (P.ilsiters[r] == it + 1) {
@@ -334,6 +356,8 @@ static int begin_call(lsq_ctx *c, int64_t I, int nr) {
     LSQ_TRY(c->counters.ensure(sizeof(unsigned long long) * 2 * (size_t)std::max<int64_t>(I, 1)));
     LSQ_TRY(c->obj.ensure(sizeof(double) * (size_t)std::max(nr, 1)));
     LSQ_TRY(c->bad.ensure(sizeof(int)));
+    LSQ_TRY(c->active.ensure(sizeof(unsigned long long)));
+    LSQ_HIP(hipMemsetAsync(c->active.p, 0, sizeof(unsigned long long), c->stream));
     LSQ_HIP(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long) * 2 * (size_t)std::max<int64_t>(I, 1), c->stream));
     LSQ_HIP(hipMemsetAsync(c->obj.p, 0, sizeof(double) * (size_t)std::max(nr, 1), c->stream));
     LSQ_HIP(hipMemsetAsync(c->bad.p, 0, sizeof(int), c->stream));
@@ -344,7 +368,10 @@ static int finish_call(lsq_ctx *c, int64_t I, int nr, double *obj_sums, int64_t 
     std::vector<unsigned long long> cnt(2 * (size_t)std::max<int64_t>(I, 1));
     LSQ_HIP(hipMemcpyAsync(obj_sums, c->obj.p, sizeof(double) * (size_t)nr, hipMemcpyDeviceToHost, c->stream));
     LSQ_HIP(hipMemcpyAsync(cnt.data(), c->counters.p, sizeof(unsigned long long) * cnt.size(), hipMemcpyDeviceToHost, c->stream));
+    unsigned long long act = 0;
+    LSQ_HIP(hipMemcpyAsync(&act, c->active.p, sizeof(act), hipMemcpyDeviceToHost, c->stream));
     LSQ_HIP(hipStreamSynchronize(c->stream));
+    if (c->schedule == 3) c->icm_node_updates += (int64_t)act;
     if (stats) for (int64_t q = 0; q < 2 * I; ++q) stats[q] = (int64_t)cnt[(size_t)q];
     return LSQ_OK;
 }
@@ -475,12 +502,15 @@ extern "C" int lsq_encode_icm_fully(lsq_ctx *c, int16_t *B, const float *X, cons
     LSQ_TRY(upload_xk(c, X, K, d, n, m));
     LSQ_TRY(upload_codes(c, B, n, m, h, c->recCur));
     LSQ_TRY(prepare_tables(c, c->sK.as<float>(), d, m));
-    LSQ_TRY(build_unaries(c, c->sX.as<float>(), c->sK.as<float>(), d, n, m, c->schedule == 2 ? lsq_slice_width(m) : 0));
+    LSQ_TRY(build_unaries(c, c->sX.as<float>(), c->sK.as<float>(), d, n, m, u_slice_width(c, m)));
     LSQ_TRY(c->recNew.ensure((size_t)n * lsq_code_stride(m)));
     int32_t order[LSQ_MAX_M];
     LSQ_TRY(lsq_node_order(seed, it, m, randord, order));
-    LSQ_TRY(lsq_launch_perturb(c->stream, c->recCur.as<uint8_t>(), c->recNew.as<uint8_t>(), n, m, npert, seed, it, (uint64_t)(idx_first - 1)));
-    LSQ_TRY(run_sweeps(c, c->recNew.as<uint8_t>(), n, m, order, niter));
+    LSQ_TRY(c->vNew.ensure(sizeof(unsigned short) * (size_t)n));
+    LSQ_TRY(c->active.ensure(sizeof(unsigned long long)));
+    LSQ_HIP(hipMemsetAsync(c->vNew.p, 0, sizeof(unsigned short) * (size_t)n, c->stream));
+    LSQ_TRY(lsq_launch_perturb(c->stream, c->recCur.as<uint8_t>(), c->recNew.as<uint8_t>(), n, m, npert, seed, it, (uint64_t)(idx_first - 1), nullptr, nullptr));
+    LSQ_TRY(run_sweeps(c, c->recNew.as<uint8_t>(), c->vNew.as<unsigned short>(), n, m, order, niter));
     LSQ_TRY(lsq_launch_codes_to_i16(c->stream, c->recNew.as<uint8_t>(), n, m, c->sB16.as<int16_t>()));
     LSQ_HIP(hipMemcpyAsync(B, c->sB16.p, sizeof(int16_t) * (size_t)n * m, hipMemcpyDeviceToHost, c->stream));
     LSQ_HIP(hipStreamSynchronize(c->stream));
@@ -521,7 +551,7 @@ extern "C" int lsq_veccost(lsq_ctx *c, const float *X, const int16_t *B, const f
     LSQ_TRY(upload_codes(c, B, n, m, h, c->recCur));
     LSQ_TRY(c->prev.ensure(sizeof(float) * (size_t)n));
     LSQ_TRY(lsq_launch_cost(c->stream, c->sX.as<float>(), c->sK.as<float>(), c->recCur.as<uint8_t>(), c->recCur.as<uint8_t>(),
-                            c->prev.as<float>(), nullptr, n, d, m, 0));
+                            c->prev.as<float>(), nullptr, n, d, m, 0, nullptr, nullptr));
     LSQ_HIP(hipMemcpyAsync(cost, c->prev.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     LSQ_HIP(hipStreamSynchronize(c->stream));
     return LSQ_OK;
@@ -539,7 +569,7 @@ extern "C" int lsq_qerror(lsq_ctx *c, const float *X, const int16_t *B, const fl
     LSQ_TRY(c->obj.ensure(sizeof(double)));
     LSQ_HIP(hipMemsetAsync(c->obj.p, 0, sizeof(double), c->stream));
     LSQ_TRY(lsq_launch_cost(c->stream, c->sX.as<float>(), c->sK.as<float>(), c->recCur.as<uint8_t>(), c->recCur.as<uint8_t>(),
-                            c->prev.as<float>(), nullptr, n, d, m, 0));
+                            c->prev.as<float>(), nullptr, n, d, m, 0, nullptr, nullptr));
     LSQ_TRY(lsq_launch_sum_f64(c->stream, c->prev.as<float>(), n, c->obj.as<double>()));
     double sum = 0.0;
     LSQ_HIP(hipMemcpyAsync(&sum, c->obj.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -555,7 +585,7 @@ extern "C" int lsq_perturb(lsq_ctx *c, int16_t *B, int64_t n, int m, int h, int 
     if (n == 0) return LSQ_OK;
     LSQ_TRY(upload_codes(c, B, n, m, h, c->recCur));
     LSQ_TRY(c->recNew.ensure((size_t)n * lsq_code_stride(m)));
-    LSQ_TRY(lsq_launch_perturb(c->stream, c->recCur.as<uint8_t>(), c->recNew.as<uint8_t>(), n, m, npert, seed, it, global_offset));
+    LSQ_TRY(lsq_launch_perturb(c->stream, c->recCur.as<uint8_t>(), c->recNew.as<uint8_t>(), n, m, npert, seed, it, global_offset, nullptr, nullptr));
     LSQ_TRY(lsq_launch_codes_to_i16(c->stream, c->recNew.as<uint8_t>(), n, m, c->sB16.as<int16_t>()));
     LSQ_HIP(hipMemcpyAsync(B, c->sB16.p, sizeof(int16_t) * (size_t)n * m, hipMemcpyDeviceToHost, c->stream));
     LSQ_HIP(hipStreamSynchronize(c->stream));

@@ -20,6 +20,8 @@
 //
 // One wave = one vector: lane l owns candidates 4l..4l+3; a table column or unary row is exactly
 // one coalesced `global_load_dwordx4`.  The wave-level argmin is a 6-step DPP min + one ballot.
+#include <stdlib.h>
+
 #include "lsq_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -299,6 +301,189 @@ __global__ __launch_bounds__(1024) void icm_slice_kernel(const float *__restrict
     }
 }
 
+// ---- LDS-walk schedule (schedule 3) ----------------------------------------------------------------
+// Same arithmetic as icm_slice_kernel, but ONE block walks all 256/SL slices for its own range of
+// <= 4096 vectors, keeping the running (min value, index) of every vector in LDS.  This removes the
+// partial-result round trip through HBM (2 x 8 B x 256/SL per vector and node update) and the combine
+// launch; the price is re-staging the (m-1) x 256 x SL x 4 B slice table from L2 once per slice.
+// Ts is the slice-major copy of the pair tables, Ts[j][slice][kk][b][SL] (kk = rank of k among k != j),
+// so that staging is one contiguous, fully coalesced copy.
+template <int M, int SL>
+__global__ __launch_bounds__(1024) void icm_walk_kernel(const float *__restrict__ Usj, const float *__restrict__ Tsj,
+                                                        uint8_t *__restrict__ rec, unsigned short *__restrict__ valid,
+                                                        int64_t n, int j, int per_pass, int use_skip,
+                                                        unsigned long long *__restrict__ active_total) {
+    constexpr int CS = (M <= 8) ? 8 : 16;
+    constexpr int NS = LSQ_H / SL;
+    constexpr int LPV = SL / 4;
+    constexpr int VPW = 64 / LPV;
+    constexpr int CW = (M - 1 + 3) / 4;
+    constexpr int RW = CS / 4;
+    constexpr int TAB = (M - 1) * LSQ_H * LPV;          // f32x4 entries of one slice table
+    extern __shared__ f32x4 lds_walk[];
+    f32x4 *tab = lds_walk;
+    float *bestv = reinterpret_cast<float *>(lds_walk + TAB);                      // [4096] by compact index
+    unsigned short *besti = reinterpret_cast<unsigned short *>(bestv + 4096);      // [4096]
+    unsigned short *list = besti + 4096;                                           // [4096] active local indices
+    __shared__ int wave_tot[16];
+    __shared__ int nact_s;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int v = lane / LPV, q = lane % LPV;
+    constexpr int step = 16 * VPW;
+
+    uint32_t sel[CW > 0 ? CW : 1];
+#pragma unroll
+    for (int w = 0; w < CW; ++w) {
+        uint32_t sv = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int kk = 4 * w + t;
+            const int k = kk + (kk >= j ? 1 : 0);
+            sv |= (uint32_t)((kk < M - 1 ? k - 4 * w : 0) & 7) << (8 * t);
+        }
+        sel[w] = sv;
+    }
+
+    struct Item { f32x4 u; uint32_t r[RW]; };
+
+    const int64_t npass = (n + per_pass - 1) / per_pass;
+    for (int64_t pass = blockIdx.x; pass < npass; pass += gridDim.x) {
+        const int64_t lo = pass * per_pass;
+        const int64_t hi = (lo + per_pass < n) ? lo + per_pass : n;
+        const int cnt = (int)(hi - lo);
+
+        // ---- compact list of the vectors whose node j must be recomputed (exact skip: a node whose
+        // conditioning codes did not change since it was last minimised keeps the same argmin)
+        {
+            const int base = (int)threadIdx.x * 4;
+            int f[4], c = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int idx = base + e;
+                f[e] = 0;
+                if (idx < cnt) f[e] = (!use_skip) || !((valid[lo + idx] >> j) & 1);
+                c += f[e];
+            }
+            int inc = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += t;
+            }
+            if (lane == 63) wave_tot[wave] = inc;
+            __syncthreads();
+            int wbase = 0;
+            for (int w2 = 0; w2 < wave; ++w2) wbase += wave_tot[w2];
+            int pos = wbase + inc - c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (f[e]) list[pos++] = (unsigned short)(base + e);
+            if (threadIdx.x == 1023) nact_s = wbase + inc;
+            __syncthreads();
+        }
+        const int nact = nact_s;
+        if (nact == 0) continue;                               // block-uniform
+        if (threadIdx.x == 0 && active_total) atomicAdd(active_total, (unsigned long long)nact);
+
+        for (int slice = 0; slice < NS; ++slice) {
+            const float *Ub = Usj + (int64_t)slice * n * SL;
+            auto load_item = [&](int c0, Item &it) {
+                const int ci = c0 + v;
+                if (ci < nact) {
+                    const int64_t i = lo + list[ci];
+                    it.u = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(Ub + i * SL) + q);
+                    const uint32_t *rp = reinterpret_cast<const uint32_t *>(rec + i * CS);
+#pragma unroll
+                    for (int w = 0; w < RW; ++w) it.r[w] = rp[w];
+                } else {
+                    it.u = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int w = 0; w < RW; ++w) it.r[w] = 0u;
+                }
+            };
+            // the first U loads of this slice are issued before the table is (re)staged
+            int c0 = wave * VPW;
+            Item a, b;
+            load_item(c0, a);
+            load_item(c0 + step, b);
+            __syncthreads();                                   // everyone is done with the previous slice table
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(Tsj) + (int64_t)slice * TAB;
+            for (int e = threadIdx.x; e < TAB; e += 1024) tab[e] = src[e];
+            __syncthreads();
+            for (; c0 < nact; c0 += step) {
+                const Item cur = a;
+                a = b;
+                load_item(c0 + 2 * step, b);
+                f32x4 s = cur.u;
+#pragma unroll
+                for (int w = 0; w < CW; ++w) {
+                    const uint32_t hiw = (w + 1 < RW) ? cur.r[w + 1] : 0u;
+                    const uint32_t cw = __builtin_amdgcn_perm(hiw, cur.r[w], sel[w]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int kk = 4 * w + t;
+                        if (kk < M - 1) {
+                            const uint32_t code = (cw >> (8 * t)) & 0xffu;
+                            s = s + tab[(kk * LSQ_H + code) * LPV + q];      // ascending k, plain f32 add
+                        }
+                    }
+                }
+                float lm = fminf(fminf(s.x, s.y), fminf(s.z, s.w));
+                int li = ((s.x == lm) ? 0 : (s.y == lm) ? 1 : (s.z == lm) ? 2 : 3) + 4 * q;
+                if (lm != lm) { lm = __builtin_inff(); li = 1000; }
+                if (slice == 0 && q == 0 && s.x != s.x) { lm = -__builtin_inff(); li = 0; }
+                {
+                    float ov = dpp_self<DPP_XOR1, 0xf>(lm);
+                    int oi = __builtin_amdgcn_update_dpp(li, li, DPP_XOR1, 0xf, 0xf, false);
+                    if (ov < lm || (ov == lm && oi < li)) { lm = ov; li = oi; }
+                    if (LPV == 4) {
+                        ov = dpp_self<DPP_XOR2, 0xf>(lm);
+                        oi = __builtin_amdgcn_update_dpp(li, li, DPP_XOR2, 0xf, 0xf, false);
+                        if (ov < lm || (ov == lm && oi < li)) { lm = ov; li = oi; }
+                    }
+                }
+                if (q == 0 && c0 + v < nact) {
+                    const int ci = c0 + v;
+                    if (slice == 0 || lm < bestv[ci]) {        // strict <: the lowest slice keeps ties
+                        bestv[ci] = lm;
+                        besti[ci] = (unsigned short)(SL * slice + li);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int ci = threadIdx.x; ci < nact; ci += 1024) {
+            const int64_t i = lo + list[ci];
+            const unsigned bi = besti[ci];
+            const uint8_t code = (uint8_t)(bi > 255 ? 0 : bi);
+            const uint8_t old = rec[i * CS + j];
+            rec[i * CS + j] = code;
+            if (valid) valid[i] = (code != old) ? (unsigned short)(1u << j) : (unsigned short)(valid[i] | (1u << j));
+        }
+        __syncthreads();
+    }
+}
+
+// Ts[j][slice][kk][b][SL] <- T[j][k(kk)][b][slice*SL ..]   (one thread per float4)
+template <int SL>
+__global__ __launch_bounds__(256) void tables_to_slices_kernel(const float *__restrict__ T, float *__restrict__ Ts, int m) {
+    constexpr int NS = LSQ_H / SL, LPV = SL / 4;
+    const int64_t total = (int64_t)m * NS * (m - 1) * LSQ_H * LPV;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int qq = (int)(e % LPV);
+    int64_t r = e / LPV;
+    const int b = (int)(r % LSQ_H); r /= LSQ_H;
+    const int kk = (int)(r % (m - 1)); r /= (m - 1);
+    const int slice = (int)(r % NS);
+    const int j = (int)(r / NS);
+    const int k = kk + (kk >= j ? 1 : 0);
+    reinterpret_cast<f32x4 *>(Ts)[e] =
+        *reinterpret_cast<const f32x4 *>(T + (((int64_t)j * m + k) * LSQ_H + b) * LSQ_H + slice * SL + qq * 4);
+}
+
 template <int SL>
 __global__ __launch_bounds__(256) void icm_combine_kernel(const float2 *__restrict__ part, uint8_t *__restrict__ rec, int64_t n, int cs, int j) {
     constexpr int NS = LSQ_H / SL;
@@ -318,7 +503,8 @@ __global__ __launch_bounds__(256) void icm_combine_kernel(const float2 *__restri
 // ---- perturbation (cudautils.cu:27-80 / encode_icm.jl:55-70), one thread per vector ------------
 template <int CS>
 __global__ __launch_bounds__(256) void perturb_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int64_t n,
-                                                      int m, int npert, uint64_t seed, uint32_t it, uint64_t goff) {
+                                                      int m, int npert, uint64_t seed, uint32_t it, uint64_t goff,
+                                                      const unsigned short *__restrict__ vsrc, unsigned short *__restrict__ vdst) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint64_t w[2];
@@ -328,6 +514,7 @@ __global__ __launch_bounds__(256) void perturb_kernel(const uint8_t *__restrict_
     int need = npert < m ? npert : m;
     const uint64_t gi = goff + (uint64_t)i;
     lsq_u32x4 sel = {{0, 0, 0, 0}};
+    bool changed = false;
     for (int pp = 0; pp < m && need > 0; ++pp) {
         if ((pp & 3) == 0) sel = lsq_rng_block(seed, gi, it, LSQ_DOM_PERTURB, (uint32_t)(pp >> 2));
         const uint32_t r = sel.v[pp & 3];
@@ -335,6 +522,7 @@ __global__ __launch_bounds__(256) void perturb_kernel(const uint8_t *__restrict_
             const uint32_t rv = lsq_rng_word(seed, gi, it, LSQ_DOM_PERTURB, (uint32_t)(16 + pp));
             const uint64_t val = lsq_mulhi32(rv, LSQ_H);
             const int sh = 8 * (pp & 7);
+            changed |= (((w[pp >> 3] >> sh) & 0xffull) != val);
             w[pp >> 3] = (w[pp >> 3] & ~(0xffull << sh)) | (val << sh);
             --need;
         }
@@ -342,6 +530,8 @@ __global__ __launch_bounds__(256) void perturb_kernel(const uint8_t *__restrict_
     uint64_t *q = reinterpret_cast<uint64_t *>(dst + i * CS);
     q[0] = w[0];
     if (CS == 16) q[1] = w[1];
+    // a changed code invalidates every node: the others' conditioning changed, and it is itself no argmin
+    if (vdst) vdst[i] = changed ? (unsigned short)0 : vsrc[i];
 }
 
 // ---- cost (+ accept) ----------------------------------------------------------------------------
@@ -350,7 +540,8 @@ __global__ __launch_bounds__(256) void perturb_kernel(const uint8_t *__restrict_
 template <int M>
 __global__ __launch_bounds__(256) void cost_kernel(const float *__restrict__ X, const float *__restrict__ K,
                                                    const uint8_t *rec, uint8_t *cur, float *__restrict__ prev,
-                                                   unsigned long long *__restrict__ counters, int64_t n, int d, int mode) {
+                                                   unsigned long long *__restrict__ counters, int64_t n, int d, int mode,
+                                                   const unsigned short *__restrict__ vnew, unsigned short *__restrict__ vcur) {
     constexpr int CS = (M <= 8) ? 8 : 16;
     constexpr int NV = 2;                     // vectors in flight per wave (memory-level parallelism)
     const int lane = threadIdx.x & 63;
@@ -405,6 +596,7 @@ __global__ __launch_bounds__(256) void cost_kernel(const float *__restrict__ X, 
                         uint64_t *q = reinterpret_cast<uint64_t *>(cur + ii[v] * CS);
                         q[0] = cr[v].lo;
                         if (CS == 16) q[1] = cr[v].hi;
+                        if (vcur) vcur[ii[v]] = vnew[ii[v]];
                     }
                 }
             }
@@ -558,6 +750,85 @@ static int launch_slice_t(hipStream_t s, const float *Usj, const float *Tj, uint
     return LSQ_OK;
 }
 
+template <int M, int SL>
+static int launch_walk_t(hipStream_t s, const float *Usj, const float *Ts, uint8_t *rec, unsigned short *valid, int64_t n, int j,
+                         int use_skip, unsigned long long *active_total) {
+    constexpr int NS = LSQ_H / SL;
+    constexpr int TAB = (M - 1) * LSQ_H * (SL / 4);
+    constexpr int LDS_BYTES = TAB * 16 + 4096 * 4 + 4096 * 2 + 4096 * 2;      // table + best value/index + active list
+    static_assert(LDS_BYTES + 128 <= 160 * 1024, "slice table + running best must fit the 160 KiB LDS");
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    LSQ_HIP(hipGetDevice(&dev));
+    if (dev < 64 && !attr_set[dev]) {
+        LSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&icm_walk_kernel<M, SL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_set[dev] = true;
+    }
+    const int64_t rounds = (n + 256 * 4096 - 1) / (256 * 4096);          // passes per CU
+    int64_t per_pass = (n + 256 * rounds - 1) / (256 * rounds);
+    if (per_pass > 4096) per_pass = 4096;
+    if (per_pass < 1) per_pass = 1;
+    const int64_t npass = (n + per_pass - 1) / per_pass;
+    const unsigned grid = (unsigned)(npass < 256 ? npass : 256);
+    const float *Tsj = Ts + (int64_t)j * NS * TAB * 4;
+    hipLaunchKernelGGL((icm_walk_kernel<M, SL>), dim3(grid), dim3(1024), LDS_BYTES, s, Usj, Tsj, rec, valid, n, j, (int)per_pass,
+                       (use_skip && valid) ? 1 : 0, active_total);
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}
+
+int lsq_walk_slice_width(int m) {
+    static int forced = -1;
+    if (forced < 0) { const char *e = getenv("LSQ_WALK_SL"); forced = (e && atoi(e) == 8) ? 8 : 0; }
+    return (m <= 8 && forced != 8) ? 16 : 8;
+}
+
+int lsq_launch_icm_walk(hipStream_t s, const float *Usj, const float *Ts, uint8_t *rec, unsigned short *valid, int64_t n, int m, int j,
+                        int use_skip, unsigned long long *active_total) {
+    if (n <= 0) return LSQ_OK;
+    if (m <= 8 && lsq_walk_slice_width(m) == 8) {
+        switch (m) {
+            case 1: return launch_walk_t<1, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+            case 2: return launch_walk_t<2, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+            case 3: return launch_walk_t<3, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+            case 4: return launch_walk_t<4, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+            case 5: return launch_walk_t<5, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+            case 6: return launch_walk_t<6, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+            case 7: return launch_walk_t<7, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+            default: return launch_walk_t<8, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+        }
+    }
+    switch (m) {
+        case 1: return launch_walk_t<1, 16>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+        case 2: return launch_walk_t<2, 16>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+        case 3: return launch_walk_t<3, 16>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+        case 4: return launch_walk_t<4, 16>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+        case 5: return launch_walk_t<5, 16>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+        case 6: return launch_walk_t<6, 16>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+        case 7: return launch_walk_t<7, 16>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+        case 8: return launch_walk_t<8, 16>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+        case 9: return launch_walk_t<9, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+        case 10: return launch_walk_t<10, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+        case 11: return launch_walk_t<11, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+        case 12: return launch_walk_t<12, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+        case 13: return launch_walk_t<13, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+        case 14: return launch_walk_t<14, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+        case 15: return launch_walk_t<15, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+        case 16: return launch_walk_t<16, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+        default: lsq_set_error("m = %d out of range 1..16", m); return LSQ_EINVAL;
+    }
+}
+
+int lsq_launch_tables_to_slices(hipStream_t s, const float *T, float *Ts, int m, int sl) {
+    if (m < 2) return LSQ_OK;
+    const int64_t total = (int64_t)m * (LSQ_H / sl) * (m - 1) * LSQ_H * (sl / 4);
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (sl == 16) hipLaunchKernelGGL(tables_to_slices_kernel<16>, dim3(grid), dim3(256), 0, s, T, Ts, m);
+    else hipLaunchKernelGGL(tables_to_slices_kernel<8>, dim3(grid), dim3(256), 0, s, T, Ts, m);
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}
+
 int lsq_launch_icm_slice(hipStream_t s, const float *Usj, const float *T, uint8_t *rec, float2 *part, int64_t n, int m, int j) {
     if (n <= 0) return LSQ_OK;
     const float *Tj = T + (int64_t)j * m * LSQ_H * LSQ_H;
@@ -590,16 +861,16 @@ int lsq_launch_icm_slice(hipStream_t s, const float *Usj, const float *T, uint8_
     } while (0)
 
 int lsq_launch_perturb(hipStream_t s, const uint8_t *src, uint8_t *dst, int64_t n, int m, int npert, uint64_t seed,
-                       uint32_t it, uint64_t global_offset) {
+                       uint32_t it, uint64_t global_offset, const unsigned short *vsrc, unsigned short *vdst) {
     if (n <= 0) return LSQ_OK;
-    LSQ_CS_LAUNCH(m, perturb_kernel, thread_grid(n), src, dst, n, m, npert, seed, it, global_offset);
+    LSQ_CS_LAUNCH(m, perturb_kernel, thread_grid(n), src, dst, n, m, npert, seed, it, global_offset, vsrc, vdst);
     return LSQ_OK;
 }
 
 int lsq_launch_cost(hipStream_t s, const float *X, const float *K, const uint8_t *rec, uint8_t *cur, float *prev,
-                    unsigned long long *counters, int64_t n, int d, int m, int mode) {
+                    unsigned long long *counters, int64_t n, int d, int m, int mode, const unsigned short *vnew, unsigned short *vcur) {
     if (n <= 0) return LSQ_OK;
-    LSQ_DISPATCH_M(m, hipLaunchKernelGGL(cost_kernel<M_>, dim3(wave_grid((n + 1) / 2)), dim3(256), 0, s, X, K, rec, cur, prev, counters, n, d, mode));
+    LSQ_DISPATCH_M(m, hipLaunchKernelGGL(cost_kernel<M_>, dim3(wave_grid((n + 1) / 2)), dim3(256), 0, s, X, K, rec, cur, prev, counters, n, d, mode, vnew, vcur));
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }

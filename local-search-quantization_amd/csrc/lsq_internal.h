@@ -85,8 +85,10 @@ int lsq_launch_codes_compact(hipStream_t s, const uint8_t *rec, int64_t n, int m
 int lsq_launch_codes_from_i16(hipStream_t s, const int16_t *B, int64_t n, int m, int h, uint8_t *rec, int *bad_flag);
 int lsq_launch_codes_to_i16(hipStream_t s, const uint8_t *rec, int64_t n, int m, int16_t *B);
 
+// vsrc/vdst (optional): per-vector node-validity masks (bit j = code j is the argmin for the current other
+// codes); a perturbation that changes a code clears the whole mask.
 int lsq_launch_perturb(hipStream_t s, const uint8_t *src, uint8_t *dst, int64_t n, int m, int npert,
-                       uint64_t seed, uint32_t it, uint64_t global_offset);
+                       uint64_t seed, uint32_t it, uint64_t global_offset, const unsigned short *vsrc, unsigned short *vdst);
 // one ICM node update of node j for all n vectors: Uj = U + j*n*256, T = full table [m][m][256][256]
 int lsq_launch_icm_node(hipStream_t s, const float *Uj, const float *T, uint8_t *rec, int64_t n, int m, int j);
 // fused: for every vector, all `nsweeps` sweeps in `order` with register-resident unaries
@@ -95,10 +97,18 @@ int lsq_launch_icm_fused(hipStream_t s, const float *U, const float *T, uint8_t 
 // LDS-slice schedule: U plane j is slice-major [256/SL][n][SL]; part = [256/SL][n] (min, local idx) scratch
 static inline int lsq_slice_width(int m) { return m <= 10 ? 16 : 8; }
 int lsq_launch_icm_slice(hipStream_t s, const float *Usj, const float *T, uint8_t *rec, float2 *part, int64_t n, int m, int j);
+// LDS-walk schedule: one block walks all slices of its vector range; Ts = slice-major pair tables
+int lsq_walk_slice_width(int m);      // 16 for m <= 8 (8 if LSQ_WALK_SL=8 is set: tuning knob), 8 above
+int lsq_launch_tables_to_slices(hipStream_t s, const float *T, float *Ts, int m, int sl);
+// valid (optional): validity masks, maintained by the kernel; use_skip: skip vectors whose bit j is set (exact);
+// active_total (optional): += number of vectors actually recomputed
+int lsq_launch_icm_walk(hipStream_t s, const float *Usj, const float *Ts, uint8_t *rec, unsigned short *valid, int64_t n, int m, int j,
+                        int use_skip, unsigned long long *active_total);
 // cost of `rec`; mode 0: prev[i] = cost.  mode 1 (accept): if cost < prev[i] { cur[i] = rec[i]; prev[i] = cost }
 // and counters[0] += (#cost == prev), counters[1] += (#cost < prev)   (counters: 2 x uint64 on device)
 int lsq_launch_cost(hipStream_t s, const float *X, const float *K, const uint8_t *rec, uint8_t *cur, float *prev,
-                    unsigned long long *counters, int64_t n, int d, int m, int mode);
+                    unsigned long long *counters, int64_t n, int d, int m, int mode,
+                    const unsigned short *vnew, unsigned short *vcur);      // accept also copies the validity mask
 // *sum += SUM_i v[i]  (f64)
 int lsq_launch_sum_f64(hipStream_t s, const float *v, int64_t n, double *sum);
 

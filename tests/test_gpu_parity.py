@@ -72,7 +72,7 @@ CONFIGS = [
 ]
 
 
-@pytest.mark.parametrize("schedule", [2, 0, 1])
+@pytest.mark.parametrize("schedule", [3, 2, 0, 1])
 @pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: "d%d_n%d_m%d" % (c[0], c[1], c[2]))
 def test_encode_icm_matches_oracle(lsq, oracle, cfg, schedule):
     d, n, m, ils, J, npert, randord, seed, kind = cfg
