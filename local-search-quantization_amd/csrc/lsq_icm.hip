@@ -387,35 +387,57 @@ __global__ __launch_bounds__(1024) void icm_walk_kernel(const float *__restrict_
         if (nact == 0) continue;                               // block-uniform
         if (threadIdx.x == 0 && active_total) atomicAdd(active_total, (unsigned long long)nact);
 
+        constexpr int NST = (TAB + 1023) / 1024;               // float4 table entries staged per thread
+        f32x4 nxt[NST > 0 ? NST : 1];
+        auto prefetch_tab = [&](int sl) {
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(Tsj) + (int64_t)sl * TAB;
+#pragma unroll
+            for (int r = 0; r < NST; ++r) {
+                const int e = (int)threadIdx.x + r * 1024;
+                nxt[r] = (e < TAB) ? src[e] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        prefetch_tab(0);
+
+        // The U stream is ONE flat software pipeline over (slice, iteration): the loads of the first
+        // iterations of slice s+1 are already in flight while slice s finishes, so the HBM latency is
+        // not re-exposed at each of the NS slice boundaries (it was ~45 us of fixed cost per launch).
+        constexpr int DEPTH = 2;                               // items in flight per wave (4 measured slower)
+        const int ipw = (wave * VPW < nact) ? (nact - wave * VPW + step - 1) / step : 0;   // iterations per slice, this wave
+        int ls = 0, lit = 0;                                   // (slice, iteration) of the next load to issue
+        auto load_next = [&](Item &it) {
+            const int ci = wave * VPW + lit * step + v;
+            if (ls < NS && lit < ipw && ci < nact) {
+                const int64_t i = lo + list[ci];
+                it.u = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(Usj + ((int64_t)ls * n + i) * SL) + q);
+                const uint32_t *rp = reinterpret_cast<const uint32_t *>(rec + i * CS);
+#pragma unroll
+                for (int w = 0; w < RW; ++w) it.r[w] = rp[w];
+            } else {
+                it.u = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int w = 0; w < RW; ++w) it.r[w] = 0u;
+            }
+            if (++lit >= ipw) { lit = 0; ++ls; }
+        };
+        Item pipe[DEPTH];
+#pragma unroll
+        for (int p = 0; p < DEPTH; ++p) load_next(pipe[p]);
+
         for (int slice = 0; slice < NS; ++slice) {
-            const float *Ub = Usj + (int64_t)slice * n * SL;
-            auto load_item = [&](int c0, Item &it) {
-                const int ci = c0 + v;
-                if (ci < nact) {
-                    const int64_t i = lo + list[ci];
-                    it.u = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(Ub + i * SL) + q);
-                    const uint32_t *rp = reinterpret_cast<const uint32_t *>(rec + i * CS);
-#pragma unroll
-                    for (int w = 0; w < RW; ++w) it.r[w] = rp[w];
-                } else {
-                    it.u = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int w = 0; w < RW; ++w) it.r[w] = 0u;
-                }
-            };
-            // the first U loads of this slice are issued before the table is (re)staged
-            int c0 = wave * VPW;
-            Item a, b;
-            load_item(c0, a);
-            load_item(c0 + step, b);
             __syncthreads();                                   // everyone is done with the previous slice table
-            const f32x4 *src = reinterpret_cast<const f32x4 *>(Tsj) + (int64_t)slice * TAB;
-            for (int e = threadIdx.x; e < TAB; e += 1024) tab[e] = src[e];
+#pragma unroll
+            for (int r = 0; r < NST; ++r) {                    // commit the table prefetched one slice ago
+                const int e = (int)threadIdx.x + r * 1024;
+                if (e < TAB) tab[e] = nxt[r];
+            }
             __syncthreads();
-            for (; c0 < nact; c0 += step) {
-                const Item cur = a;
-                a = b;
-                load_item(c0 + 2 * step, b);
+            if (slice + 1 < NS) prefetch_tab(slice + 1);       // next slice's table travels L2 -> VGPRs under this slice's work
+            for (int c0 = wave * VPW; c0 < nact; c0 += step) {
+                const Item cur = pipe[0];
+#pragma unroll
+                for (int p = 0; p + 1 < DEPTH; ++p) pipe[p] = pipe[p + 1];
+                load_next(pipe[DEPTH - 1]);
                 f32x4 s = cur.u;
 #pragma unroll
                 for (int w = 0; w < CW; ++w) {

@@ -20,7 +20,7 @@ def _np(a, dtype):
 
 
 class Engine:
-    def __init__(self, device=0, chunk=None, profile=False, schedule=None):
+    def __init__(self, device=0, chunk=None, profile=False, schedule=None, skip=None):
         self._L = _lib.load()
         h = C.c_void_p()
         _lib.check(self._L.lsq_create(C.byref(h), int(device)))
@@ -30,6 +30,8 @@ class Engine:
             self.set_option("chunk", int(chunk))
         if schedule is not None:
             self.set_option("schedule", int(schedule))
+        if skip is not None:
+            self.set_option("skip", int(bool(skip)))
         if profile:
             self.set_option("profile", 1)
 

@@ -84,6 +84,24 @@ def test_encode_icm_matches_oracle(lsq, oracle, cfg, schedule):
     assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0)
 
 
+def test_skip_unchanged_is_exact(lsq, oracle):
+    """Schedule 3 memoises node updates whose conditioning codes did not change.  It must be a pure
+    optimisation: identical codes/objective with skip on and off (and equal to the oracle), while
+    strictly fewer node updates are recomputed.  n spans several passes per block and ragged tails."""
+    d, n, m, ils, J, npert, seed = 64, 9001, 8, [1, 3], 4, 4, 77
+    X, K, B0 = make_problem(d, n, m, seed=seed)
+    Bs_ref, objs_ref, st_ref = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, True, seed, want_stats=True)
+    counts = {}
+    for skip in (1, 0):
+        with lsq.Engine(0, schedule=3, skip=skip, profile=True) as eng:
+            Bs, objs = eng.encode_icm(X, B0, K, m, ils, J, npert, True, seed=seed)
+            counts[skip] = eng.timings()["icm_node_updates"]
+        assert np.array_equal(Bs, Bs_ref), "skip=%d: %d codes differ" % (skip, (Bs != Bs_ref).sum())
+        assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0)
+    assert counts[0] == n * 3 * J * m
+    assert 0 < counts[1] < counts[0]
+
+
 def test_device_api_chunking_and_offsets(lsq, oracle):
     """Results must not depend on the resident chunk size nor on how the caller shards (P8):
     encode [0,n) in one call == two calls on halves with global_offset."""
