@@ -308,7 +308,7 @@ __global__ __launch_bounds__(1024) void icm_slice_kernel(const float *__restrict
 // launch; the price is re-staging the (m-1) x 256 x SL x 4 B slice table from L2 once per slice.
 // Ts is the slice-major copy of the pair tables, Ts[j][slice][kk][b][SL] (kk = rank of k among k != j),
 // so that staging is one contiguous, fully coalesced copy.
-template <int M, int SL>
+template <int M, int SL, int DEPTH = 2, int ABL = 0>      // ABL: timing-only ablations (1: no U stream, 2: no table adds)
 __global__ __launch_bounds__(1024) void icm_walk_kernel(const float *__restrict__ Usj, const float *__restrict__ Tsj,
                                                         uint8_t *__restrict__ rec, unsigned short *__restrict__ valid,
                                                         int64_t n, int j, int per_pass, int use_skip,
@@ -399,30 +399,77 @@ __global__ __launch_bounds__(1024) void icm_walk_kernel(const float *__restrict_
         };
         prefetch_tab(0);
 
-        // The U stream is ONE flat software pipeline over (slice, iteration): the loads of the first
-        // iterations of slice s+1 are already in flight while slice s finishes, so the HBM latency is
-        // not re-exposed at each of the NS slice boundaries (it was ~45 us of fixed cost per launch).
-        constexpr int DEPTH = 2;                               // items in flight per wave (4 measured slower)
+        // The U stream is ONE flat software pipeline over (slice, iteration), two items in flight per
+        // wave (deeper measured slower): the loads of the first iterations of slice s+1 are in flight
+        // while slice s finishes.  The two item buffers have STATIC roles (loop unrolled by two, the
+        // roles swap when a slice has an odd iteration count) so no register copies are issued: the
+        // kernel is instruction-issue bound (ablations in DESIGN.md), every slot counts.
         const int ipw = (wave * VPW < nact) ? (nact - wave * VPW + step - 1) / step : 0;   // iterations per slice, this wave
         int ls = 0, lit = 0;                                   // (slice, iteration) of the next load to issue
         auto load_next = [&](Item &it) {
-            const int ci = wave * VPW + lit * step + v;
-            if (ls < NS && lit < ipw && ci < nact) {
-                const int64_t i = lo + list[ci];
-                it.u = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(Usj + ((int64_t)ls * n + i) * SL) + q);
-                const uint32_t *rp = reinterpret_cast<const uint32_t *>(rec + i * CS);
+            // always in bounds (indices clamped): no exec-mask juggling; results of clamped lanes are discarded
+            int ci = wave * VPW + lit * step + v;
+            ci = ci < nact ? ci : nact - 1;
+            const int lsc = ls < NS ? ls : NS - 1;
+            const int64_t i = lo + list[ci];
+            if (ABL == 1) it.u = (f32x4){(float)i, 1.f, 2.f, 3.f};
+            else it.u = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(Usj + ((int64_t)lsc * n + i) * SL) + q);
+            const uint32_t *rp = reinterpret_cast<const uint32_t *>(rec + i * CS);
 #pragma unroll
-                for (int w = 0; w < RW; ++w) it.r[w] = rp[w];
-            } else {
-                it.u = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int w = 0; w < RW; ++w) it.r[w] = 0u;
-            }
+            for (int w = 0; w < RW; ++w) it.r[w] = rp[w];
             if (++lit >= ipw) { lit = 0; ++ls; }
         };
-        Item pipe[DEPTH];
+        auto compute = [&](const Item &cur, int slice, int c0) {
+            f32x4 s = cur.u;
 #pragma unroll
-        for (int p = 0; p < DEPTH; ++p) load_next(pipe[p]);
+            for (int w = 0; w < CW; ++w) {
+                const uint32_t hiw = (w + 1 < RW) ? cur.r[w + 1] : 0u;
+                const uint32_t cw = __builtin_amdgcn_perm(hiw, cur.r[w], sel[w]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int kk = 4 * w + t;
+                    if (kk < M - 1) {
+                        const uint32_t code = (cw >> (8 * t)) & 0xffu;
+                        if (ABL != 2) s = s + tab[(kk * LSQ_H + code) * LPV + q];      // ascending k, plain f32 add
+                        else s.x += (float)code;
+                    }
+                }
+            }
+            // first-argmin over this vector's SL candidates: in-lane 4, then the LPV lanes (branch-free)
+            float lm = fminf(fminf(s.x, s.y), fminf(s.z, s.w));
+            int li = ((s.x == lm) ? 0 : (s.y == lm) ? 1 : (s.z == lm) ? 2 : 3) + 4 * q;
+            if (__builtin_expect(__ballot((lm != lm) | (s.x != s.x)) != 0ull, 0)) {       // wave-uniform, rare: a NaN is present
+                const bool lane_nan = lm != lm;                              // all four NaN: never wins
+                lm = lane_nan ? __builtin_inff() : lm;
+                li = lane_nan ? 1000 : li;
+                const bool s0_nan = (slice == 0) & (q == 0) & (s.x != s.x);  // s[0] NaN: the strict-< scan keeps index 0
+                lm = s0_nan ? -__builtin_inff() : lm;
+                li = s0_nan ? 0 : li;
+            }
+            float qm = fminf(lm, dpp_self<DPP_XOR1, 0xf>(lm));               // minimum value over the vector's lanes
+            if (LPV == 4) qm = fminf(qm, dpp_self<DPP_XOR2, 0xf>(qm));
+            int qi = (lm == qm) ? li : 0x7fff;                               // lowest index among the lanes that hold it
+            {
+                const int o1 = __builtin_amdgcn_update_dpp(qi, qi, DPP_XOR1, 0xf, 0xf, false);
+                qi = o1 < qi ? o1 : qi;
+                if (LPV == 4) {
+                    const int o2 = __builtin_amdgcn_update_dpp(qi, qi, DPP_XOR2, 0xf, 0xf, false);
+                    qi = o2 < qi ? o2 : qi;
+                }
+            }
+            if (q == 0 && c0 + v < nact) {
+                const int ci = c0 + v;
+                const bool take = (slice == 0) | (qm < bestv[ci]);           // strict <: the lowest slice keeps ties
+                if (take) {
+                    bestv[ci] = qm;
+                    besti[ci] = (unsigned short)(SL * slice + qi);
+                }
+            }
+        };
+        Item bufA, bufB;
+        load_next(bufA);
+        load_next(bufB);
+        int phase = 0;                                         // 0: bufA holds the next item to consume
 
         for (int slice = 0; slice < NS; ++slice) {
             __syncthreads();                                   // everyone is done with the previous slice table
@@ -433,46 +480,19 @@ __global__ __launch_bounds__(1024) void icm_walk_kernel(const float *__restrict_
             }
             __syncthreads();
             if (slice + 1 < NS) prefetch_tab(slice + 1);       // next slice's table travels L2 -> VGPRs under this slice's work
-            for (int c0 = wave * VPW; c0 < nact; c0 += step) {
-                const Item cur = pipe[0];
-#pragma unroll
-                for (int p = 0; p + 1 < DEPTH; ++p) pipe[p] = pipe[p + 1];
-                load_next(pipe[DEPTH - 1]);
-                f32x4 s = cur.u;
-#pragma unroll
-                for (int w = 0; w < CW; ++w) {
-                    const uint32_t hiw = (w + 1 < RW) ? cur.r[w + 1] : 0u;
-                    const uint32_t cw = __builtin_amdgcn_perm(hiw, cur.r[w], sel[w]);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int kk = 4 * w + t;
-                        if (kk < M - 1) {
-                            const uint32_t code = (cw >> (8 * t)) & 0xffu;
-                            s = s + tab[(kk * LSQ_H + code) * LPV + q];      // ascending k, plain f32 add
-                        }
-                    }
+            int c0 = wave * VPW, t = 0;
+            if (phase == 0) {
+                for (; t + 1 < ipw; t += 2) {
+                    compute(bufA, slice, c0); load_next(bufA); c0 += step;
+                    compute(bufB, slice, c0); load_next(bufB); c0 += step;
                 }
-                float lm = fminf(fminf(s.x, s.y), fminf(s.z, s.w));
-                int li = ((s.x == lm) ? 0 : (s.y == lm) ? 1 : (s.z == lm) ? 2 : 3) + 4 * q;
-                if (lm != lm) { lm = __builtin_inff(); li = 1000; }
-                if (slice == 0 && q == 0 && s.x != s.x) { lm = -__builtin_inff(); li = 0; }
-                {
-                    float ov = dpp_self<DPP_XOR1, 0xf>(lm);
-                    int oi = __builtin_amdgcn_update_dpp(li, li, DPP_XOR1, 0xf, 0xf, false);
-                    if (ov < lm || (ov == lm && oi < li)) { lm = ov; li = oi; }
-                    if (LPV == 4) {
-                        ov = dpp_self<DPP_XOR2, 0xf>(lm);
-                        oi = __builtin_amdgcn_update_dpp(li, li, DPP_XOR2, 0xf, 0xf, false);
-                        if (ov < lm || (ov == lm && oi < li)) { lm = ov; li = oi; }
-                    }
+                if (t < ipw) { compute(bufA, slice, c0); load_next(bufA); phase = 1; }
+            } else {
+                for (; t + 1 < ipw; t += 2) {
+                    compute(bufB, slice, c0); load_next(bufB); c0 += step;
+                    compute(bufA, slice, c0); load_next(bufA); c0 += step;
                 }
-                if (q == 0 && c0 + v < nact) {
-                    const int ci = c0 + v;
-                    if (slice == 0 || lm < bestv[ci]) {        // strict <: the lowest slice keeps ties
-                        bestv[ci] = lm;
-                        besti[ci] = (unsigned short)(SL * slice + li);
-                    }
-                }
+                if (t < ipw) { compute(bufB, slice, c0); load_next(bufB); phase = 0; }
             }
         }
         __syncthreads();
@@ -772,7 +792,7 @@ static int launch_slice_t(hipStream_t s, const float *Usj, const float *Tj, uint
     return LSQ_OK;
 }
 
-template <int M, int SL>
+template <int M, int SL, int DEPTH = 2, int ABL = 0>
 static int launch_walk_t(hipStream_t s, const float *Usj, const float *Ts, uint8_t *rec, unsigned short *valid, int64_t n, int j,
                          int use_skip, unsigned long long *active_total) {
     constexpr int NS = LSQ_H / SL;
@@ -783,7 +803,7 @@ static int launch_walk_t(hipStream_t s, const float *Usj, const float *Ts, uint8
     int dev = 0;
     LSQ_HIP(hipGetDevice(&dev));
     if (dev < 64 && !attr_set[dev]) {
-        LSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&icm_walk_kernel<M, SL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        LSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&icm_walk_kernel<M, SL, DEPTH, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set[dev] = true;
     }
     const int64_t rounds = (n + 256 * 4096 - 1) / (256 * 4096);          // passes per CU
@@ -793,7 +813,7 @@ static int launch_walk_t(hipStream_t s, const float *Usj, const float *Ts, uint8
     const int64_t npass = (n + per_pass - 1) / per_pass;
     const unsigned grid = (unsigned)(npass < 256 ? npass : 256);
     const float *Tsj = Ts + (int64_t)j * NS * TAB * 4;
-    hipLaunchKernelGGL((icm_walk_kernel<M, SL>), dim3(grid), dim3(1024), LDS_BYTES, s, Usj, Tsj, rec, valid, n, j, (int)per_pass,
+    hipLaunchKernelGGL((icm_walk_kernel<M, SL, DEPTH, ABL>), dim3(grid), dim3(1024), LDS_BYTES, s, Usj, Tsj, rec, valid, n, j, (int)per_pass,
                        (use_skip && valid) ? 1 : 0, active_total);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
@@ -828,7 +848,16 @@ int lsq_launch_icm_walk(hipStream_t s, const float *Usj, const float *Ts, uint8_
         case 5: return launch_walk_t<5, 16>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
         case 6: return launch_walk_t<6, 16>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
         case 7: return launch_walk_t<7, 16>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
-        case 8: return launch_walk_t<8, 16>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+        case 8: {
+            static int depth = -1;
+            if (depth < 0) { const char *e = getenv("LSQ_WALK_DEPTH"); depth = e ? atoi(e) : 2; }
+            if (depth == 3) return launch_walk_t<8, 16, 3>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+            if (depth == 4) return launch_walk_t<8, 16, 4>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+            if (depth == 1) return launch_walk_t<8, 16, 1>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+            if (depth == 11) return launch_walk_t<8, 16, 2, 1>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+            if (depth == 12) return launch_walk_t<8, 16, 2, 2>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+            return launch_walk_t<8, 16>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+        }
         case 9: return launch_walk_t<9, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
         case 10: return launch_walk_t<10, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
         case 11: return launch_walk_t<11, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
