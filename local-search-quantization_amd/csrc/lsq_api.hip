@@ -58,6 +58,8 @@ struct lsq_ctx {
     int64_t chunk = 1 << 20;
     int profile = 0;
     int schedule = 3;        // 0: per-node L2-gather kernel, 1: fused sweeps, 2: LDS-slice + combine, 3: LDS-walk (default)
+    int lane = 0;            // schedule 3, m <= 8: experimental one-lane-per-vector kernel (measured 2.5x slower: VGPR spills)
+    int ablation = 0;        // timing-only kernel ablations (results are garbage when != 0)
     int skip = 1;            // schedule 3: skip node updates whose inputs did not change (exact memoisation)
     // workspace
     DevBuf sci, T, Ts, U, part, vCur, vNew, active, recCur, recNew, prev, counters, obj, bad;
@@ -161,6 +163,8 @@ extern "C" int lsq_set_option(lsq_ctx *c, const char *key, int64_t value) {
     } else if (!strcmp(key, "profile")) c->profile = value != 0;
     else if (!strcmp(key, "own_stream")) c->stream = c->own_stream;
     else if (!strcmp(key, "skip")) c->skip = value != 0;
+    else if (!strcmp(key, "lane")) c->lane = value != 0;
+    else if (!strcmp(key, "ablation")) c->ablation = (int)value;
     else if (!strcmp(key, "schedule")) {
         if (value < 0 || value > 3) { lsq_set_error("schedule must be 0..3"); return LSQ_EINVAL; }
         c->schedule = (int)value;
@@ -269,8 +273,12 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t c
         for (int sw = 0; sw < nsweeps; ++sw)
             for (int q = 0; q < m; ++q) {
                 const int j = order[q];
-                LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>() + (int64_t)j * cn * LSQ_H, c->Ts.as<float>(), rec, valid, cn, m, j, c->skip,
-                                            c->active.as<unsigned long long>()));
+                if (c->lane && m <= 8 && lsq_walk_slice_width(m) == 16)
+                    LSQ_TRY(lsq_launch_icm_lane(c->stream, c->U.as<float>() + (int64_t)j * cn * LSQ_H, c->Ts.as<float>(), rec, valid, cn, m, j, c->skip,
+                                                c->active.as<unsigned long long>(), c->ablation));
+                else
+                    LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>() + (int64_t)j * cn * LSQ_H, c->Ts.as<float>(), rec, valid, cn, m, j, c->skip,
+                                                c->active.as<unsigned long long>()));
             }
         c->icm_launches += (int64_t)nsweeps * m;
     } else if (c->schedule == 2) {

@@ -301,6 +301,13 @@ __global__ __launch_bounds__(1024) void icm_slice_kernel(const float *__restrict
     }
 }
 
+// vectors per block pass of the LDS-walk kernel: table + 10 B per vector must fit the 160 KiB LDS
+constexpr int lsq_walk_pp(int M, int SL) {
+    return ((M - 1) * LSQ_H * (SL / 4) * 16 + 4096 * 10 + 256 <= 160 * 1024) ? 4096
+         : ((M - 1) * LSQ_H * (SL / 4) * 16 + 3072 * 10 + 256 <= 160 * 1024) ? 3072 : 2048;
+}
+#define LSQ_WALK_PP(M, SL) lsq_walk_pp(M, SL)
+
 // ---- LDS-walk schedule (schedule 3) ----------------------------------------------------------------
 // Same arithmetic as icm_slice_kernel, but ONE block walks all 256/SL slices for its own range of
 // <= 4096 vectors, keeping the running (min value, index) of every vector in LDS.  This removes the
@@ -320,11 +327,14 @@ __global__ __launch_bounds__(1024) void icm_walk_kernel(const float *__restrict_
     constexpr int CW = (M - 1 + 3) / 4;
     constexpr int RW = CS / 4;
     constexpr int TAB = (M - 1) * LSQ_H * LPV;          // f32x4 entries of one slice table
+    constexpr int PP = LSQ_WALK_PP(M, SL);               // vectors per pass (LDS budget)
     extern __shared__ f32x4 lds_walk[];
     f32x4 *tab = lds_walk;
-    float *bestv = reinterpret_cast<float *>(lds_walk + TAB);                      // [4096] by compact index
-    unsigned short *besti = reinterpret_cast<unsigned short *>(bestv + 4096);      // [4096]
-    unsigned short *list = besti + 4096;                                           // [4096] active local indices
+    // running first-argmin per (compact) vector: one packed 64-bit key = orderable(value) << 32 | candidate index,
+    // minimised with ONE LDS atomic per lane -- the atomic does the cross-lane and the cross-slice reduction,
+    // and the packed compare returns the LOWEST index among equal values (encode_icm.jl:105-119).
+    unsigned long long *best64 = reinterpret_cast<unsigned long long *>(lds_walk + TAB);      // [PP]
+    unsigned short *list = reinterpret_cast<unsigned short *>(best64 + PP);                    // [PP] active local indices
     __shared__ int wave_tot[16];
     __shared__ int nact_s;
 
@@ -386,6 +396,7 @@ __global__ __launch_bounds__(1024) void icm_walk_kernel(const float *__restrict_
         const int nact = nact_s;
         if (nact == 0) continue;                               // block-uniform
         if (threadIdx.x == 0 && active_total) atomicAdd(active_total, (unsigned long long)nact);
+        for (int ci = threadIdx.x; ci < nact; ci += 1024) best64[ci] = ~0ull;      // ordered before the first atomics by the slice-0 barriers
 
         constexpr int NST = (TAB + 1023) / 1024;               // float4 table entries staged per thread
         f32x4 nxt[NST > 0 ? NST : 1];
@@ -419,7 +430,7 @@ __global__ __launch_bounds__(1024) void icm_walk_kernel(const float *__restrict_
             for (int w = 0; w < RW; ++w) it.r[w] = rp[w];
             if (++lit >= ipw) { lit = 0; ++ls; }
         };
-        auto compute = [&](const Item &cur, int slice, int c0) {
+        auto gather = [&](const Item &cur) -> f32x4 {
             f32x4 s = cur.u;
 #pragma unroll
             for (int w = 0; w < CW; ++w) {
@@ -435,37 +446,21 @@ __global__ __launch_bounds__(1024) void icm_walk_kernel(const float *__restrict_
                     }
                 }
             }
-            // first-argmin over this vector's SL candidates: in-lane 4, then the LPV lanes (branch-free)
-            float lm = fminf(fminf(s.x, s.y), fminf(s.z, s.w));
-            int li = ((s.x == lm) ? 0 : (s.y == lm) ? 1 : (s.z == lm) ? 2 : 3) + 4 * q;
-            if (__builtin_expect(__ballot((lm != lm) | (s.x != s.x)) != 0ull, 0)) {       // wave-uniform, rare: a NaN is present
-                const bool lane_nan = lm != lm;                              // all four NaN: never wins
-                lm = lane_nan ? __builtin_inff() : lm;
-                li = lane_nan ? 1000 : li;
-                const bool s0_nan = (slice == 0) & (q == 0) & (s.x != s.x);  // s[0] NaN: the strict-< scan keeps index 0
-                lm = s0_nan ? -__builtin_inff() : lm;
-                li = s0_nan ? 0 : li;
-            }
-            float qm = fminf(lm, dpp_self<DPP_XOR1, 0xf>(lm));               // minimum value over the vector's lanes
-            if (LPV == 4) qm = fminf(qm, dpp_self<DPP_XOR2, 0xf>(qm));
-            int qi = (lm == qm) ? li : 0x7fff;                               // lowest index among the lanes that hold it
-            {
-                const int o1 = __builtin_amdgcn_update_dpp(qi, qi, DPP_XOR1, 0xf, 0xf, false);
-                qi = o1 < qi ? o1 : qi;
-                if (LPV == 4) {
-                    const int o2 = __builtin_amdgcn_update_dpp(qi, qi, DPP_XOR2, 0xf, 0xf, false);
-                    qi = o2 < qi ? o2 : qi;
-                }
-            }
-            if (q == 0 && c0 + v < nact) {
-                const int ci = c0 + v;
-                const bool take = (slice == 0) | (qm < bestv[ci]);           // strict <: the lowest slice keeps ties
-                if (take) {
-                    bestv[ci] = qm;
-                    besti[ci] = (unsigned short)(SL * slice + qi);
-                }
-            }
+            return s;
         };
+        auto finish = [&](f32x4 s, int slice, int c0) {
+            // first-argmin: in-lane over 4 candidates, then one packed LDS atomic min per lane
+            float lm = fminf(fminf(s.x, s.y), fminf(s.z, s.w));
+            uint32_t li = ((s.x == lm) ? 0u : (s.y == lm) ? 1u : (s.z == lm) ? 2u : 3u) + 4u * q + (uint32_t)(SL * slice);
+            const uint32_t bits = __float_as_uint(lm + 0.0f);                  // -0 -> +0: they compare equal in the reference
+            uint32_t ord = bits ^ ((uint32_t)((int32_t)bits >> 31) | 0x80000000u);   // monotone float -> uint
+            if (__builtin_expect(__ballot((lm != lm) | (s.x != s.x)) != 0ull, 0)) {       // wave-uniform, rare: a NaN is present
+                if (lm != lm) ord = 0xffffffffu;                               // all four NaN: never wins
+                if ((slice == 0) & (q == 0) & (s.x != s.x)) { ord = 0u; li = 0u; }   // s[0] NaN: the strict-< scan keeps index 0
+            }
+            if (c0 + v < nact) atomicMin(&best64[c0 + v], ((unsigned long long)ord << 32) | li);
+        };
+        auto compute = [&](const Item &cur, int slice, int c0) { finish(gather(cur), slice, c0); };
         Item bufA, bufB;
         load_next(bufA);
         load_next(bufB);
@@ -498,7 +493,7 @@ __global__ __launch_bounds__(1024) void icm_walk_kernel(const float *__restrict_
         __syncthreads();
         for (int ci = threadIdx.x; ci < nact; ci += 1024) {
             const int64_t i = lo + list[ci];
-            const unsigned bi = besti[ci];
+            const unsigned bi = (unsigned)(best64[ci] & 0xffffffffull);
             const uint8_t code = (uint8_t)(bi > 255 ? 0 : bi);
             const uint8_t old = rec[i * CS + j];
             rec[i * CS + j] = code;
@@ -797,8 +792,9 @@ static int launch_walk_t(hipStream_t s, const float *Usj, const float *Ts, uint8
                          int use_skip, unsigned long long *active_total) {
     constexpr int NS = LSQ_H / SL;
     constexpr int TAB = (M - 1) * LSQ_H * (SL / 4);
-    constexpr int LDS_BYTES = TAB * 16 + 4096 * 4 + 4096 * 2 + 4096 * 2;      // table + best value/index + active list
-    static_assert(LDS_BYTES + 128 <= 160 * 1024, "slice table + running best must fit the 160 KiB LDS");
+    constexpr int PP = LSQ_WALK_PP(M, SL);
+    constexpr int LDS_BYTES = TAB * 16 + PP * 8 + PP * 2;                // slice table + packed running best + active list
+    static_assert(LDS_BYTES + 256 <= 160 * 1024, "slice table + running best must fit the 160 KiB LDS");
     static bool attr_set[64] = {false};
     int dev = 0;
     LSQ_HIP(hipGetDevice(&dev));
@@ -806,9 +802,9 @@ static int launch_walk_t(hipStream_t s, const float *Usj, const float *Ts, uint8
         LSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&icm_walk_kernel<M, SL, DEPTH, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set[dev] = true;
     }
-    const int64_t rounds = (n + 256 * 4096 - 1) / (256 * 4096);          // passes per CU
+    const int64_t rounds = (n + 256 * (int64_t)PP - 1) / (256 * (int64_t)PP);          // passes per CU
     int64_t per_pass = (n + 256 * rounds - 1) / (256 * rounds);
-    if (per_pass > 4096) per_pass = 4096;
+    if (per_pass > PP) per_pass = PP;
     if (per_pass < 1) per_pass = 1;
     const int64_t npass = (n + per_pass - 1) / per_pass;
     const unsigned grid = (unsigned)(npass < 256 ? npass : 256);
