@@ -163,6 +163,17 @@ LSQ_API int lsq_node_order(uint64_t seed, uint32_t it, int m, int randord, int32
 /* splitarray(1:n, nparts)  src/utils.jl:152-177 -> part's [start, start+len) , 0-based */
 LSQ_API int lsq_splitarray(int64_t n, int nparts, int part, int64_t *start, int64_t *len);
 
+/* ---- (3b) search side of the path (host code) --------------------------------
+ * linscan_aqd_query_extra_byte(dists, idx, codes, queries, codebooks, dbnorms, nqueries, ncodes, m, h, d, nn)
+ *   src/linscan/cpp/linscan_aqd_pairwise_byte.cpp:97-104, ccall at src/linscan/Linscan.jl:63-69.
+ * Same argument list plus `nthreads` (0 = all cores).  codes: m x n uint8 0-based; queries: d x nq;
+ * codebooks = hcat(C...); dbnorms: n.  Outputs (caller-allocated): dists nn x nq f32 ascending,
+ * idx nn x nq int32, 1-BASED.  Distances are bit-identical to the reference build (same f32
+ * operation order); ties are ordered by id, as the reference's pair sort does.  Requires nn <= n. */
+LSQ_API int lsq_linscan_aqd_query_extra_byte(float *dists, int *idx, const unsigned char *codes, const float *queries,
+                                     const float *codebooks, const float *dbnorms, int nqueries, int ncodes,
+                                     int m, int h, int d, int nn, int nthreads);
+
 /* ---- (4) device-side generators used by the benchmark harness -----------------------------
  * X[i][t] = float(uniform integer 0..255) (SIFT-like);  codes uniform 0..h-1 (randinit);
  * codebooks: K[j][a][:] = scale * x_{pick(j,a)} for a Philox-picked synthetic vector. */

@@ -13,11 +13,12 @@ from . import _lib  # noqa: F401
 from .engine import Engine, randinit as randinit_rows, node_order, splitarray as split_ranges, device_count  # noqa: F401
 from .reference_api import (  # noqa: F401
     encode_icm_cuda, encoding_icm, encode_icm_fully, get_unaries, get_binaries, veccost, qerror,
-    randinit, splitarray, default_engine,
+    randinit, splitarray, default_engine, linscan_lsq, eval_recall, quantize_norms, reconstruct,
+    fvecs_read, ivecs_read, bvecs_read,
 )
 from . import distributed  # noqa: F401
 
 __all__ = [
     "Engine", "encode_icm_cuda", "encoding_icm", "encode_icm_fully", "get_unaries", "get_binaries",
-    "veccost", "qerror", "randinit", "splitarray", "node_order", "device_count", "distributed",
+    "veccost", "qerror", "randinit", "splitarray", "node_order", "device_count", "distributed", "linscan_lsq", "eval_recall",
 ]

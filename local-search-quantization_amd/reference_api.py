@@ -107,6 +107,101 @@ def qerror(X, B, C, *, engine=None):
     return eng.qerror(_X_of(X), _B_of(B), _K_of(C), m, h=h)
 
 
+def linscan_lsq(B, X, C, dbnorms, R, k=10000, *, nthreads=0):
+    """Linear scan with LSQ codes + separately stored norms  (src/linscan/Linscan.jl:46-73).
+    B (m, n) uint8 0-based; X (d, nq) queries; C list of (d, h); dbnorms (n,); R (d, d) rotation.
+    -> dists (k, nq) float32 ascending, res (k, nq) int32 1-based ids."""
+    from . import _lib
+    B = np.ascontiguousarray(np.asarray(B, dtype=np.uint8).T)                   # (n, m)
+    RX = np.ascontiguousarray((np.asarray(R, dtype=np.float32).T @ np.asarray(X, dtype=np.float32)).T)   # (nq, d)
+    K = _K_of(C)
+    dbn = np.ascontiguousarray(dbnorms, dtype=np.float32)
+    n, m = B.shape
+    nq, d = RX.shape
+    h = np.asarray(C[0]).shape[1]
+    dists = np.zeros((nq, k), dtype=np.float32)
+    res = np.zeros((nq, k), dtype=np.int32)
+    _lib.check(_lib.load().lsq_linscan_aqd_query_extra_byte(dists.ctypes.data, res.ctypes.data, B.ctypes.data, RX.ctypes.data,
+                                                            K.ctypes.data, dbn.ctypes.data, nq, n, m, h, d, k, int(nthreads)))
+    return dists.T, res.T
+
+
+def eval_recall(ids_gnd, ids_predicted, k, V=False):
+    """recall@N curve (src/linscan/Linscan.jl:76-117): ids_gnd (nq,), ids_predicted (k, nq), same id base.
+    -> recall_at_i (k,) with recall_at_i[i-1] = fraction of queries whose true neighbour ranks <= i."""
+    ids_gnd = np.asarray(ids_gnd)
+    P = np.asarray(ids_predicted)
+    nq = P.shape[1]
+    assert nq == ids_gnd.shape[0]
+    ranks = np.full(nq, k + 1, dtype=np.int64)
+    for i in range(nq):
+        pos = np.nonzero(P[:k, i] == ids_gnd[i])[0]
+        if pos.size == 1:                                   # the reference requires exactly one hit (:94-98)
+            ranks[i] = pos[0] + 1
+    rec = np.array([(ranks <= i).sum() / nq for i in range(1, k + 1)], dtype=np.float64)
+    if V:
+        for i in (1, 2, 5, 10, 20, 50, 100, 200, 500, 1000, 2000, 5000, 10000):
+            if i <= k:
+                print("r@%d = %s" % (i, 100.0 * rec[i - 1]))
+    return rec
+
+
+def reconstruct(B, C):
+    """src/utils.jl:203-223: CB = sum_i C[i][:, B[i, :]] accumulated in codebook order from zero (f32). -> (d, n)"""
+    B = np.asarray(B)
+    d = np.asarray(C[0]).shape[0]
+    CB = np.zeros((d, B.shape[1]), dtype=np.float32)
+    for i, Ci in enumerate(C):
+        CB += np.asarray(Ci, dtype=np.float32)[:, B[i].astype(np.int64) - 1]
+    return CB
+
+
+def quantize_norms(B, C, cbnorms):
+    """src/utils.jl:6-31: squared norm of every reconstruction (f32, dimensions ascending), then the index
+    (1-based Int16) of the nearest scalar centroid in `cbnorms`; ties -> lowest index (findmin)."""
+    CB = reconstruct(B, C)
+    norms = np.zeros(CB.shape[1], dtype=np.float32)
+    for j in range(CB.shape[0]):                      # sequential f32 accumulation, j ascending
+        norms += CB[j] * CB[j]
+    cb = np.asarray(cbnorms, dtype=np.float32)
+    d2 = (norms[None, :] - cb[:, None]) ** 2          # (h, n) f32
+    return (np.argmin(d2, axis=0) + 1).astype(np.int16)
+
+
+def _vecs_read(filename, bounds, dtype, item):
+    """TEXMEX .fvecs/.ivecs/.bvecs (src/read/*vecs_read.jl): records [int32 d][d x item]; bounds = (a, b) 1-based
+    inclusive, an int n (first n vectors) or None (all).  -> (d, n) column-per-vector like the reference."""
+    with open(filename, "rb") as f:
+        d = int(np.frombuffer(f.read(4), dtype=np.int32)[0])
+        rec = 4 + d * item
+        f.seek(0, 2)
+        total = f.tell() // rec
+        if bounds is None:
+            a, b = 1, total
+        elif isinstance(bounds, (int, np.integer)):
+            a, b = 1, int(bounds)
+        else:
+            a, b = int(bounds[0]), int(bounds[-1])
+        assert a >= 1 and b <= total
+        f.seek((a - 1) * rec)
+        raw = np.frombuffer(f.read((b - a + 1) * rec), dtype=np.uint8).reshape(b - a + 1, rec)
+    dims = raw[:, :4].copy().view(np.int32).ravel()
+    assert np.all(dims == d), "inconsistent dimension headers"
+    return np.ascontiguousarray(raw[:, 4:]).view(dtype).reshape(b - a + 1, d).T
+
+
+def fvecs_read(bounds, filename):
+    return _vecs_read(filename, bounds, np.float32, 4)
+
+
+def ivecs_read(bounds, filename):
+    return _vecs_read(filename, bounds, np.int32, 4)
+
+
+def bvecs_read(bounds, filename):
+    return _vecs_read(filename, bounds, np.uint8, 1)
+
+
 def randinit(n, m, h, *, seed=0):
     return _engine.randinit(n, m, h, seed=seed).T
 
