@@ -91,7 +91,7 @@ def test_bad_arguments(lsq):
 # ---- row 8(f)-2: norm quantisation and the TEXMEX readers (host glue) ---------------------------
 def test_quantize_norms_and_reconstruct(lsq):
     rng = np.random.default_rng(3)
-    d, n, m = 16, 200, 4
+    d, n, m = 16, 600, 4
     C = [rng.standard_normal((d, H)).astype(np.float32) for _ in range(m)]
     B = rng.integers(1, H + 1, size=(m, n)).astype(np.int16)
     CB = lsq.reconstruct(B, C)
