@@ -38,9 +38,9 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=3)
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--n", type=int, default=1_000_000, help="vectors per GPU")
-    p.add_argument("--d", type=int, default=128)
-    p.add_argument("--m", type=int, default=8)
+    p.add_argument("--vectors", dest="n", type=int, default=1_000_000, help="vectors per GPU")
+    p.add_argument("--dim", dest="d", type=int, default=128)
+    p.add_argument("--codebooks", dest="m", type=int, default=8)
     p.add_argument("--ils", type=int, default=16)
     p.add_argument("--icmiter", type=int, default=4)
     p.add_argument("--npert", type=int, default=4)
@@ -99,15 +99,21 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev                      # one rank per GPU in production; modulo only for 1-GPU smoke runs
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("LSQ_BENCH_BACKEND", "nccl")       # "nccl" IS RCCL on ROCm; gloo only for 1-GPU smoke tests
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend)
 
     n, d, m, h = args.n, args.d, args.m, 256
-    eng = lsq.Engine(local_rank, profile=True, schedule=args.schedule, chunk=(args.chunk or None))
+    eng = lsq.Engine(dev_index, profile=True, schedule=args.schedule, chunk=(args.chunk or None))
     eng.set_option("skip", args.skip)
     eng.set_option("lane", args.lane)
     eng.set_option("ablation", args.ablation)
