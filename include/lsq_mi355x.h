@@ -174,6 +174,13 @@ LSQ_API int lsq_linscan_aqd_query_extra_byte(float *dists, int *idx, const unsig
                                      const float *codebooks, const float *dbnorms, int nqueries, int ncodes,
                                      int m, int h, int d, int nn, int nthreads);
 
+/* update_codebooks(X, B, h) -> C      src/codebook_update.jl:52-86 (host code; north_star keeps it on the host).
+ * K[t, :] = lsqr(sparsify_codes(B, h), X[t, :]) for every dimension t (LSQR of Paige & Saunders, Float32,
+ * x0 = 0, atol = btol = sqrt(eps(Float32)), conlim = 1e8 -- IterativeSolvers' defaults; PARITY UNPINNED, the
+ * reference neither vendors nor pins IterativeSolvers).  X d x n, B m x n Int16 1-based; K_out d x (m*h)
+ * = hcat(C...) caller-allocated.  nthreads 0 = all cores (dimensions are independent). */
+LSQ_API int lsq_update_codebooks(const float *X, const int16_t *B, int d, int64_t n, int m, int h, int nthreads, float *K_out);
+
 /* ---- (4) device-side generators used by the benchmark harness -----------------------------
  * X[i][t] = float(uniform integer 0..255) (SIFT-like);  codes uniform 0..h-1 (randinit);
  * codebooks: K[j][a][:] = scale * x_{pick(j,a)} for a Philox-picked synthetic vector. */

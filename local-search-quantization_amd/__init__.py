@@ -14,7 +14,7 @@ from .engine import Engine, randinit as randinit_rows, node_order, splitarray as
 from .reference_api import (  # noqa: F401
     encode_icm_cuda, encoding_icm, encode_icm_fully, get_unaries, get_binaries, veccost, qerror,
     randinit, splitarray, default_engine, linscan_lsq, eval_recall, quantize_norms, reconstruct,
-    fvecs_read, ivecs_read, bvecs_read,
+    fvecs_read, ivecs_read, bvecs_read, update_codebooks, train_lsq,
 )
 from . import distributed  # noqa: F401
 

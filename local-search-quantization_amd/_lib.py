@@ -55,6 +55,7 @@ SIGNATURES = {
     "lsq_node_order": (_i, [_u64, _u32, _i, _i, _vp]),
     "lsq_splitarray": (_i, [_i64, _i, _i, C.POINTER(_i64), C.POINTER(_i64)]),
     "lsq_linscan_aqd_query_extra_byte": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
+    "lsq_update_codebooks": (_i, [_vp, _vp, _i, _i64, _i, _i, _i, _vp]),
     "lsq_synth_data_u8_dev": (_i, [_vp, _u64, _u64, _i64, _i, _vp]),
     "lsq_randinit_dev": (_i, [_vp, _u64, _u64, _i64, _i, _i, _vp]),
     "lsq_synth_codebooks_dev": (_i, [_vp, _u64, _i, _i, _i, _vp]),

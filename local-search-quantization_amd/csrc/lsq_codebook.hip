@@ -1,0 +1,144 @@
+// lsq_codebook.hip -- codebook update by sparse least squares (HOST code; north_star keeps it on the host).
+//
+// Replaces update_codebooks(X, B, h) of the reference (src/codebook_update.jl:52-86): for every dimension t,
+//     K[t, :] = lsqr(S, X[t, :])        S = sparsify_codes(B, h)  (src/utils.jl:50-69)
+// where S is the n x (m*h) matrix with S[i, (j-1)*h + B[j,i]] = 1 (one 1 per codebook and row), solved by
+// IterativeSolvers.lsqr with its defaults (x0 = 0, damp = 0, atol = btol = sqrt(eps(Float32)),
+// conlim = 1e8, maxiter = max(size(S))).  IterativeSolvers is not vendored nor version-pinned by the
+// reference (PARITY UNPINNED); this file restates the published LSQR algorithm of Paige & Saunders
+// (ACM TOMS 8(1), 1982) in Float32 with the same stopping rules, and never materialises S:
+//     (S v)[i]   = sum_j v[j*h + b_ij]           (gather)
+//     (S' u)[c] += u[i] for every code c of row i (scatter)
+// Rows of K (dimensions) are independent and are spread over std::thread workers -- the reference spreads
+// them over `julia -p` workers the same way (codebook_update.jl:67-79, splitarray(1:d, nworkers())).
+#include <cmath>
+#include <thread>
+#include <vector>
+
+#include "lsq_internal.h"
+
+namespace {
+
+struct CodeView {
+    const int32_t *col;      // [n][m] absolute column j*h + (b_ij - 1)
+    int64_t n;
+    int m, cols;
+};
+
+inline float norm2(const std::vector<float> &v) {
+    float s = 0.0f;
+    for (float x : v) s += x * x;
+    return std::sqrt(s);
+}
+
+// LSQR for one right-hand side b (length n); x (length cols) starts at 0.  Returns the iteration count.
+int lsqr_one(const CodeView &A, const std::vector<float> &b, std::vector<float> &x, float atol, float btol, float conlim, int64_t maxiter) {
+    const int64_t n = A.n;
+    const int m = A.m, cols = A.cols;
+    std::fill(x.begin(), x.end(), 0.0f);
+    std::vector<float> u(b), v((size_t)cols, 0.0f), w, tmpm((size_t)n), tmpn((size_t)cols);
+    const float ctol = conlim > 0 ? 1.0f / conlim : 0.0f;
+    float Anorm = 0, Acond = 0, ddnorm = 0, res2 = 0, xnorm = 0, xxnorm = 0, z = 0, sn2 = 0, cs2 = -1;
+    float beta = norm2(u), alpha = 0;
+    if (beta > 0) {
+        const float ib = 1.0f / beta;
+        for (auto &e : u) e *= ib;
+        for (int64_t i = 0; i < n; ++i) { const float ui = u[(size_t)i]; const int32_t *c = A.col + i * m; for (int j = 0; j < m; ++j) v[(size_t)c[j]] += ui; }
+        alpha = norm2(v);
+    }
+    if (alpha > 0) { const float ia = 1.0f / alpha; for (auto &e : v) e *= ia; }
+    w = v;
+    float Arnorm = alpha * beta;
+    if (Arnorm == 0) return 0;
+    float rhobar = alpha, phibar = beta;
+    const float bnorm = beta;
+    float rnorm = beta;
+    int64_t itn = 0;
+    while (itn < maxiter) {
+        ++itn;
+        // u = S v - alpha u
+        for (int64_t i = 0; i < n; ++i) { const int32_t *c = A.col + i * m; float s = 0.0f; for (int j = 0; j < m; ++j) s += v[(size_t)c[j]]; tmpm[(size_t)i] = s; }
+        for (int64_t i = 0; i < n; ++i) u[(size_t)i] = -alpha * u[(size_t)i] + tmpm[(size_t)i];
+        beta = norm2(u);
+        if (beta > 0) {
+            const float ib = 1.0f / beta;
+            for (auto &e : u) e *= ib;
+            Anorm = std::sqrt(Anorm * Anorm + alpha * alpha + beta * beta);
+            // v = S' u - beta v
+            std::fill(tmpn.begin(), tmpn.end(), 0.0f);
+            for (int64_t i = 0; i < n; ++i) { const float ui = u[(size_t)i]; const int32_t *c = A.col + i * m; for (int j = 0; j < m; ++j) tmpn[(size_t)c[j]] += ui; }
+            for (int c = 0; c < cols; ++c) v[(size_t)c] = -beta * v[(size_t)c] + tmpn[(size_t)c];
+            alpha = norm2(v);
+            if (alpha > 0) { const float ia = 1.0f / alpha; for (auto &e : v) e *= ia; }
+        }
+        // plane rotation (damp = 0: rhobar1 = rhobar, cs1 = 1, sn1 = 0, psi = 0)
+        const float rhobar1 = rhobar;
+        const float rho = std::sqrt(rhobar1 * rhobar1 + beta * beta);
+        const float cs = rhobar1 / rho, sn = beta / rho;
+        const float theta = sn * alpha;
+        rhobar = -cs * alpha;
+        const float phi = cs * phibar;
+        phibar = sn * phibar;
+        const float tau = sn * phi;
+        const float t1 = phi / rho, t2 = -theta / rho;
+        float dk2 = 0.0f;
+        for (int c = 0; c < cols; ++c) {
+            const float wc = w[(size_t)c];
+            x[(size_t)c] += t1 * wc;
+            const float wr = wc / rho;
+            dk2 += wr * wr;
+            w[(size_t)c] = t2 * wc + v[(size_t)c];
+        }
+        ddnorm += dk2;
+        // norm estimates and the stopping rules of Paige & Saunders
+        const float delta = sn2 * rho, gambar = -cs2 * rho, rhs = phi - delta * z, zbar = rhs / gambar;
+        xnorm = std::sqrt(xxnorm + zbar * zbar);
+        const float gamma = std::sqrt(gambar * gambar + theta * theta);
+        cs2 = gambar / gamma; sn2 = theta / gamma; z = rhs / gamma;
+        xxnorm += z * z;
+        Acond = Anorm * std::sqrt(ddnorm);
+        const float res1 = phibar * phibar;
+        rnorm = std::sqrt(res1 + res2);
+        Arnorm = alpha * std::fabs(tau);
+        const float test1 = rnorm / bnorm;
+        const float test2 = Arnorm / (Anorm * rnorm);
+        const float test3 = 1.0f / Acond;
+        const float tt1 = test1 / (1 + Anorm * xnorm / bnorm);
+        const float rtol = btol + atol * Anorm * xnorm / bnorm;
+        if (1 + test3 <= 1 || 1 + test2 <= 1 || 1 + tt1 <= 1) break;
+        if (test3 <= ctol || test2 <= atol || test1 <= rtol) break;
+    }
+    return (int)itn;
+}
+
+}  // namespace
+
+extern "C" int lsq_update_codebooks(const float *X, const int16_t *B, int d, int64_t n, int m, int h, int nthreads, float *K) {
+    if (d < 1 || n < 1 || m < 1 || h < 1 || !X || !B || !K) { lsq_set_error("lsq_update_codebooks: bad arguments"); return LSQ_EINVAL; }
+    const int cols = m * h;
+    std::vector<int32_t> col((size_t)n * m);
+    for (int64_t i = 0; i < n; ++i)
+        for (int j = 0; j < m; ++j) {
+            const int b = B[i * m + j];
+            if (b < 1 || b > h) { lsq_set_error("lsq_update_codebooks: code %d outside 1..%d", b, h); return LSQ_ECODE; }
+            col[(size_t)(i * m + j)] = j * h + (b - 1);
+        }
+    const CodeView A{col.data(), n, m, cols};
+    const float tol = std::sqrt(1.1920929e-07f);             // sqrt(eps(Float32)): IterativeSolvers' default atol = btol
+    const int64_t maxiter = n > cols ? n : cols;
+    int nt = nthreads > 0 ? nthreads : (int)std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if (nt > d) nt = d;
+    auto work = [&](int t0, int t1) {
+        std::vector<float> b((size_t)n), x((size_t)cols);
+        for (int t = t0; t < t1; ++t) {
+            for (int64_t i = 0; i < n; ++i) b[(size_t)i] = X[i * d + t];
+            lsqr_one(A, b, x, tol, tol, 1e8f, maxiter);
+            for (int c = 0; c < cols; ++c) K[(size_t)c * d + t] = x[(size_t)c];
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; ++t) pool.emplace_back(work, (int)((int64_t)d * t / nt), (int)((int64_t)d * (t + 1) / nt));
+    for (auto &th : pool) th.join();
+    return LSQ_OK;
+}

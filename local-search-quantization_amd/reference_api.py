@@ -146,6 +146,58 @@ def eval_recall(ids_gnd, ids_predicted, k, V=False):
     return rec
 
 
+def update_codebooks(X, B, h, V=False, codebook_upd_method="lsqr", *, nthreads=0):
+    """src/codebook_update.jl:52-86 -> list of m (d, h) codebooks minimising ||X - sum_j C_j[:, B_j]||^2 (LSQR)."""
+    from . import _lib
+    if codebook_upd_method != "lsqr":
+        raise ValueError("only the reference's default method 'lsqr' is provided")
+    Xr, Br = _X_of(X), _B_of(B)
+    n, d = Xr.shape
+    m = Br.shape[1]
+    K = np.zeros((m * h, d), dtype=np.float32)
+    _lib.check(_lib.load().lsq_update_codebooks(Xr.ctypes.data, Br.ctypes.data, d, n, m, h, int(nthreads), K.ctypes.data))
+    return [np.ascontiguousarray(K[j * h:(j + 1) * h].T) for j in range(m)]
+
+
+def train_lsq(X, m, h, R, B, C, niter, ilsiter, icmiter, randord, npert, V=False, *, seed=0, engine=None):
+    """src/lsq/LSQ.jl:10-88: alternate codebook update (host LSQR) and ILS/ICM encoding (GPU).
+    -> (C, B, cbnorms, B_norms, obj).  The final norm codebook is the reference's plain k-means on the squared
+    norms of the reconstructions (Clustering.kmeans there; a seeded Lloyd iteration here -- unpinned)."""
+    X = np.asarray(X, dtype=np.float32)
+    R = np.asarray(R, dtype=np.float32)
+    d, n = X.shape
+    RX = R.T @ X
+    C = update_codebooks(RX, B, h, V)
+    C = [R @ Ci for Ci in C]
+    it = 0
+
+    def encode(Bc, it):
+        Bs, _ = encode_icm_cuda(X, Bc, C, [ilsiter], icmiter, npert, randord, 1, V, seed=seed + it, engine=engine)
+        return Bs[-1]
+
+    B = encode(np.asarray(B, dtype=np.int16), it)
+    obj = np.zeros(niter, dtype=np.float32)
+    for iter_ in range(niter):
+        obj[iter_] = qerror(X, B, C, engine=engine)
+        if V:
+            print("%3d %e" % (iter_ + 1, obj[iter_]))
+        C = update_codebooks(X, B, h, V)
+        it += 1
+        B = encode(B, it)
+    CB = reconstruct(B, C)
+    dbnorms = (CB.astype(np.float32) ** 2).sum(0).astype(np.float32)
+    rng = np.random.default_rng(seed)
+    cb = np.sort(rng.choice(dbnorms, size=min(h, n), replace=False)).astype(np.float32)
+    for _ in range(25):                                   # Lloyd on scalars
+        assign = np.argmin(np.abs(dbnorms[None, :] - cb[:, None]), axis=0)
+        for c in range(cb.shape[0]):
+            sel = assign == c
+            if sel.any():
+                cb[c] = dbnorms[sel].mean()
+    B_norms = (np.argmin(np.abs(dbnorms[None, :] - cb[:, None]), axis=0) + 1).reshape(1, n).astype(np.int16)
+    return C, B, cb, B_norms, obj
+
+
 def reconstruct(B, C):
     """src/utils.jl:203-223: CB = sum_i C[i][:, B[i, :]] accumulated in codebook order from zero (f32). -> (d, n)"""
     B = np.asarray(B)
