@@ -645,6 +645,89 @@ __global__ __launch_bounds__(256) void cost_kernel(const float *__restrict__ X, 
     }
 }
 
+// Even d: half a wave per vector, 8-byte loads.  Lane l' (0..31) of a half owns dimensions
+// t = 128c + {2l', 2l'+1, 2l'+64, 2l'+65}: the two residues x = 2l', 2l'+1 (mod 64) of the canonical 64 strided
+// partial sums, each accumulated in ascending t, so the reduction order is exactly oracle cost_one()'s:
+// level 1 in-lane (p[2l'] + p[2l'+1]), levels 2..32 across the 32 lanes of the half (DPP), result in the
+// half's last lane.  Half the load instructions of cost_kernel and twice the bytes per instruction.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int M>
+__global__ __launch_bounds__(256) void cost2_kernel(const float *__restrict__ X, const float *__restrict__ K,
+                                                    const uint8_t *rec, uint8_t *cur, float *__restrict__ prev,
+                                                    unsigned long long *__restrict__ counters, int64_t n, int d, int mode,
+                                                    const unsigned short *__restrict__ vnew, unsigned short *__restrict__ vcur) {
+    constexpr int CS = (M <= 8) ? 8 : 16;
+    constexpr int RW = CS / 4;
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5, lp = lane & 31;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    unsigned n_eq = 0, n_lt = 0;
+    for (int64_t i0 = w * 2; i0 < n; i0 += nwaves * 2) {
+        const bool live = i0 + half < n;
+        const int64_t i = live ? i0 + half : n - 1;                       // clamped: loads stay in bounds
+        uint32_t r[RW];
+        const uint32_t *rp = reinterpret_cast<const uint32_t *>(rec + i * CS);
+#pragma unroll
+        for (int q = 0; q < RW; ++q) r[q] = rp[q];
+        const float pc = (mode == 1) ? prev[i] : 0.0f;
+        const float *x = X + i * (int64_t)d;
+        const float *kb[M];
+#pragma unroll
+        for (int k = 0; k < M; ++k) kb[k] = K + ((int64_t)(k * LSQ_H) + ((r[k >> 2] >> (8 * (k & 3))) & 0xffu)) * d;
+        float p0 = 0.0f, p1 = 0.0f;
+        for (int c0 = 0; c0 < d; c0 += 128) {
+            const int ta = c0 + 2 * lp, tb = ta + 64;
+            const bool va = ta < d, vb = tb < d;
+            const int ua = va ? ta : 0, ub = vb ? tb : 0;
+            const f32x2 xa = *reinterpret_cast<const f32x2 *>(x + ua), xb = *reinterpret_cast<const f32x2 *>(x + ub);
+            f32x2 ka[M], kbv[M];
+#pragma unroll
+            for (int k = 0; k < M; ++k) {
+                ka[k] = *reinterpret_cast<const f32x2 *>(kb[k] + ua);
+                kbv[k] = *reinterpret_cast<const f32x2 *>(kb[k] + ub);
+            }
+            f32x2 ca = (f32x2){0.f, 0.f}, cb = (f32x2){0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < M; ++k) { ca = ca + ka[k]; cb = cb + kbv[k]; }      // k ascending from 0 (utils.jl:238-244)
+            const f32x2 ra = ca - xa, rb = cb - xb;
+            const f32x2 sa = ra * ra, sb = rb * rb;                                 // never fused (-ffp-contract=off)
+            p0 = p0 + (va ? sa.x : 0.0f);                                           // residue 2l':   t ascending
+            p1 = p1 + (va ? sa.y : 0.0f);                                           // residue 2l'+1
+            p0 = p0 + (vb ? sb.x : 0.0f);
+            p1 = p1 + (vb ? sb.y : 0.0f);
+        }
+        float v = p0 + p1;                                                          // tree level 1
+        v = v + dpp_self<DPP_XOR1, 0xf>(v);                                         // levels 2, 4, 8, 16: within the row
+        v = v + dpp_self<DPP_XOR2, 0xf>(v);
+        v = v + dpp_self<DPP_HALF_MIRROR, 0xf>(v);
+        v = v + dpp_self<DPP_MIRROR, 0xf>(v);
+        v = v + dpp_zero<DPP_BCAST15, 0xa>(v);                                      // level 32: rows 1 and 3 add rows 0 and 2
+        const float costA = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+        const float costB = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+        const float cost = half ? costB : costA;
+        if (mode == 0) {
+            if (live && lp == 0) prev[i] = cost;
+        } else {
+            const bool eq = live && (cost == pc), lt = live && (cost < pc);          // strict improvement only (encode_icm.jl:183-186)
+            n_eq += (unsigned)__popcll(__ballot(eq && lp == 0));
+            n_lt += (unsigned)__popcll(__ballot(lt && lp == 0));
+            if (lt && lp == 0) {
+                prev[i] = cost;
+                uint32_t *qd = reinterpret_cast<uint32_t *>(cur + i * CS);
+#pragma unroll
+                for (int q = 0; q < RW; ++q) qd[q] = r[q];
+                if (vcur) vcur[i] = vnew[i];
+            }
+        }
+    }
+    if (mode == 1 && lane == 0 && (n_eq | n_lt)) {
+        if (n_eq) atomicAdd(&counters[0], (unsigned long long)n_eq);
+        if (n_lt) atomicAdd(&counters[1], (unsigned long long)n_lt);
+    }
+}
+
 __global__ __launch_bounds__(256) void sum_f64_kernel(const float *__restrict__ v, int64_t n, double *__restrict__ sum) {
     __shared__ double sh[4];
     double acc = 0.0;
@@ -917,7 +1000,14 @@ int lsq_launch_perturb(hipStream_t s, const uint8_t *src, uint8_t *dst, int64_t 
 int lsq_launch_cost(hipStream_t s, const float *X, const float *K, const uint8_t *rec, uint8_t *cur, float *prev,
                     unsigned long long *counters, int64_t n, int d, int m, int mode, const unsigned short *vnew, unsigned short *vcur) {
     if (n <= 0) return LSQ_OK;
-    LSQ_DISPATCH_M(m, hipLaunchKernelGGL(cost_kernel<M_>, dim3(wave_grid((n + 1) / 2)), dim3(256), 0, s, X, K, rec, cur, prev, counters, n, d, mode, vnew, vcur));
+    static int use_v2 = -1;
+    if (use_v2 < 0) { const char *e = getenv("LSQ_COST_V2"); use_v2 = e ? atoi(e) : 1; }
+    // half a wave per vector with 8-byte loads: measured 13 % faster at d = 128, 7 % slower at d = 960 (same box)
+    if (use_v2 && d % 2 == 0 && d <= 256 && ((uintptr_t)X | (uintptr_t)K) % 8 == 0) {
+        LSQ_DISPATCH_M(m, hipLaunchKernelGGL(cost2_kernel<M_>, dim3(wave_grid((n + 1) / 2)), dim3(256), 0, s, X, K, rec, cur, prev, counters, n, d, mode, vnew, vcur));
+    } else {
+        LSQ_DISPATCH_M(m, hipLaunchKernelGGL(cost_kernel<M_>, dim3(wave_grid((n + 1) / 2)), dim3(256), 0, s, X, K, rec, cur, prev, counters, n, d, mode, vnew, vcur));
+    }
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }
