@@ -180,6 +180,17 @@ def main():
             "note": "achieved counts only node updates that were actually recomputed; with skip=1 the others are resolved by "
                     "exact memoisation (inputs unchanged since the node was last minimised) and move no bytes",
         }
+        # HBM traffic per launch from the committed rocprofv3 PMC passes of this build (separate --pmc FETCH_SIZE and
+        # --pmc WRITE_SIZE runs of this same command; FETCH_SIZE x2 = the gfx950 correction for wide streaming reads,
+        # /opt/skills/guides/MI355X_MICROARCH.md section HBM).  Not measurable live inside the benchmark process.
+        try:
+            if args.schedule == 3 and args.skip and n == 1_000_000 and d == 128 and m == 8:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01c_pmc_per_kernel.json")))
+                wk = [k for k in pmc if k.startswith("icm_walk_kernel")][0]
+                roof["traffic"] = (2.0 * pmc[wk]["FETCH_SIZE"]["mean_per_dispatch"] + pmc[wk]["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0
+                roof["traffic_source"] = "profiles/r01c_pmc_per_kernel.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, per dispatch)"
+        except Exception:
+            roof["traffic"] = None
         if args.schedule in (0, 1):
             roof["l2_gather"] = {"achieved": table_bytes / avg_launch_s / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s",
                                  "frac": table_bytes / avg_launch_s / 1e9 / L2_PEAK_GBS}
