@@ -259,3 +259,42 @@ def test_large_shape_sample_vs_oracle(lsq, oracle, d, m):
     for i in np.sort(rng.choice(n, size=24, replace=False)):
         ref, _ = oracle.encode_icm(X[i:i + 1], B0[i:i + 1], K, m, H, ils, J, npert, True, seed, global_offset=int(i))
         assert np.array_equal(ref[0, 0], got[i]), "vector %d differs" % i
+
+
+def _run_c_consumer(tmp_path, X, B0, K, m, ils, J, npert, randord, seed):
+    """Builds tests/c_abi_consumer.c with plain gcc and runs it in a fresh process (no Python / torch inside)."""
+    import os
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_abi_consumer")
+    libdir = os.path.join(root, "local-search-quantization_amd")
+    subprocess.check_call(["gcc", "-O2", os.path.join(root, "tests", "c_abi_consumer.c"), "-I", os.path.join(root, "include"),
+                           "-L", libdir, "-llsq_mi355x", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    n, d = X.shape
+    ils = np.asarray(ils, dtype=np.int64)
+    with open(tmp_path / "in.bin", "wb") as f:
+        f.write(struct.pack("<8i", d, n, m, H, len(ils), J, npert, int(randord)))
+        f.write(struct.pack("<Q", seed))
+        f.write(ils.tobytes())
+        f.write(np.ascontiguousarray(X, np.float32).tobytes())
+        f.write(np.ascontiguousarray(B0, np.int16).tobytes())
+        f.write(np.ascontiguousarray(K, np.float32).tobytes())
+    out = subprocess.check_output([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], env=dict(os.environ)).decode()
+    raw = open(tmp_path / "out.bin", "rb").read()
+    nb = len(ils) * n * m
+    Bs = np.frombuffer(raw[:2 * nb], dtype=np.int16).reshape(len(ils), n, m)
+    objs = np.frombuffer(raw[2 * nb:2 * nb + 4 * len(ils)], dtype=np.float32)
+    secs = struct.unpack("<d", raw[2 * nb + 4 * len(ils):])[0]
+    return Bs, objs, secs, out
+
+
+def test_plain_c_consumer_matches_oracle(oracle, tmp_path):
+    """Drop-in proof: a C program that only includes include/lsq_mi355x.h and links liblsq_mi355x.so (what a Julia
+    ccall binding does) gets the oracle's codes bit for bit."""
+    d, n, m, ils, J, npert, seed = 128, 3000, 8, [1, 3], 4, 4, 5
+    X, K, B0 = make_problem(d, n, m, seed=seed)
+    Bs, objs, secs, out = _run_c_consumer(tmp_path, X, B0, K, m, ils, J, npert, True, seed)
+    Bs_ref, objs_ref = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, True, seed)
+    assert np.array_equal(Bs, Bs_ref)
+    assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0)
