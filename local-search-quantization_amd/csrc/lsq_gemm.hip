@@ -12,29 +12,34 @@
 // (157 TF peak) -- this is the right unit for an exact-f32 contraction; nothing is reshaped into
 // a lower precision.
 //
-// Tiling: 256 threads = 4 waves (2x2), block tile 128 rows x 128 cols, K chunk 32 staged in LDS
-// (row stride 33 floats -> the per-k column reads are bank-conflict-free).  Each wave owns a
+// Tiling: 256 threads = 4 waves (2x2), block tile 128 rows x 128 cols, K chunks of BK staged in LDS
+// (row stride BK+1 floats -> the per-k column reads are bank-conflict-free).  BK = 8 by default: with three
+// resident blocks per CU (77 VGPRs + 64 accumulators) short chunks interleave staging and MFMA phases of different
+// blocks best -- measured on one box at 10^6 x 128: BK 64/32/16/8 -> 9.3/7.5/6.5/6.3 ms (d = 960: 10.1 -> 9.4 ms).  Each wave owns a
 // 64x64 sub-tile = 2x2 MFMA 32x32 accumulators (64 VGPRs).  The MFMA M dimension carries the
 // ROWS of A (vectors) and N the candidates, so for a fixed accumulator register a wave stores
 // two 128-byte runs of consecutive candidates -- full-line writes of the 8 KB/vector unary rows.
 // Block -> tile mapping is XCD-aware: the col tiles that share one 128-row A panel run on the
 // same XCD (block b sits on XCD b % 8), so the panel is fetched from HBM once and re-served by
 // that XCD's L2.
+#include <stdlib.h>
+
 #include "lsq_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32, LD = BK + 1;
+constexpr int BM = 128, BN = 128;
 
-template <bool VEC4>
+template <bool VEC4, int BK>
 __device__ inline void stage_tile(const float *__restrict__ src, int64_t rows_total, int64_t row0, int Kd, int k0,
                                   float scale, float *__restrict__ dst, int tid) {
-    // 128 rows x 32 k -> 1024 float4 slots, 4 per thread
+    // 128 rows x BK k -> 32*BK float4 slots
+    constexpr int LD = BK + 1, Q4 = BK / 4;
 #pragma unroll
     for (int e = tid; e < BM * BK / 4; e += 256) {
-        const int r = e >> 3, q = e & 7;
+        const int r = e / Q4, q = e % Q4;
         const int64_t gr = row0 + r;
         const int kk = k0 + 4 * q;
         float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
@@ -55,11 +60,12 @@ __device__ inline void stage_tile(const float *__restrict__ src, int64_t rows_to
     }
 }
 
-template <bool VEC4>
+template <bool VEC4, int BK>
 __global__ __launch_bounds__(256) void chain_gemm_kernel(const float *__restrict__ A, const float *__restrict__ Bm,
                                                          const float *__restrict__ addv, float alpha, int64_t M, int N,
                                                          int Kd, int h, int64_t plane_stride, int64_t row_stride,
                                                          float *__restrict__ D, int64_t row_tiles, int col_tiles, int slice) {
+    constexpr int LD = BK + 1;
     __shared__ float As[BM * LD];
     __shared__ float Bs[BN * LD];
 
@@ -85,8 +91,8 @@ __global__ __launch_bounds__(256) void chain_gemm_kernel(const float *__restrict
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     for (int k0 = 0; k0 < Kd; k0 += BK) {
-        stage_tile<VEC4>(A, M, row0, Kd, k0, 1.0f, As, tid);
-        stage_tile<VEC4>(Bm, N, col0, Kd, k0, alpha, Bs, tid);
+        stage_tile<VEC4, BK>(A, M, row0, Kd, k0, 1.0f, As, tid);
+        stage_tile<VEC4, BK>(Bm, N, col0, Kd, k0, alpha, Bs, tid);
         __syncthreads();
         const int kend = (Kd - k0 < BK) ? ((Kd - k0 + 1) & ~1) : BK;   // odd tail: one zero product appended
         const float *ap = As + (wy * 64 + l31) * LD + lhi;
@@ -147,11 +153,22 @@ int lsq_launch_chain_gemm(hipStream_t s, const float *A, const float *Bm, const 
     const int64_t blocks = ((row_tiles + 7) / 8) * 8 * col_tiles;
     if (blocks > 0x7fffffffLL) { lsq_set_error("chain_gemm: grid too large"); return LSQ_EINVAL; }
     const bool vec4 = (Kd % 4 == 0) && (((uintptr_t)A | (uintptr_t)Bm) % 16 == 0);
-    if (vec4)
-        hipLaunchKernelGGL(chain_gemm_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
+    static int bk = -1;
+    if (bk < 0) { const char *e = getenv("LSQ_GEMM_BK"); bk = e ? atoi(e) : 8; }
+    if (vec4 && bk == 64)
+        hipLaunchKernelGGL((chain_gemm_kernel<true, 64>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
+                           plane_stride, row_stride, D, row_tiles, col_tiles, slice);
+    else if (vec4 && bk == 8)
+        hipLaunchKernelGGL((chain_gemm_kernel<true, 8>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
+                           plane_stride, row_stride, D, row_tiles, col_tiles, slice);
+    else if (vec4 && bk == 16)
+        hipLaunchKernelGGL((chain_gemm_kernel<true, 16>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
+                           plane_stride, row_stride, D, row_tiles, col_tiles, slice);
+    else if (vec4)
+        hipLaunchKernelGGL((chain_gemm_kernel<true, 32>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
                            plane_stride, row_stride, D, row_tiles, col_tiles, slice);
     else
-        hipLaunchKernelGGL(chain_gemm_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
+        hipLaunchKernelGGL((chain_gemm_kernel<false, 32>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
                            plane_stride, row_stride, D, row_tiles, col_tiles, slice);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
