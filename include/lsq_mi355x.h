@@ -85,12 +85,14 @@ LSQ_API int lsq_destroy(lsq_ctx *ctx);
 LSQ_API int lsq_set_stream(lsq_ctx *ctx, void *hip_stream);
 /* Options: "chunk" (vectors per resident chunk, default 1048576), "profile" (0/1), "own_stream",
  *   "schedule" (all give bit-identical codes):
- *        3 (default) one launch per node update; a 1024-thread block walks all LDS-staged table slices
- *                    for its <= 4096 vectors, unaries streamed slice-major from HBM;
+ *        4 (default) one launch per ILS iteration: a 1024-thread block owns <= 4096 vectors and runs the
+ *                    icmiter x m node updates back to back, walking all LDS-staged table slices for each;
+ *                    unaries streamed slice-major from HBM;
+ *        3 the same kernel, one launch per node update;
  *        2 same slices, one slice per block, partial minima combined by a second kernel;
  *        0 one launch per node update, table columns gathered through L2;
  *        1 fused sweeps, unaries register-resident;
- *   "skip" (0/1, default 1; schedule 3): a node whose conditioning codes did not change since it was
+ *   "skip" (0/1, default 1; schedules 3 and 4): a node whose conditioning codes did not change since it was
  *        last minimised is not recomputed (exact memoisation -- same codes, fewer bytes). */
 LSQ_API int lsq_set_option(lsq_ctx *ctx, const char *key, int64_t value);
 LSQ_API int lsq_get_timings(lsq_ctx *ctx, lsq_timings *out);

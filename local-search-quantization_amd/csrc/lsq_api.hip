@@ -57,7 +57,8 @@ struct lsq_ctx {
     hipStream_t stream = nullptr;
     int64_t chunk = 1 << 20;
     int profile = 0;
-    int schedule = 3;        // 0: per-node L2-gather kernel, 1: fused sweeps, 2: LDS-slice + combine, 3: LDS-walk (default)
+    int schedule = 4;        // 0: per-node L2-gather kernel, 1: fused sweeps, 2: LDS-slice + combine, 3: LDS-walk, one launch per node,
+                             // 4: LDS-walk, one launch per ILS iteration (default)
     int lane = 0;            // schedule 3, m <= 8: experimental one-lane-per-vector kernel (measured 2.5x slower: VGPR spills)
     int ablation = 0;        // timing-only kernel ablations (results are garbage when != 0)
     int skip = 1;            // schedule 3: skip node updates whose inputs did not change (exact memoisation)
@@ -166,7 +167,7 @@ extern "C" int lsq_set_option(lsq_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "lane")) c->lane = value != 0;
     else if (!strcmp(key, "ablation")) c->ablation = (int)value;
     else if (!strcmp(key, "schedule")) {
-        if (value < 0 || value > 3) { lsq_set_error("schedule must be 0..3"); return LSQ_EINVAL; }
+        if (value < 0 || value > 4) { lsq_set_error("schedule must be 0..4"); return LSQ_EINVAL; }
         c->schedule = (int)value;
     } else { lsq_set_error("unknown option '%s'", key); return LSQ_EINVAL; }
     return LSQ_OK;
@@ -238,7 +239,7 @@ static int check_shape(const char *fn, int d, int64_t n, int m, int h) {
 
 // ---- device core ----------------------------------------------------------------------------------
 static int u_slice_width(const lsq_ctx *c, int m) {      // layout of the unary planes for the active schedule
-    return c->schedule == 2 ? lsq_slice_width(m) : c->schedule == 3 ? lsq_walk_slice_width(m) : 0;
+    return c->schedule == 2 ? lsq_slice_width(m) : c->schedule >= 3 ? lsq_walk_slice_width(m) : 0;
 }
 
 static int prepare_tables(lsq_ctx *c, const float *dK, int d, int m) {
@@ -249,7 +250,7 @@ static int prepare_tables(lsq_ctx *c, const float *dK, int d, int m) {
     LSQ_TRY(lsq_launch_sqnorms(c->stream, dK, mh, d, c->sci.as<float>()));
     // rows r = (k,b), cols c = (j,a):  T[((j*m + k)*h + b)*h + a] = chain(K[k,b][t] * 2 K[j,a][t])
     LSQ_TRY(lsq_launch_chain_gemm(c->stream, dK, dK, nullptr, 2.0f, mh, mh, d, LSQ_H, (int64_t)m * LSQ_H * LSQ_H, LSQ_H, c->T.as<float>(), 0));
-    if (c->schedule == 3 && m > 1) {        // slice-major copy for the LDS-walk kernel's contiguous staging
+    if (c->schedule >= 3 && m > 1) {        // slice-major copy for the LDS-walk kernel's contiguous staging
         LSQ_TRY(c->Ts.ensure(sizeof(float) * (size_t)m * (m - 1) * LSQ_H * LSQ_H));
         LSQ_TRY(lsq_launch_tables_to_slices(c->stream, c->T.as<float>(), c->Ts.as<float>(), m, lsq_walk_slice_width(m)));
     }
@@ -269,7 +270,15 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t c
     if (c->schedule == 1) {
         LSQ_TRY(lsq_launch_icm_fused(c->stream, c->U.as<float>(), c->T.as<float>(), rec, cn, m, order, nsweeps));
         c->icm_launches += 1;
-    } else if (c->schedule == 3) {
+    } else if (c->schedule == 4 && !c->lane) {
+        // the whole ILS iteration (nsweeps x m node updates) in ONE launch: a block owns its vectors throughout
+        std::vector<int32_t> seq((size_t)nsweeps * m);
+        for (int sw = 0; sw < nsweeps; ++sw)
+            for (int q = 0; q < m; ++q) seq[(size_t)sw * m + q] = order[q];
+        LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>(), c->Ts.as<float>(), c->T.as<float>(), rec, valid, cn, m, seq.data(), (int)seq.size(), c->skip,
+                                    c->active.as<unsigned long long>(), c->ablation));
+        c->icm_launches += ((int64_t)seq.size() + 63) / 64;
+    } else if (c->schedule >= 3) {
         for (int sw = 0; sw < nsweeps; ++sw)
             for (int q = 0; q < m; ++q) {
                 const int j = order[q];
@@ -277,8 +286,8 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t c
                     LSQ_TRY(lsq_launch_icm_lane(c->stream, c->U.as<float>() + (int64_t)j * cn * LSQ_H, c->Ts.as<float>(), rec, valid, cn, m, j, c->skip,
                                                 c->active.as<unsigned long long>(), c->ablation));
                 else
-                    LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>() + (int64_t)j * cn * LSQ_H, c->Ts.as<float>(), rec, valid, cn, m, j, c->skip,
-                                                c->active.as<unsigned long long>()));
+                    LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>(), c->Ts.as<float>(), c->T.as<float>(), rec, valid, cn, m, &order[q], 1, c->skip,
+                                                c->active.as<unsigned long long>(), c->ablation));
             }
         c->icm_launches += (int64_t)nsweeps * m;
     } else if (c->schedule == 2) {
@@ -297,7 +306,7 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t c
             }
         c->icm_launches += (int64_t)nsweeps * m;
     }
-    if (c->schedule != 3) c->icm_node_updates += cn * (int64_t)nsweeps * m;      // schedule 3 counts on the device (skips)
+    if (c->schedule < 3) c->icm_node_updates += cn * (int64_t)nsweeps * m;      // schedule 3 counts on the device (skips)
     return LSQ_OK;
 }
 
@@ -379,7 +388,7 @@ static int finish_call(lsq_ctx *c, int64_t I, int nr, double *obj_sums, int64_t 
     unsigned long long act = 0;
     LSQ_HIP(hipMemcpyAsync(&act, c->active.p, sizeof(act), hipMemcpyDeviceToHost, c->stream));
     LSQ_HIP(hipStreamSynchronize(c->stream));
-    if (c->schedule == 3) c->icm_node_updates += (int64_t)act;
+    if (c->schedule >= 3) c->icm_node_updates += (int64_t)act;
     if (stats) for (int64_t q = 0; q < 2 * I; ++q) stats[q] = (int64_t)cnt[(size_t)q];
     return LSQ_OK;
 }

@@ -308,17 +308,20 @@ constexpr int lsq_walk_pp(int M, int SL) {
 }
 #define LSQ_WALK_PP(M, SL) lsq_walk_pp(M, SL)
 
-// ---- LDS-walk schedule (schedule 3) ----------------------------------------------------------------
+#define LSQ_WALK_MAX_NODES 64
+struct WalkNodes { int count; uint8_t j[LSQ_WALK_MAX_NODES]; };      // kernel argument: node updates of one launch, in order
+
+// ---- LDS-walk schedule (schedules 3 and 4) ----------------------------------------------------------------
 // Same arithmetic as icm_slice_kernel, but ONE block walks all 256/SL slices for its own range of
 // <= 4096 vectors, keeping the running (min value, index) of every vector in LDS.  This removes the
 // partial-result round trip through HBM (2 x 8 B x 256/SL per vector and node update) and the combine
 // launch; the price is re-staging the (m-1) x 256 x SL x 4 B slice table from L2 once per slice.
 // Ts is the slice-major copy of the pair tables, Ts[j][slice][kk][b][SL] (kk = rank of k among k != j),
 // so that staging is one contiguous, fully coalesced copy.
-template <int M, int SL, int DEPTH = 2, int ABL = 0>      // ABL: timing-only ablations (1: no U stream, 2: no table adds)
-__global__ __launch_bounds__(1024) void icm_walk_kernel(const float *__restrict__ Usj, const float *__restrict__ Tsj,
+template <int M, int SL, int ABL = 0>      // ABL: timing-only ablations (1: no U stream, 2: no table adds), option "ablation"
+__global__ __launch_bounds__(1024) void icm_walk_kernel(const float *__restrict__ U, const float *__restrict__ Ts, const float *__restrict__ T,
                                                         uint8_t *__restrict__ rec, unsigned short *__restrict__ valid,
-                                                        int64_t n, int j, int per_pass, int use_skip,
+                                                        int64_t n, const WalkNodes nodes, int per_pass, int use_skip, int direct_max,
                                                         unsigned long long *__restrict__ active_total) {
     constexpr int CS = (M <= 8) ? 8 : 16;
     constexpr int NS = LSQ_H / SL;
@@ -343,19 +346,6 @@ __global__ __launch_bounds__(1024) void icm_walk_kernel(const float *__restrict_
     const int v = lane / LPV, q = lane % LPV;
     constexpr int step = 16 * VPW;
 
-    uint32_t sel[CW > 0 ? CW : 1];
-#pragma unroll
-    for (int w = 0; w < CW; ++w) {
-        uint32_t sv = 0;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int kk = 4 * w + t;
-            const int k = kk + (kk >= j ? 1 : 0);
-            sv |= (uint32_t)((kk < M - 1 ? k - 4 * w : 0) & 7) << (8 * t);
-        }
-        sel[w] = sv;
-    }
-
     struct Item { f32x4 u; uint32_t r[RW]; };
 
     const int64_t npass = (n + per_pass - 1) / per_pass;
@@ -363,6 +353,26 @@ __global__ __launch_bounds__(1024) void icm_walk_kernel(const float *__restrict_
         const int64_t lo = pass * per_pass;
         const int64_t hi = (lo + per_pass < n) ? lo + per_pass : n;
         const int cnt = (int)(hi - lo);
+
+        // A block owns its vector range for the whole launch, so the launch may carry a SEQUENCE of node updates
+        // (a full ILS iteration: icmiter sweeps x m nodes, encode_icm.jl:72-76): node update t+1 of a vector only
+        // depends on node update t of the same vector, which this block wrote itself (ordered by the barriers).
+        for (int nu = 0; nu < nodes.count; ++nu) {
+        const int j = nodes.j[nu];
+        const float *__restrict__ Usj = U + (int64_t)j * n * LSQ_H;
+        const float *__restrict__ Tsj = Ts + (int64_t)j * NS * TAB * 4;
+        uint32_t sel[CW > 0 ? CW : 1];
+    #pragma unroll
+        for (int w = 0; w < CW; ++w) {
+            uint32_t sv = 0;
+    #pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int kk = 4 * w + t;
+                const int k = kk + (kk >= j ? 1 : 0);
+                sv |= (uint32_t)((kk < M - 1 ? k - 4 * w : 0) & 7) << (8 * t);
+            }
+            sel[w] = sv;
+        }
 
         // ---- compact list of the vectors whose node j must be recomputed (exact skip: a node whose
         // conditioning codes did not change since it was last minimised keeps the same argmin)
@@ -394,8 +404,34 @@ __global__ __launch_bounds__(1024) void icm_walk_kernel(const float *__restrict_
             __syncthreads();
         }
         const int nact = nact_s;
-        if (nact == 0) continue;                               // block-uniform
+        if (nact == 0) { __syncthreads(); continue; }          // block-uniform (the barrier protects nact_s / wave_tot reuse)
         if (threadIdx.x == 0 && active_total) atomicAdd(active_total, (unsigned long long)nact);
+        if (nact <= direct_max) {
+            // LIGHT block (few active vectors: small n, or a late sweep): staging the whole (m-1) x 256 KiB table through
+            // LDS would cost more than the vectors need.  One wave per vector instead, the (m-1) 1 KiB table columns
+            // gathered straight from L2 (row-major T) -- the icm_node_kernel arithmetic on the slice-major U layout.
+            const float *__restrict__ Tj = T + (int64_t)j * M * LSQ_H * LSQ_H;
+            for (int ci = wave; ci < nact; ci += 16) {
+                const int64_t i = lo + __builtin_amdgcn_readfirstlane((int)list[ci]);
+                const CodeRec cr = load_rec<CS>(rec, i);
+                f32x4 s = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(Usj + ((int64_t)(lane / LPV) * n + i) * SL) + (lane % LPV));
+                f32x4 c[M > 1 ? M - 1 : 1];
+#pragma unroll
+                for (int kk = 0; kk < M - 1; ++kk) {
+                    const int k = kk + (kk >= j ? 1 : 0);
+                    c[kk] = reinterpret_cast<const f32x4 *>(Tj + ((int64_t)(k * LSQ_H) + cr.get(k)) * LSQ_H)[lane];
+                }
+#pragma unroll
+                for (int kk = 0; kk < M - 1; ++kk) s = s + c[kk];      // ascending k, plain f32 adds
+                const uint32_t code = (uint32_t)wave_first_argmin(s, lane);
+                if (lane == 0) {
+                    rec[i * CS + j] = (uint8_t)code;
+                    if (valid) valid[i] = (code != cr.get(j)) ? (unsigned short)(1u << j) : (unsigned short)(valid[i] | (1u << j));
+                }
+            }
+            __syncthreads();
+            continue;
+        }
         for (int ci = threadIdx.x; ci < nact; ci += 1024) best64[ci] = ~0ull;      // ordered before the first atomics by the slice-0 barriers
 
         constexpr int NST = (TAB + 1023) / 1024;               // float4 table entries staged per thread
@@ -500,6 +536,7 @@ __global__ __launch_bounds__(1024) void icm_walk_kernel(const float *__restrict_
             if (valid) valid[i] = (code != old) ? (unsigned short)(1u << j) : (unsigned short)(valid[i] | (1u << j));
         }
         __syncthreads();
+        }   // node updates
     }
 }
 
@@ -870,10 +907,9 @@ static int launch_slice_t(hipStream_t s, const float *Usj, const float *Tj, uint
     return LSQ_OK;
 }
 
-template <int M, int SL, int DEPTH = 2, int ABL = 0>
-static int launch_walk_t(hipStream_t s, const float *Usj, const float *Ts, uint8_t *rec, unsigned short *valid, int64_t n, int j,
-                         int use_skip, unsigned long long *active_total) {
-    constexpr int NS = LSQ_H / SL;
+template <int M, int SL, int ABL = 0>
+static int launch_walk_t(hipStream_t s, const float *U, const float *Ts, const float *T, uint8_t *rec, unsigned short *valid, int64_t n,
+                         const WalkNodes &nodes, int use_skip, unsigned long long *active_total) {
     constexpr int TAB = (M - 1) * LSQ_H * (SL / 4);
     constexpr int PP = LSQ_WALK_PP(M, SL);
     constexpr int LDS_BYTES = TAB * 16 + PP * 8 + PP * 2;                // slice table + packed running best + active list
@@ -882,7 +918,7 @@ static int launch_walk_t(hipStream_t s, const float *Usj, const float *Ts, uint8
     int dev = 0;
     LSQ_HIP(hipGetDevice(&dev));
     if (dev < 64 && !attr_set[dev]) {
-        LSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&icm_walk_kernel<M, SL, DEPTH, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        LSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&icm_walk_kernel<M, SL, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set[dev] = true;
     }
     const int64_t rounds = (n + 256 * (int64_t)PP - 1) / (256 * (int64_t)PP);          // passes per CU
@@ -891,9 +927,10 @@ static int launch_walk_t(hipStream_t s, const float *Usj, const float *Ts, uint8
     if (per_pass < 1) per_pass = 1;
     const int64_t npass = (n + per_pass - 1) / per_pass;
     const unsigned grid = (unsigned)(npass < 256 ? npass : 256);
-    const float *Tsj = Ts + (int64_t)j * NS * TAB * 4;
-    hipLaunchKernelGGL((icm_walk_kernel<M, SL, DEPTH, ABL>), dim3(grid), dim3(1024), LDS_BYTES, s, Usj, Tsj, rec, valid, n, j, (int)per_pass,
-                       (use_skip && valid) ? 1 : 0, active_total);
+    static int direct_max = -1;          // blocks with at most this many active vectors gather from L2 instead of staging (tuning knob)
+    if (direct_max < 0) { const char *e = getenv("LSQ_WALK_DIRECT"); direct_max = e ? atoi(e) : 256; }
+    hipLaunchKernelGGL((icm_walk_kernel<M, SL, ABL>), dim3(grid), dim3(1024), LDS_BYTES, s, U, Ts, T, rec, valid, n, nodes, (int)per_pass,
+                       (use_skip && valid) ? 1 : 0, (T && ABL == 0) ? direct_max : 0, active_total);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }
@@ -904,49 +941,40 @@ int lsq_walk_slice_width(int m) {
     return (m <= 8 && forced != 8) ? 16 : 8;
 }
 
-int lsq_launch_icm_walk(hipStream_t s, const float *Usj, const float *Ts, uint8_t *rec, unsigned short *valid, int64_t n, int m, int j,
-                        int use_skip, unsigned long long *active_total) {
-    if (n <= 0) return LSQ_OK;
-    if (m <= 8 && lsq_walk_slice_width(m) == 8) {
-        switch (m) {
-            case 1: return launch_walk_t<1, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
-            case 2: return launch_walk_t<2, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
-            case 3: return launch_walk_t<3, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
-            case 4: return launch_walk_t<4, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
-            case 5: return launch_walk_t<5, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
-            case 6: return launch_walk_t<6, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
-            case 7: return launch_walk_t<7, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
-            default: return launch_walk_t<8, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+// `order[nnodes]`: the node updates to run back to back inside the launch (1 = one node; icmiter*m = a whole ILS iteration)
+int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const float *T, uint8_t *rec, unsigned short *valid, int64_t n, int m,
+                        const int32_t *order, int nnodes, int use_skip, unsigned long long *active_total, int ablation) {
+    if (n <= 0 || nnodes <= 0) return LSQ_OK;
+    if (m < 1 || m > LSQ_MAX_M) { lsq_set_error("m = %d out of range 1..16", m); return LSQ_EINVAL; }
+    for (int done = 0; done < nnodes; done += LSQ_WALK_MAX_NODES) {
+        WalkNodes nodes;
+        nodes.count = (nnodes - done < LSQ_WALK_MAX_NODES) ? nnodes - done : LSQ_WALK_MAX_NODES;
+        for (int t = 0; t < nodes.count; ++t) {
+            const int j = order[done + t];
+            if (j < 0 || j >= m) { lsq_set_error("node %d out of range 0..%d", j, m - 1); return LSQ_EINVAL; }
+            nodes.j[t] = (uint8_t)j;
         }
-    }
-    switch (m) {
-        case 1: return launch_walk_t<1, 16>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
-        case 2: return launch_walk_t<2, 16>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
-        case 3: return launch_walk_t<3, 16>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
-        case 4: return launch_walk_t<4, 16>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
-        case 5: return launch_walk_t<5, 16>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
-        case 6: return launch_walk_t<6, 16>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
-        case 7: return launch_walk_t<7, 16>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
-        case 8: {
-            static int depth = -1;
-            if (depth < 0) { const char *e = getenv("LSQ_WALK_DEPTH"); depth = e ? atoi(e) : 2; }
-            if (depth == 3) return launch_walk_t<8, 16, 3>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
-            if (depth == 4) return launch_walk_t<8, 16, 4>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
-            if (depth == 1) return launch_walk_t<8, 16, 1>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
-            if (depth == 11) return launch_walk_t<8, 16, 2, 1>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
-            if (depth == 12) return launch_walk_t<8, 16, 2, 2>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
-            return launch_walk_t<8, 16>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
+#define LSQ_WALK_CASE(MM, SLL) case MM: LSQ_TRY((launch_walk_t<MM, SLL>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total))); break;
+        if (m <= 8 && lsq_walk_slice_width(m) == 8) {
+            switch (m) {
+                LSQ_WALK_CASE(1, 8) LSQ_WALK_CASE(2, 8) LSQ_WALK_CASE(3, 8) LSQ_WALK_CASE(4, 8)
+                LSQ_WALK_CASE(5, 8) LSQ_WALK_CASE(6, 8) LSQ_WALK_CASE(7, 8) LSQ_WALK_CASE(8, 8)
+            }
+        } else if (m == 8 && ablation == 1) {
+            LSQ_TRY((launch_walk_t<8, 16, 1>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total)));
+        } else if (m == 8 && ablation == 2) {
+            LSQ_TRY((launch_walk_t<8, 16, 2>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total)));
+        } else {
+            switch (m) {
+                LSQ_WALK_CASE(1, 16) LSQ_WALK_CASE(2, 16) LSQ_WALK_CASE(3, 16) LSQ_WALK_CASE(4, 16)
+                LSQ_WALK_CASE(5, 16) LSQ_WALK_CASE(6, 16) LSQ_WALK_CASE(7, 16) LSQ_WALK_CASE(8, 16)
+                LSQ_WALK_CASE(9, 8) LSQ_WALK_CASE(10, 8) LSQ_WALK_CASE(11, 8) LSQ_WALK_CASE(12, 8)
+                LSQ_WALK_CASE(13, 8) LSQ_WALK_CASE(14, 8) LSQ_WALK_CASE(15, 8) LSQ_WALK_CASE(16, 8)
+            }
         }
-        case 9: return launch_walk_t<9, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
-        case 10: return launch_walk_t<10, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
-        case 11: return launch_walk_t<11, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
-        case 12: return launch_walk_t<12, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
-        case 13: return launch_walk_t<13, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
-        case 14: return launch_walk_t<14, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
-        case 15: return launch_walk_t<15, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
-        case 16: return launch_walk_t<16, 8>(s, Usj, Ts, rec, valid, n, j, use_skip, active_total);
-        default: lsq_set_error("m = %d out of range 1..16", m); return LSQ_EINVAL;
+#undef LSQ_WALK_CASE
     }
+    return LSQ_OK;
 }
 
 int lsq_launch_tables_to_slices(hipStream_t s, const float *T, float *Ts, int m, int sl) {

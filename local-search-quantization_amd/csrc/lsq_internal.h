@@ -101,9 +101,11 @@ int lsq_launch_icm_slice(hipStream_t s, const float *Usj, const float *T, uint8_
 int lsq_walk_slice_width(int m);      // 16 for m <= 8 (8 if LSQ_WALK_SL=8 is set: tuning knob), 8 above
 int lsq_launch_tables_to_slices(hipStream_t s, const float *T, float *Ts, int m, int sl);
 // valid (optional): validity masks, maintained by the kernel; use_skip: skip vectors whose bit j is set (exact);
-// active_total (optional): += number of vectors actually recomputed
-int lsq_launch_icm_walk(hipStream_t s, const float *Usj, const float *Ts, uint8_t *rec, unsigned short *valid, int64_t n, int m, int j,
-                        int use_skip, unsigned long long *active_total);
+// active_total (optional): += number of vectors actually recomputed; ablation != 0: timing-only variants (m = 8), garbage results.
+// U is the slice-major unary buffer of ALL nodes; T (optional) the row-major tables for light blocks' L2 gathers; order[nnodes] = node updates run back to back inside the launch
+// (a block owns its vectors for the whole launch): 1 entry = one node update, icmiter*m entries = a whole ILS iteration.
+int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const float *T, uint8_t *rec, unsigned short *valid, int64_t n, int m,
+                        const int32_t *order, int nnodes, int use_skip, unsigned long long *active_total, int ablation);
 // one-lane-per-vector variant of the LDS-walk kernel (m <= 8, slice width 16): same contract as lsq_launch_icm_walk
 int lsq_launch_icm_lane(hipStream_t s, const float *Usj, const float *Ts, uint8_t *rec, unsigned short *valid, int64_t n, int m, int j,
                         int use_skip, unsigned long long *active_total, int ablation);

@@ -38,7 +38,7 @@ def test_oracle_reproduces_golden(oracle, path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("schedule", [3, 2, 0, 1])
+@pytest.mark.parametrize("schedule", [4, 3, 2, 0, 1])
 @pytest.mark.parametrize("path", FIXTURES, ids=lambda p: os.path.basename(p)[:-4])
 def test_hip_reproduces_golden(lsq, path, schedule):
     z, X, K, d, n, m, J, npert, randord, seed = _load(path)

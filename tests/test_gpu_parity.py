@@ -69,10 +69,12 @@ CONFIGS = [
     (64, 100, 5, [1, 3], 1, 5, False, 8, "gauss"),
     (128, 200, 8, [2], 4, 0, True, 9, "sift"),        # no perturbation
     (24, 90, 1, [2], 2, 1, True, 10, "gauss"),        # one codebook: argmin of the unary
+    (32, 150, 8, [2], 9, 3, True, 11, "gauss"),       # 72 node updates per ILS iteration: more than one launch's node list (64)
+    (32, 70, 16, [1], 5, 4, True, 12, "gauss"),       # 80 node updates, 16-byte code records
 ]
 
 
-@pytest.mark.parametrize("schedule", [3, 2, 0, 1])
+@pytest.mark.parametrize("schedule", [4, 3, 2, 0, 1])
 @pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: "d%d_n%d_m%d" % (c[0], c[1], c[2]))
 def test_encode_icm_matches_oracle(lsq, oracle, cfg, schedule):
     d, n, m, ils, J, npert, randord, seed, kind = cfg
@@ -85,21 +87,22 @@ def test_encode_icm_matches_oracle(lsq, oracle, cfg, schedule):
 
 
 def test_skip_unchanged_is_exact(lsq, oracle):
-    """Schedule 3 memoises node updates whose conditioning codes did not change.  It must be a pure
+    """Schedules 3/4 memoise node updates whose conditioning codes did not change.  It must be a pure
     optimisation: identical codes/objective with skip on and off (and equal to the oracle), while
     strictly fewer node updates are recomputed.  n spans several passes per block and ragged tails."""
     d, n, m, ils, J, npert, seed = 64, 9001, 8, [1, 3], 4, 4, 77
     X, K, B0 = make_problem(d, n, m, seed=seed)
     Bs_ref, objs_ref, st_ref = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, True, seed, want_stats=True)
-    counts = {}
-    for skip in (1, 0):
-        with lsq.Engine(0, schedule=3, skip=skip, profile=True) as eng:
-            Bs, objs = eng.encode_icm(X, B0, K, m, ils, J, npert, True, seed=seed)
-            counts[skip] = eng.timings()["icm_node_updates"]
-        assert np.array_equal(Bs, Bs_ref), "skip=%d: %d codes differ" % (skip, (Bs != Bs_ref).sum())
-        assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0)
-    assert counts[0] == n * 3 * J * m
-    assert 0 < counts[1] < counts[0]
+    for schedule in (4, 3):
+        counts = {}
+        for skip in (1, 0):
+            with lsq.Engine(0, schedule=schedule, skip=skip, profile=True) as eng:
+                Bs, objs = eng.encode_icm(X, B0, K, m, ils, J, npert, True, seed=seed)
+                counts[skip] = eng.timings()["icm_node_updates"]
+            assert np.array_equal(Bs, Bs_ref), "schedule %d skip=%d: %d codes differ" % (schedule, skip, (Bs != Bs_ref).sum())
+            assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0)
+        assert counts[0] == n * 3 * J * m
+        assert 0 < counts[1] < counts[0]
 
 
 def test_device_api_chunking_and_offsets(lsq, oracle):
