@@ -22,6 +22,8 @@
 // one coalesced `global_load_dwordx4`.  The wave-level argmin is a 6-step DPP min + one ballot.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "lsq_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -318,7 +320,7 @@ struct WalkNodes { int count; uint8_t j[LSQ_WALK_MAX_NODES]; };      // kernel a
 // launch; the price is re-staging the (m-1) x 256 x SL x 4 B slice table from L2 once per slice.
 // Ts is the slice-major copy of the pair tables, Ts[j][slice][kk][b][SL] (kk = rank of k among k != j),
 // so that staging is one contiguous, fully coalesced copy.
-template <int M, int SL, int ABL = 0>      // ABL: timing-only ablations (1: no U stream, 2: no table adds), option "ablation"
+template <int M, int SL, int ABL = 0, int DEPTH = 2>      // DEPTH: U items in flight per wave (<= 4); ABL: timing-only ablations (1: no U stream, 2: no table adds, 3: no slice barriers), option "ablation"
 __global__ __launch_bounds__(1024) void icm_walk_kernel(const float *__restrict__ U, const float *__restrict__ Ts, const float *__restrict__ T,
                                                         uint8_t *__restrict__ rec, unsigned short *__restrict__ valid,
                                                         int64_t n, const WalkNodes nodes, int per_pass, int use_skip, int direct_max,
@@ -497,34 +499,40 @@ __global__ __launch_bounds__(1024) void icm_walk_kernel(const float *__restrict_
             if (c0 + v < nact) atomicMin(&best64[c0 + v], ((unsigned long long)ord << 32) | li);
         };
         auto compute = [&](const Item &cur, int slice, int c0) { finish(gather(cur), slice, c0); };
-        Item bufA, bufB;
-        load_next(bufA);
-        load_next(bufB);
-        int phase = 0;                                         // 0: bufA holds the next item to consume
+        Item buf[DEPTH];
+#pragma unroll
+        for (int e = 0; e < DEPTH; ++e) load_next(buf[e]);
+        int phase = 0;                                         // index of the buffer holding the next item to consume
 
         for (int slice = 0; slice < NS; ++slice) {
-            __syncthreads();                                   // everyone is done with the previous slice table
+            if (ABL != 3) __syncthreads();                     // everyone is done with the previous slice table
 #pragma unroll
             for (int r = 0; r < NST; ++r) {                    // commit the table prefetched one slice ago
                 const int e = (int)threadIdx.x + r * 1024;
                 if (e < TAB) tab[e] = nxt[r];
             }
-            __syncthreads();
+            if (ABL != 3) __syncthreads();
             if (slice + 1 < NS) prefetch_tab(slice + 1);       // next slice's table travels L2 -> VGPRs under this slice's work
             int c0 = wave * VPW, t = 0;
-            if (phase == 0) {
-                for (; t + 1 < ipw; t += 2) {
-                    compute(bufA, slice, c0); load_next(bufA); c0 += step;
-                    compute(bufB, slice, c0); load_next(bufB); c0 += step;
+            auto run = [&](auto P_) {                          // P = buffer consumed first; all buffer indices are compile-time
+                constexpr int P = decltype(P_)::value;
+                for (; t + DEPTH <= ipw; t += DEPTH) {
+#pragma unroll
+                    for (int e = 0; e < DEPTH; ++e) {
+                        compute(buf[(P + e) % DEPTH], slice, c0); load_next(buf[(P + e) % DEPTH]); c0 += step;
+                    }
                 }
-                if (t < ipw) { compute(bufA, slice, c0); load_next(bufA); phase = 1; }
-            } else {
-                for (; t + 1 < ipw; t += 2) {
-                    compute(bufB, slice, c0); load_next(bufB); c0 += step;
-                    compute(bufA, slice, c0); load_next(bufA); c0 += step;
-                }
-                if (t < ipw) { compute(bufB, slice, c0); load_next(bufB); phase = 0; }
-            }
+#pragma unroll
+                for (int e = 0; e < DEPTH - 1; ++e)
+                    if (t < ipw) {
+                        compute(buf[(P + e) % DEPTH], slice, c0); load_next(buf[(P + e) % DEPTH]); c0 += step;
+                        ++t; phase = (P + e + 1) % DEPTH;
+                    }
+            };
+            if (phase == 0) run(std::integral_constant<int, 0>{});
+            else if (phase == 1) run(std::integral_constant<int, 1 % DEPTH>{});
+            else if (phase == 2) run(std::integral_constant<int, 2 % DEPTH>{});
+            else run(std::integral_constant<int, 3 % DEPTH>{});
         }
         __syncthreads();
         for (int ci = threadIdx.x; ci < nact; ci += 1024) {
@@ -907,7 +915,7 @@ static int launch_slice_t(hipStream_t s, const float *Usj, const float *Tj, uint
     return LSQ_OK;
 }
 
-template <int M, int SL, int ABL = 0>
+template <int M, int SL, int ABL = 0, int DEPTH = 2>
 static int launch_walk_t(hipStream_t s, const float *U, const float *Ts, const float *T, uint8_t *rec, unsigned short *valid, int64_t n,
                          const WalkNodes &nodes, int use_skip, unsigned long long *active_total) {
     constexpr int TAB = (M - 1) * LSQ_H * (SL / 4);
@@ -918,7 +926,7 @@ static int launch_walk_t(hipStream_t s, const float *U, const float *Ts, const f
     int dev = 0;
     LSQ_HIP(hipGetDevice(&dev));
     if (dev < 64 && !attr_set[dev]) {
-        LSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&icm_walk_kernel<M, SL, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        LSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&icm_walk_kernel<M, SL, ABL, DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set[dev] = true;
     }
     const int64_t rounds = (n + 256 * (int64_t)PP - 1) / (256 * (int64_t)PP);          // passes per CU
@@ -929,10 +937,16 @@ static int launch_walk_t(hipStream_t s, const float *U, const float *Ts, const f
     const unsigned grid = (unsigned)(npass < 256 ? npass : 256);
     static int direct_max = -1;          // blocks with at most this many active vectors gather from L2 instead of staging (tuning knob)
     if (direct_max < 0) { const char *e = getenv("LSQ_WALK_DIRECT"); direct_max = e ? atoi(e) : 256; }
-    hipLaunchKernelGGL((icm_walk_kernel<M, SL, ABL>), dim3(grid), dim3(1024), LDS_BYTES, s, U, Ts, T, rec, valid, n, nodes, (int)per_pass,
+    hipLaunchKernelGGL((icm_walk_kernel<M, SL, ABL, DEPTH>), dim3(grid), dim3(1024), LDS_BYTES, s, U, Ts, T, rec, valid, n, nodes, (int)per_pass,
                        (use_skip && valid) ? 1 : 0, (T && ABL == 0) ? direct_max : 0, active_total);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
+}
+
+static int walk_depth() {               // tuning knob (m = 8): U items in flight per wave
+    static int d = -1;
+    if (d < 0) { const char *e = getenv("LSQ_WALK_DEPTH"); d = e ? atoi(e) : 2; }
+    return d;
 }
 
 int lsq_walk_slice_width(int m) {
@@ -960,10 +974,16 @@ int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const fl
                 LSQ_WALK_CASE(1, 8) LSQ_WALK_CASE(2, 8) LSQ_WALK_CASE(3, 8) LSQ_WALK_CASE(4, 8)
                 LSQ_WALK_CASE(5, 8) LSQ_WALK_CASE(6, 8) LSQ_WALK_CASE(7, 8) LSQ_WALK_CASE(8, 8)
             }
+        } else if (m == 8 && walk_depth() == 3) {
+            LSQ_TRY((launch_walk_t<8, 16, 0, 3>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total)));
+        } else if (m == 8 && walk_depth() == 4) {
+            LSQ_TRY((launch_walk_t<8, 16, 0, 4>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total)));
         } else if (m == 8 && ablation == 1) {
             LSQ_TRY((launch_walk_t<8, 16, 1>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total)));
         } else if (m == 8 && ablation == 2) {
             LSQ_TRY((launch_walk_t<8, 16, 2>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total)));
+        } else if (m == 8 && ablation == 3) {
+            LSQ_TRY((launch_walk_t<8, 16, 3>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total)));
         } else {
             switch (m) {
                 LSQ_WALK_CASE(1, 16) LSQ_WALK_CASE(2, 16) LSQ_WALK_CASE(3, 16) LSQ_WALK_CASE(4, 16)
