@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblsq_mi355x.so")
+LIB_PATH = os.environ.get("LSQ_LIB_PATH") or os.path.join(_HERE, "liblsq_mi355x.so")      # override: A/B builds of the same ABI
 
 LSQ_OK, LSQ_EINVAL, LSQ_EHIP, LSQ_ENOMEM, LSQ_ECODE, LSQ_ENODEV = 0, -1, -2, -3, -4, -5
 

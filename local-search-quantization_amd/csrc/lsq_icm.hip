@@ -305,8 +305,9 @@ __global__ __launch_bounds__(1024) void icm_slice_kernel(const float *__restrict
 
 // vectors per block pass of the LDS-walk kernel: table + 10 B per vector must fit the 160 KiB LDS
 constexpr int lsq_walk_pp(int M, int SL) {
-    return ((M - 1) * LSQ_H * (SL / 4) * 16 + 4096 * 10 + 256 <= 160 * 1024) ? 4096
-         : ((M - 1) * LSQ_H * (SL / 4) * 16 + 3072 * 10 + 256 <= 160 * 1024) ? 3072 : 2048;
+    const int avail = 160 * 1024 - 256 - (M - 1) * LSQ_H * (SL / 4) * 16;      // bytes left beside the slice table
+    const int pp = avail / 10 / 64 * 64;
+    return pp > 4096 ? 4096 : pp;                                             // 4096 up to m = 14 (SL = 8), 4032 at m = 16
 }
 #define LSQ_WALK_PP(M, SL) lsq_walk_pp(M, SL)
 
@@ -320,8 +321,8 @@ struct WalkNodes { int count; uint8_t j[LSQ_WALK_MAX_NODES]; };      // kernel a
 // launch; the price is re-staging the (m-1) x 256 x SL x 4 B slice table from L2 once per slice.
 // Ts is the slice-major copy of the pair tables, Ts[j][slice][kk][b][SL] (kk = rank of k among k != j),
 // so that staging is one contiguous, fully coalesced copy.
-template <int M, int SL, int ABL = 0, int DEPTH = 2>      // DEPTH: U items in flight per wave (<= 4); ABL: timing-only ablations (1: no U stream, 2: no table adds, 3: no slice barriers), option "ablation"
-__global__ __launch_bounds__(1024) void icm_walk_kernel(const float *__restrict__ U, const float *__restrict__ Ts, const float *__restrict__ T,
+template <int M, int SL, int ABL = 0, int DEPTH = 2, int NT = 1024>      // NT: threads per block (1024 or 512); DEPTH: U items in flight per wave (<= 8); ABL: timing-only ablations (1: no U stream, 2: no table adds, 3: no slice barriers, 4: U stream only -- no table adds, staging or barriers), option "ablation"
+__global__ __launch_bounds__(NT) void icm_walk_kernel(const float *__restrict__ U, const float *__restrict__ Ts, const float *__restrict__ T,
                                                         uint8_t *__restrict__ rec, unsigned short *__restrict__ valid,
                                                         int64_t n, const WalkNodes nodes, int per_pass, int use_skip, int direct_max,
                                                         unsigned long long *__restrict__ active_total) {
@@ -346,7 +347,9 @@ __global__ __launch_bounds__(1024) void icm_walk_kernel(const float *__restrict_
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int v = lane / LPV, q = lane % LPV;
-    constexpr int step = 16 * VPW;
+    constexpr int NW = NT / 64;                          // waves per block
+    constexpr int EPT = 4096 / NT;                       // vectors per thread in the compaction prologue
+    constexpr int step = NW * VPW;
 
     struct Item { f32x4 u; uint32_t r[RW]; };
 
@@ -379,10 +382,10 @@ __global__ __launch_bounds__(1024) void icm_walk_kernel(const float *__restrict_
         // ---- compact list of the vectors whose node j must be recomputed (exact skip: a node whose
         // conditioning codes did not change since it was last minimised keeps the same argmin)
         {
-            const int base = (int)threadIdx.x * 4;
-            int f[4], c = 0;
+            const int base = (int)threadIdx.x * EPT;
+            int f[EPT], c = 0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < EPT; ++e) {
                 const int idx = base + e;
                 f[e] = 0;
                 if (idx < cnt) f[e] = (!use_skip) || !((valid[lo + idx] >> j) & 1);
@@ -400,9 +403,9 @@ __global__ __launch_bounds__(1024) void icm_walk_kernel(const float *__restrict_
             for (int w2 = 0; w2 < wave; ++w2) wbase += wave_tot[w2];
             int pos = wbase + inc - c;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < EPT; ++e)
                 if (f[e]) list[pos++] = (unsigned short)(base + e);
-            if (threadIdx.x == 1023) nact_s = wbase + inc;
+            if (threadIdx.x == NT - 1) nact_s = wbase + inc;
             __syncthreads();
         }
         const int nact = nact_s;
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(1024) void icm_walk_kernel(const float *__restrict_
             // LDS would cost more than the vectors need.  One wave per vector instead, the (m-1) 1 KiB table columns
             // gathered straight from L2 (row-major T) -- the icm_node_kernel arithmetic on the slice-major U layout.
             const float *__restrict__ Tj = T + (int64_t)j * M * LSQ_H * LSQ_H;
-            for (int ci = wave; ci < nact; ci += 16) {
+            for (int ci = wave; ci < nact; ci += NW) {
                 const int64_t i = lo + __builtin_amdgcn_readfirstlane((int)list[ci]);
                 const CodeRec cr = load_rec<CS>(rec, i);
                 f32x4 s = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(Usj + ((int64_t)(lane / LPV) * n + i) * SL) + (lane % LPV));
@@ -434,22 +437,22 @@ __global__ __launch_bounds__(1024) void icm_walk_kernel(const float *__restrict_
             __syncthreads();
             continue;
         }
-        for (int ci = threadIdx.x; ci < nact; ci += 1024) best64[ci] = ~0ull;      // ordered before the first atomics by the slice-0 barriers
+        for (int ci = threadIdx.x; ci < nact; ci += NT) best64[ci] = ~0ull;      // ordered before the first atomics by the slice-0 barriers
 
-        constexpr int NST = (TAB + 1023) / 1024;               // float4 table entries staged per thread
+        constexpr int NST = (TAB + NT - 1) / NT;               // float4 table entries staged per thread
         f32x4 nxt[NST > 0 ? NST : 1];
         auto prefetch_tab = [&](int sl) {
             const f32x4 *src = reinterpret_cast<const f32x4 *>(Tsj) + (int64_t)sl * TAB;
 #pragma unroll
             for (int r = 0; r < NST; ++r) {
-                const int e = (int)threadIdx.x + r * 1024;
+                const int e = (int)threadIdx.x + r * NT;
                 nxt[r] = (e < TAB) ? src[e] : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         };
         prefetch_tab(0);
 
-        // The U stream is ONE flat software pipeline over (slice, iteration), two items in flight per
-        // wave (deeper measured slower): the loads of the first iterations of slice s+1 are in flight
+        // The U stream is ONE flat software pipeline over (slice, iteration), DEPTH (2) items in flight per
+        // wave (3, 4 at 1024 threads and 4..8 at 512 threads measured equal or slower): the loads of the first iterations of slice s+1 are in flight
         // while slice s finishes.  The two item buffers have STATIC roles (loop unrolled by two, the
         // roles swap when a slice has an odd iteration count) so no register copies are issued: the
         // kernel is instruction-issue bound (ablations in DESIGN.md), every slot counts.
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(1024) void icm_walk_kernel(const float *__restrict_
                     const int kk = 4 * w + t;
                     if (kk < M - 1) {
                         const uint32_t code = (cw >> (8 * t)) & 0xffu;
-                        if (ABL != 2) s = s + tab[(kk * LSQ_H + code) * LPV + q];      // ascending k, plain f32 add
+                        if (ABL != 2 && ABL != 4) s = s + tab[(kk * LSQ_H + code) * LPV + q];      // ascending k, plain f32 add
                         else s.x += (float)code;
                     }
                 }
@@ -505,14 +508,14 @@ __global__ __launch_bounds__(1024) void icm_walk_kernel(const float *__restrict_
         int phase = 0;                                         // index of the buffer holding the next item to consume
 
         for (int slice = 0; slice < NS; ++slice) {
-            if (ABL != 3) __syncthreads();                     // everyone is done with the previous slice table
+            if (ABL < 3) __syncthreads();                      // everyone is done with the previous slice table
 #pragma unroll
             for (int r = 0; r < NST; ++r) {                    // commit the table prefetched one slice ago
-                const int e = (int)threadIdx.x + r * 1024;
-                if (e < TAB) tab[e] = nxt[r];
+                const int e = (int)threadIdx.x + r * NT;
+                if (e < TAB && ABL != 4) tab[e] = nxt[r];
             }
-            if (ABL != 3) __syncthreads();
-            if (slice + 1 < NS) prefetch_tab(slice + 1);       // next slice's table travels L2 -> VGPRs under this slice's work
+            if (ABL < 3) __syncthreads();
+            if (slice + 1 < NS && ABL != 4) prefetch_tab(slice + 1);       // next slice's table travels L2 -> VGPRs under this slice's work
             int c0 = wave * VPW, t = 0;
             auto run = [&](auto P_) {                          // P = buffer consumed first; all buffer indices are compile-time
                 constexpr int P = decltype(P_)::value;
@@ -529,13 +532,19 @@ __global__ __launch_bounds__(1024) void icm_walk_kernel(const float *__restrict_
                         ++t; phase = (P + e + 1) % DEPTH;
                     }
             };
-            if (phase == 0) run(std::integral_constant<int, 0>{});
-            else if (phase == 1) run(std::integral_constant<int, 1 % DEPTH>{});
-            else if (phase == 2) run(std::integral_constant<int, 2 % DEPTH>{});
-            else run(std::integral_constant<int, 3 % DEPTH>{});
+            switch (phase) {
+                case 0: run(std::integral_constant<int, 0>{}); break;
+                case 1: run(std::integral_constant<int, 1 % DEPTH>{}); break;
+                case 2: run(std::integral_constant<int, 2 % DEPTH>{}); break;
+                case 3: run(std::integral_constant<int, 3 % DEPTH>{}); break;
+                case 4: run(std::integral_constant<int, 4 % DEPTH>{}); break;
+                case 5: run(std::integral_constant<int, 5 % DEPTH>{}); break;
+                case 6: run(std::integral_constant<int, 6 % DEPTH>{}); break;
+                default: run(std::integral_constant<int, 7 % DEPTH>{}); break;
+            }
         }
         __syncthreads();
-        for (int ci = threadIdx.x; ci < nact; ci += 1024) {
+        for (int ci = threadIdx.x; ci < nact; ci += NT) {
             const int64_t i = lo + list[ci];
             const unsigned bi = (unsigned)(best64[ci] & 0xffffffffull);
             const uint8_t code = (uint8_t)(bi > 255 ? 0 : bi);
@@ -915,7 +924,7 @@ static int launch_slice_t(hipStream_t s, const float *Usj, const float *Tj, uint
     return LSQ_OK;
 }
 
-template <int M, int SL, int ABL = 0, int DEPTH = 2>
+template <int M, int SL, int ABL = 0, int DEPTH = 2, int NT = 1024>
 static int launch_walk_t(hipStream_t s, const float *U, const float *Ts, const float *T, uint8_t *rec, unsigned short *valid, int64_t n,
                          const WalkNodes &nodes, int use_skip, unsigned long long *active_total) {
     constexpr int TAB = (M - 1) * LSQ_H * (SL / 4);
@@ -926,7 +935,7 @@ static int launch_walk_t(hipStream_t s, const float *U, const float *Ts, const f
     int dev = 0;
     LSQ_HIP(hipGetDevice(&dev));
     if (dev < 64 && !attr_set[dev]) {
-        LSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&icm_walk_kernel<M, SL, ABL, DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        LSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&icm_walk_kernel<M, SL, ABL, DEPTH, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_set[dev] = true;
     }
     const int64_t rounds = (n + 256 * (int64_t)PP - 1) / (256 * (int64_t)PP);          // passes per CU
@@ -937,16 +946,10 @@ static int launch_walk_t(hipStream_t s, const float *U, const float *Ts, const f
     const unsigned grid = (unsigned)(npass < 256 ? npass : 256);
     static int direct_max = -1;          // blocks with at most this many active vectors gather from L2 instead of staging (tuning knob)
     if (direct_max < 0) { const char *e = getenv("LSQ_WALK_DIRECT"); direct_max = e ? atoi(e) : 256; }
-    hipLaunchKernelGGL((icm_walk_kernel<M, SL, ABL, DEPTH>), dim3(grid), dim3(1024), LDS_BYTES, s, U, Ts, T, rec, valid, n, nodes, (int)per_pass,
+    hipLaunchKernelGGL((icm_walk_kernel<M, SL, ABL, DEPTH, NT>), dim3(grid), dim3(NT), LDS_BYTES, s, U, Ts, T, rec, valid, n, nodes, (int)per_pass,
                        (use_skip && valid) ? 1 : 0, (T && ABL == 0) ? direct_max : 0, active_total);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
-}
-
-static int walk_depth() {               // tuning knob (m = 8): U items in flight per wave
-    static int d = -1;
-    if (d < 0) { const char *e = getenv("LSQ_WALK_DEPTH"); d = e ? atoi(e) : 2; }
-    return d;
 }
 
 int lsq_walk_slice_width(int m) {
@@ -960,6 +963,8 @@ int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const fl
                         const int32_t *order, int nnodes, int use_skip, unsigned long long *active_total, int ablation) {
     if (n <= 0 || nnodes <= 0) return LSQ_OK;
     if (m < 1 || m > LSQ_MAX_M) { lsq_set_error("m = %d out of range 1..16", m); return LSQ_EINVAL; }
+    static int big_nt = -1;              // block size for m > 8 (tuning knob LSQ_WALK_BIG_NT=1024 restores the old shape)
+    if (big_nt < 0) { const char *e = getenv("LSQ_WALK_BIG_NT"); big_nt = (e && atoi(e) == 1024) ? 1024 : 512; }
     for (int done = 0; done < nnodes; done += LSQ_WALK_MAX_NODES) {
         WalkNodes nodes;
         nodes.count = (nnodes - done < LSQ_WALK_MAX_NODES) ? nnodes - done : LSQ_WALK_MAX_NODES;
@@ -968,31 +973,36 @@ int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const fl
             if (j < 0 || j >= m) { lsq_set_error("node %d out of range 0..%d", j, m - 1); return LSQ_EINVAL; }
             nodes.j[t] = (uint8_t)j;
         }
+        // m > 8: up to 15 table reads in flight + 8..15 staged table registers per thread do not fit 128 VGPRs (measured:
+        // ~100 spilled registers, 2.5x slower) -> 512-thread blocks (256 VGPRs per wave), more U items in flight instead
+#define LSQ_WALK_CASE_BIG(MM) case MM: \
+            if (big_nt == 512) LSQ_TRY((launch_walk_t<MM, 8, 0, 4, 512>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total))); \
+            else LSQ_TRY((launch_walk_t<MM, 8>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total))); \
+            break;
 #define LSQ_WALK_CASE(MM, SLL) case MM: LSQ_TRY((launch_walk_t<MM, SLL>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total))); break;
         if (m <= 8 && lsq_walk_slice_width(m) == 8) {
             switch (m) {
                 LSQ_WALK_CASE(1, 8) LSQ_WALK_CASE(2, 8) LSQ_WALK_CASE(3, 8) LSQ_WALK_CASE(4, 8)
                 LSQ_WALK_CASE(5, 8) LSQ_WALK_CASE(6, 8) LSQ_WALK_CASE(7, 8) LSQ_WALK_CASE(8, 8)
             }
-        } else if (m == 8 && walk_depth() == 3) {
-            LSQ_TRY((launch_walk_t<8, 16, 0, 3>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total)));
-        } else if (m == 8 && walk_depth() == 4) {
-            LSQ_TRY((launch_walk_t<8, 16, 0, 4>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total)));
         } else if (m == 8 && ablation == 1) {
             LSQ_TRY((launch_walk_t<8, 16, 1>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total)));
         } else if (m == 8 && ablation == 2) {
             LSQ_TRY((launch_walk_t<8, 16, 2>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total)));
         } else if (m == 8 && ablation == 3) {
             LSQ_TRY((launch_walk_t<8, 16, 3>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total)));
+        } else if (m == 8 && ablation == 4) {
+            LSQ_TRY((launch_walk_t<8, 16, 4>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total)));
         } else {
             switch (m) {
                 LSQ_WALK_CASE(1, 16) LSQ_WALK_CASE(2, 16) LSQ_WALK_CASE(3, 16) LSQ_WALK_CASE(4, 16)
                 LSQ_WALK_CASE(5, 16) LSQ_WALK_CASE(6, 16) LSQ_WALK_CASE(7, 16) LSQ_WALK_CASE(8, 16)
-                LSQ_WALK_CASE(9, 8) LSQ_WALK_CASE(10, 8) LSQ_WALK_CASE(11, 8) LSQ_WALK_CASE(12, 8)
-                LSQ_WALK_CASE(13, 8) LSQ_WALK_CASE(14, 8) LSQ_WALK_CASE(15, 8) LSQ_WALK_CASE(16, 8)
+                LSQ_WALK_CASE_BIG(9) LSQ_WALK_CASE_BIG(10) LSQ_WALK_CASE_BIG(11) LSQ_WALK_CASE_BIG(12)
+                LSQ_WALK_CASE_BIG(13) LSQ_WALK_CASE_BIG(14) LSQ_WALK_CASE_BIG(15) LSQ_WALK_CASE_BIG(16)
             }
         }
 #undef LSQ_WALK_CASE
+#undef LSQ_WALK_CASE_BIG
     }
     return LSQ_OK;
 }
