@@ -13,9 +13,10 @@
 // a lower precision.
 //
 // Tiling: 256 threads = 4 waves (2x2), block tile 128 rows x 128 cols, K chunks of BK staged in LDS
-// (row stride BK+1 floats -> the per-k column reads are bank-conflict-free).  BK = 8 by default: with three
-// resident blocks per CU (77 VGPRs + 64 accumulators) short chunks interleave staging and MFMA phases of different
-// blocks best -- measured on one box at 10^6 x 128: BK 64/32/16/8 -> 9.3/7.5/6.5/6.3 ms (d = 960: 10.1 -> 9.4 ms).  Each wave owns a
+// (row stride BK+1 floats -> the per-k column reads are bank-conflict-free), double-buffered: the next chunk is loaded
+// into registers while the MFMAs of the current one run, one barrier per chunk.  BK = 16 by default (three resident
+// blocks per CU); measured on one box at 10^6 x 128: BK 8/16/32/64 -> 5.9/5.7/6.4/10.6 ms (single-buffered BK = 8 was
+// 6.7 ms; d = 960, 250 K vectors: 9.4 -> 8.3 ms).  Each wave owns a
 // 64x64 sub-tile = 2x2 MFMA 32x32 accumulators (64 VGPRs).  The MFMA M dimension carries the
 // ROWS of A (vectors) and N the candidates, so for a fixed accumulator register a wave stores
 // two 128-byte runs of consecutive candidates -- full-line writes of the 8 KB/vector unary rows.
@@ -32,31 +33,46 @@ namespace {
 
 constexpr int BM = 128, BN = 128;
 
+// One K chunk of a 128-row panel: global -> registers (tile_load), registers -> LDS (tile_store).  Split in two so
+// that the loads of chunk c+1 are in flight while the MFMAs of chunk c run (register double buffering).
 template <bool VEC4, int BK>
-__device__ inline void stage_tile(const float *__restrict__ src, int64_t rows_total, int64_t row0, int Kd, int k0,
-                                  float scale, float *__restrict__ dst, int tid) {
-    // 128 rows x BK k -> 32*BK float4 slots
-    constexpr int LD = BK + 1, Q4 = BK / 4;
+struct TileRegs { float4 v[BM * BK / 4 / 256]; };
+
+template <bool VEC4, int BK>
+__device__ inline void tile_load(const float *__restrict__ src, int64_t rows_total, int64_t row0, int Kd, int k0,
+                                 TileRegs<VEC4, BK> &t, int tid) {
+    constexpr int Q4 = BK / 4, NE = BM * BK / 4 / 256;
 #pragma unroll
-    for (int e = tid; e < BM * BK / 4; e += 256) {
+    for (int i = 0; i < NE; ++i) {
+        const int e = tid + i * 256;
         const int r = e / Q4, q = e % Q4;
         const int64_t gr = row0 + r;
         const int kk = k0 + 4 * q;
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gr < rows_total) {
             const float *p = src + gr * (int64_t)Kd + kk;
             if (VEC4 && kk + 3 < Kd) {
-                const float4 v = *reinterpret_cast<const float4 *>(p);
-                v0 = v.x; v1 = v.y; v2 = v.z; v3 = v.w;
+                v = *reinterpret_cast<const float4 *>(p);
             } else {
-                if (kk + 0 < Kd) v0 = p[0];
-                if (kk + 1 < Kd) v1 = p[1];
-                if (kk + 2 < Kd) v2 = p[2];
-                if (kk + 3 < Kd) v3 = p[3];
+                if (kk + 0 < Kd) v.x = p[0];
+                if (kk + 1 < Kd) v.y = p[1];
+                if (kk + 2 < Kd) v.z = p[2];
+                if (kk + 3 < Kd) v.w = p[3];
             }
         }
+        t.v[i] = v;
+    }
+}
+
+template <bool VEC4, int BK>
+__device__ inline void tile_store(const TileRegs<VEC4, BK> &t, float scale, float *__restrict__ dst, int tid) {
+    constexpr int LD = BK + 1, Q4 = BK / 4, NE = BM * BK / 4 / 256;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = tid + i * 256;
+        const int r = e / Q4, q = e % Q4;
         float *o = dst + r * LD + 4 * q;
-        o[0] = v0 * scale; o[1] = v1 * scale; o[2] = v2 * scale; o[3] = v3 * scale;   // scale is +-2 or 1: exact
+        o[0] = t.v[i].x * scale; o[1] = t.v[i].y * scale; o[2] = t.v[i].z * scale; o[3] = t.v[i].w * scale;   // scale is +-2 or 1: exact
     }
 }
 
@@ -66,8 +82,8 @@ __global__ __launch_bounds__(256) void chain_gemm_kernel(const float *__restrict
                                                          int Kd, int h, int64_t plane_stride, int64_t row_stride,
                                                          float *__restrict__ D, int64_t row_tiles, int col_tiles, int slice) {
     constexpr int LD = BK + 1;
-    __shared__ float As[BM * LD];
-    __shared__ float Bs[BN * LD];
+    __shared__ float As[2][BM * LD];
+    __shared__ float Bs[2][BN * LD];
 
     const int64_t b = blockIdx.x;
     const int xcd = (int)(b & 7);
@@ -90,14 +106,23 @@ __global__ __launch_bounds__(256) void chain_gemm_kernel(const float *__restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    TileRegs<VEC4, BK> ra, rb;
+    tile_load<VEC4, BK>(A, M, row0, Kd, 0, ra, tid);
+    tile_load<VEC4, BK>(Bm, N, col0, Kd, 0, rb, tid);
+    tile_store<VEC4, BK>(ra, 1.0f, As[0], tid);
+    tile_store<VEC4, BK>(rb, alpha, Bs[0], tid);
+    __syncthreads();
+    int cur = 0;
     for (int k0 = 0; k0 < Kd; k0 += BK) {
-        stage_tile<VEC4, BK>(A, M, row0, Kd, k0, 1.0f, As, tid);
-        stage_tile<VEC4, BK>(Bm, N, col0, Kd, k0, alpha, Bs, tid);
-        __syncthreads();
+        const bool more = k0 + BK < Kd;
+        if (more) {                                              // next chunk travels HBM/L2 -> registers under this chunk's MFMAs
+            tile_load<VEC4, BK>(A, M, row0, Kd, k0 + BK, ra, tid);
+            tile_load<VEC4, BK>(Bm, N, col0, Kd, k0 + BK, rb, tid);
+        }
         const int kend = (Kd - k0 < BK) ? ((Kd - k0 + 1) & ~1) : BK;   // odd tail: one zero product appended
-        const float *ap = As + (wy * 64 + l31) * LD + lhi;
-        const float *bp = Bs + (wx * 64 + l31) * LD + lhi;
-        for (int kk = 0; kk < kend; kk += 2) {
+        const float *ap = As[cur] + (wy * 64 + l31) * LD + lhi;
+        const float *bp = Bs[cur] + (wx * 64 + l31) * LD + lhi;
+        for (int kk = 0; kk < kend; kk += 2) {                  // ascending k through one accumulator: the oracle's fmaf chain
             const float a0 = ap[kk], a1 = ap[32 * LD + kk];
             const float b0 = bp[kk], b1 = bp[32 * LD + kk];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
@@ -105,7 +130,12 @@ __global__ __launch_bounds__(256) void chain_gemm_kernel(const float *__restrict
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
+        if (more) {                                              // the other buffer was last read one iteration ago (barrier below)
+            tile_store<VEC4, BK>(ra, 1.0f, As[cur ^ 1], tid);
+            tile_store<VEC4, BK>(rb, alpha, Bs[cur ^ 1], tid);
+        }
         __syncthreads();
+        cur ^= 1;
     }
 
 #pragma unroll
@@ -154,7 +184,7 @@ int lsq_launch_chain_gemm(hipStream_t s, const float *A, const float *Bm, const 
     if (blocks > 0x7fffffffLL) { lsq_set_error("chain_gemm: grid too large"); return LSQ_EINVAL; }
     const bool vec4 = (Kd % 4 == 0) && (((uintptr_t)A | (uintptr_t)Bm) % 16 == 0);
     static int bk = -1;
-    if (bk < 0) { const char *e = getenv("LSQ_GEMM_BK"); bk = e ? atoi(e) : 8; }
+    if (bk < 0) { const char *e = getenv("LSQ_GEMM_BK"); bk = e ? atoi(e) : 16; }
     if (vec4 && bk == 64)
         hipLaunchKernelGGL((chain_gemm_kernel<true, 64>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
                            plane_stride, row_stride, D, row_tiles, col_tiles, slice);
