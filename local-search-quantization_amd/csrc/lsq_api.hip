@@ -64,7 +64,9 @@ struct lsq_ctx {
     int skip = 1;            // schedule 3: skip node updates whose inputs did not change (exact memoisation)
     // workspace
     DevBuf sci, T, Ts, U, part, vCur, vNew, active, recCur, recNew, prev, counters, obj, bad;
-    DevBuf sX, sK, sB16, sOut16, sTight, sF32;    // staging for the host-buffer entry points
+    DevBuf sX, sX2, sK, sB16, sOut16, sTight, sF32;    // staging for the host-buffer entry points (sX/sX2: double-buffered X chunks)
+    hipStream_t copy_stream = nullptr;               // H2D of X runs here, under the compute of the previous panel / chunk
+    hipEvent_t copy_done = nullptr;
     // timings
     double cat_ms[CAT_COUNT] = {0, 0, 0, 0, 0, 0};
     int64_t icm_launches = 0, icm_node_updates = 0;
@@ -146,6 +148,8 @@ extern "C" int lsq_destroy(lsq_ctx *c) {
                       &c->sX, &c->sK, &c->sB16, &c->sOut16, &c->sTight, &c->sF32};
     for (DevBuf *b : bufs) b->release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->copy_done) (void)hipEventDestroy(c->copy_done);
     delete c;
     return LSQ_OK;
 }
@@ -249,7 +253,7 @@ static int prepare_tables(lsq_ctx *c, const float *dK, int d, int m) {
     LSQ_TRY(c->T.ensure(sizeof(float) * (size_t)mh * mh));
     LSQ_TRY(lsq_launch_sqnorms(c->stream, dK, mh, d, c->sci.as<float>()));
     // rows r = (k,b), cols c = (j,a):  T[((j*m + k)*h + b)*h + a] = chain(K[k,b][t] * 2 K[j,a][t])
-    LSQ_TRY(lsq_launch_chain_gemm(c->stream, dK, dK, nullptr, 2.0f, mh, mh, d, LSQ_H, (int64_t)m * LSQ_H * LSQ_H, LSQ_H, c->T.as<float>(), 0));
+    LSQ_TRY(lsq_launch_chain_gemm(c->stream, dK, dK, nullptr, 2.0f, mh, mh, d, LSQ_H, (int64_t)m * LSQ_H * LSQ_H, LSQ_H, c->T.as<float>(), 0, mh, 0));
     if (c->schedule >= 3 && m > 1) {        // slice-major copy for the LDS-walk kernel's contiguous staging
         LSQ_TRY(c->Ts.ensure(sizeof(float) * (size_t)m * (m - 1) * LSQ_H * LSQ_H));
         LSQ_TRY(lsq_launch_tables_to_slices(c->stream, c->T.as<float>(), c->Ts.as<float>(), m, lsq_walk_slice_width(m)));
@@ -257,12 +261,14 @@ static int prepare_tables(lsq_ctx *c, const float *dK, int d, int m) {
     return LSQ_OK;
 }
 
-static int build_unaries(lsq_ctx *c, const float *dX, const float *dK, int d, int64_t cn, int m, int slice) {
+// unaries of rows [r0, r0 + rows) of a cn-vector chunk (dX points at the chunk's first vector)
+static int build_unaries(lsq_ctx *c, const float *dX, const float *dK, int d, int64_t cn, int m, int slice, int64_t r0, int64_t rows) {
     Timer t(c, CAT_UNARIES);
     LSQ_TRY(c->U.ensure(sizeof(float) * (size_t)m * (size_t)cn * LSQ_H));
     // row-major  (slice == 0): U[(j*cn + i)*h + a]                      = chain(x_i[t] * -2 K[j,a][t]) + sci[j,a]
     // slice-major (slice = SL): U[j*cn*h + ((a/SL)*cn + i)*SL + a%SL]   (same values, LDS-slice schedule)
-    return lsq_launch_chain_gemm(c->stream, dX, dK, c->sci.as<float>(), -2.0f, cn, m * LSQ_H, d, LSQ_H, cn * (int64_t)LSQ_H, LSQ_H, c->U.as<float>(), slice);
+    return lsq_launch_chain_gemm(c->stream, dX + r0 * d, dK, c->sci.as<float>(), -2.0f, rows, m * LSQ_H, d, LSQ_H, cn * (int64_t)LSQ_H, LSQ_H,
+                                 c->U.as<float>(), slice, cn, r0);
 }
 
 static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t cn, int m, const int32_t *order, int nsweeps) {
@@ -319,9 +325,10 @@ struct EncodeParams {
 
 // One resident chunk: recCur holds the chunk's codes on entry; snapshots are emitted through `snap`.
 template <class Snap>
-static int encode_chunk(lsq_ctx *c, const float *dXc, const float *dK, int64_t cn, uint64_t goff, const EncodeParams &P, int64_t I, Snap snap) {
+static int encode_chunk(lsq_ctx *c, const float *dXc, const float *dK, int64_t cn, uint64_t goff, const EncodeParams &P, int64_t I, Snap snap,
+                        bool unaries_ready = false) {
     const int cs = lsq_code_stride(P.m);
-    LSQ_TRY(build_unaries(c, dXc, dK, P.d, cn, P.m, u_slice_width(c, P.m)));
+    if (!unaries_ready) LSQ_TRY(build_unaries(c, dXc, dK, P.d, cn, P.m, u_slice_width(c, P.m), 0, cn));
     LSQ_TRY(c->recNew.ensure((size_t)cn * cs));
     LSQ_TRY(c->prev.ensure(sizeof(float) * (size_t)cn));
     LSQ_TRY(c->vCur.ensure(sizeof(unsigned short) * (size_t)cn));
@@ -435,19 +442,37 @@ static int encode_host(lsq_ctx *c, const char *fn, const float *X, const int16_t
     LSQ_TRY(prepare_tables(c, dK, d, m));
     const EncodeParams P{d, m, ilsiters, nr, icmiter, npert, randord, seed, it0};
     const int cs = lsq_code_stride(m);
-    for (int64_t off = 0; off < n; off += c->chunk) {
+    // Chunk c+1's X is uploaded on a second stream under the ILS iterations of chunk c (double-buffered staging).  The first
+    // chunk goes through the compute stream in one piece: a pageable copy on another stream costs ~7 ms more, and splitting it
+    // into panels whose unary GEMMs start early was measured slower (tools/ubench_h2d.hip, tools/host_api_rate.py).
+    if (n > c->chunk) {
+        if (!c->copy_stream) LSQ_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        if (!c->copy_done) LSQ_HIP(hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming));
+    }
+    DevBuf *xb[2] = {&c->sX, &c->sX2};
+    int which = 0;
+    for (int64_t off = 0; off < n; off += c->chunk, which ^= 1) {
         const int64_t cn = std::min<int64_t>(c->chunk, n - off);
-        LSQ_TRY(c->sX.ensure(sizeof(float) * (size_t)cn * d));
+        LSQ_TRY(xb[which]->ensure(sizeof(float) * (size_t)cn * d));
         LSQ_TRY(c->sB16.ensure(sizeof(int16_t) * (size_t)cn * m));
         LSQ_TRY(c->sOut16.ensure(sizeof(int16_t) * (size_t)cn * m * nr));
         LSQ_TRY(c->recCur.ensure((size_t)cn * cs));
-        LSQ_HIP(hipMemcpyAsync(c->sX.p, X + off * d, sizeof(float) * (size_t)cn * d, hipMemcpyHostToDevice, c->stream));
+        float *dXc = xb[which]->as<float>();
+        if (off == 0) LSQ_HIP(hipMemcpyAsync(dXc, X, sizeof(float) * (size_t)cn * d, hipMemcpyHostToDevice, c->stream));
+        else LSQ_HIP(hipStreamWaitEvent(c->stream, c->copy_done, 0));      // uploaded under the previous chunk's compute
         LSQ_HIP(hipMemcpyAsync(c->sB16.p, B + off * m, sizeof(int16_t) * (size_t)cn * m, hipMemcpyHostToDevice, c->stream));
         LSQ_TRY(lsq_launch_codes_from_i16(c->stream, c->sB16.as<int16_t>(), cn, m, h, c->recCur.as<uint8_t>(), c->bad.as<int>()));
         auto snap = [&](int r, const uint8_t *cur) {
             return lsq_launch_codes_to_i16(c->stream, cur, cn, m, c->sOut16.as<int16_t>() + (int64_t)r * cn * m);
         };
-        LSQ_TRY(encode_chunk(c, c->sX.as<float>(), dK, cn, global_offset + (uint64_t)off, P, I, snap));
+        LSQ_TRY(encode_chunk(c, dXc, dK, cn, global_offset + (uint64_t)off, P, I, snap));
+        const int64_t noff = off + c->chunk;
+        if (noff < n) {      // next chunk's X: its buffer was last read by chunk c-1, which completed at the previous synchronize
+            const int64_t ncn = std::min<int64_t>(c->chunk, n - noff);
+            LSQ_TRY(xb[which ^ 1]->ensure(sizeof(float) * (size_t)ncn * d));
+            LSQ_HIP(hipMemcpyAsync(xb[which ^ 1]->p, X + noff * d, sizeof(float) * (size_t)ncn * d, hipMemcpyHostToDevice, c->copy_stream));
+            LSQ_HIP(hipEventRecord(c->copy_done, c->copy_stream));
+        }
         for (int r = 0; r < nr; ++r)
             LSQ_HIP(hipMemcpyAsync(Bs + ((int64_t)r * n + off) * m, c->sOut16.as<int16_t>() + (int64_t)r * cn * m,
                                    sizeof(int16_t) * (size_t)cn * m, hipMemcpyDeviceToHost, c->stream));
@@ -519,7 +544,7 @@ extern "C" int lsq_encode_icm_fully(lsq_ctx *c, int16_t *B, const float *X, cons
     LSQ_TRY(upload_xk(c, X, K, d, n, m));
     LSQ_TRY(upload_codes(c, B, n, m, h, c->recCur));
     LSQ_TRY(prepare_tables(c, c->sK.as<float>(), d, m));
-    LSQ_TRY(build_unaries(c, c->sX.as<float>(), c->sK.as<float>(), d, n, m, u_slice_width(c, m)));
+    LSQ_TRY(build_unaries(c, c->sX.as<float>(), c->sK.as<float>(), d, n, m, u_slice_width(c, m), 0, n));
     LSQ_TRY(c->recNew.ensure((size_t)n * lsq_code_stride(m)));
     int32_t order[LSQ_MAX_M];
     LSQ_TRY(lsq_node_order(seed, it, m, randord, order));
@@ -542,7 +567,7 @@ extern "C" int lsq_get_unaries(lsq_ctx *c, const float *X, const float *K, int d
     LSQ_TRY(upload_xk(c, X, K, d, n, m));
     LSQ_TRY(c->sci.ensure(sizeof(float) * (size_t)m * LSQ_H));
     LSQ_TRY(lsq_launch_sqnorms(c->stream, c->sK.as<float>(), m * LSQ_H, d, c->sci.as<float>()));
-    LSQ_TRY(build_unaries(c, c->sX.as<float>(), c->sK.as<float>(), d, n, m, 0));
+    LSQ_TRY(build_unaries(c, c->sX.as<float>(), c->sK.as<float>(), d, n, m, 0, 0, n));
     LSQ_HIP(hipMemcpyAsync(U, c->U.p, sizeof(float) * (size_t)m * n * LSQ_H, hipMemcpyDeviceToHost, c->stream));
     LSQ_HIP(hipStreamSynchronize(c->stream));
     return LSQ_OK;

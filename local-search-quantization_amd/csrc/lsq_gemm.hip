@@ -80,7 +80,8 @@ template <bool VEC4, int BK>
 __global__ __launch_bounds__(256) void chain_gemm_kernel(const float *__restrict__ A, const float *__restrict__ Bm,
                                                          const float *__restrict__ addv, float alpha, int64_t M, int N,
                                                          int Kd, int h, int64_t plane_stride, int64_t row_stride,
-                                                         float *__restrict__ D, int64_t row_tiles, int col_tiles, int slice) {
+                                                         float *__restrict__ D, int64_t row_tiles, int col_tiles, int slice,
+                                                         int64_t Mtot, int64_t rbase) {
     constexpr int LD = BK + 1;
     __shared__ float As[2][BM * LD];
     __shared__ float Bs[2][BN * LD];
@@ -144,9 +145,10 @@ __global__ __launch_bounds__(256) void chain_gemm_kernel(const float *__restrict
         if (c >= N) continue;
         const float add = addv ? addv[c] : 0.0f;
         // row-major planes: off = (c/h)*plane + (c%h) + r*row_stride
-        // slice-major planes (slice = SL > 0): off = (c/h)*plane + ((c%h)/SL)*(M*SL) + (c%h)%SL + r*SL
+        // slice-major planes (slice = SL > 0): off = (c/h)*plane + ((c%h)/SL)*(Mtot*SL) + (c%h)%SL + r*SL
+        // (r counts from rbase: the launch may cover rows [rbase, rbase + M) of a Mtot-row output)
         const int a = c % h;
-        const int64_t coff = slice ? (int64_t)(c / h) * plane_stride + (int64_t)(a / slice) * (M * slice) + (a % slice)
+        const int64_t coff = slice ? (int64_t)(c / h) * plane_stride + (int64_t)(a / slice) * (Mtot * slice) + (a % slice)
                                    : (int64_t)(c / h) * plane_stride + a;
         const int64_t rstride = slice ? (int64_t)slice : row_stride;
 #pragma unroll
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256) void chain_gemm_kernel(const float *__restrict
                 if (row < M) {
                     float v = acc[ti][tj][r];
                     if (addv) v = v + add;           // one rounded add (utils.jl:112-118)
-                    D[coff + row * rstride] = v;
+                    D[coff + (rbase + row) * rstride] = v;
                 }
             }
         }
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(256) void sqnorms_kernel(const float *__restrict__ 
 }  // namespace
 
 int lsq_launch_chain_gemm(hipStream_t s, const float *A, const float *Bm, const float *addv, float alpha, int64_t M,
-                          int N, int Kd, int h, int64_t plane_stride, int64_t row_stride, float *D, int slice) {
+                          int N, int Kd, int h, int64_t plane_stride, int64_t row_stride, float *D, int slice, int64_t Mtot, int64_t rbase) {
     if (M <= 0 || N <= 0) return LSQ_OK;
     const int64_t row_tiles = (M + BM - 1) / BM;
     const int col_tiles = (N + BN - 1) / BN;
@@ -187,19 +189,19 @@ int lsq_launch_chain_gemm(hipStream_t s, const float *A, const float *Bm, const 
     if (bk < 0) { const char *e = getenv("LSQ_GEMM_BK"); bk = e ? atoi(e) : 16; }
     if (vec4 && bk == 64)
         hipLaunchKernelGGL((chain_gemm_kernel<true, 64>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                           plane_stride, row_stride, D, row_tiles, col_tiles, slice);
+                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase);
     else if (vec4 && bk == 8)
         hipLaunchKernelGGL((chain_gemm_kernel<true, 8>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                           plane_stride, row_stride, D, row_tiles, col_tiles, slice);
+                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase);
     else if (vec4 && bk == 16)
         hipLaunchKernelGGL((chain_gemm_kernel<true, 16>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                           plane_stride, row_stride, D, row_tiles, col_tiles, slice);
+                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase);
     else if (vec4)
         hipLaunchKernelGGL((chain_gemm_kernel<true, 32>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                           plane_stride, row_stride, D, row_tiles, col_tiles, slice);
+                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase);
     else
         hipLaunchKernelGGL((chain_gemm_kernel<false, 32>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                           plane_stride, row_stride, D, row_tiles, col_tiles, slice);
+                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }

@@ -70,10 +70,12 @@ __host__ __device__ inline uint32_t lsq_mulhi32(uint32_t a, uint32_t b) { return
 
 // D[off(r,c)] = chain_t( A[r][t] * (alpha * Bm[c][t]) ) (+ addv[c]);  r<M, c<N, t<Kd.
 // off(r,c) = (c / h) * plane_stride + (c % h) + r * row_stride            (slice == 0, row-major planes)
-//          = (c / h) * plane_stride + ((c % h) / slice) * (M * slice) + (c % h) % slice + r * slice   (slice-major)
-// Chain = k-ascending fmaf from +0.
+//          = (c / h) * plane_stride + ((c % h) / slice) * (Mtot * slice) + (c % h) % slice + r * slice   (slice-major)
+// Chain = k-ascending fmaf from +0.  The launch covers output rows [rbase, rbase + M) of a Mtot-row result (A points at
+// row rbase): row r above counts from rbase -- lets the caller build the unaries panel by panel under the H2D copies.
 int lsq_launch_chain_gemm(hipStream_t s, const float *A, const float *Bm, const float *addv, float alpha,
-                          int64_t M, int N, int Kd, int h, int64_t plane_stride, int64_t row_stride, float *D, int slice);
+                          int64_t M, int N, int Kd, int h, int64_t plane_stride, int64_t row_stride, float *D, int slice,
+                          int64_t Mtot, int64_t rbase);
 // sci[r] = chain_t(Kb[r][t]^2)
 int lsq_launch_sqnorms(hipStream_t s, const float *Kb, int rows, int d, float *sci);
 

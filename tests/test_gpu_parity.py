@@ -129,6 +129,21 @@ def test_device_api_chunking_and_offsets(lsq, oracle):
         assert np.allclose((sa + sb) / n, objs_ref, rtol=1e-5, atol=0)
 
 
+def test_host_api_chunking(lsq, oracle):
+    """Host-buffer entry point with several resident chunks: chunk c+1's X is uploaded on a second stream under the
+    compute of chunk c (double-buffered staging) -- results must equal the one-chunk call and the oracle, for
+    1, 2, 3 (odd: both staging buffers end up last) and many ragged chunks, and on repeated calls of one context."""
+    d, n, m, ils, J, npert, seed = 64, 1531, 8, [2, 3], 3, 4, 5
+    X, K, B0 = make_problem(d, n, m, seed=seed)
+    Bs_ref, objs_ref = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, True, seed)
+    for chunk in (4096, 800, 600, 127):
+        with lsq.Engine(0, chunk=chunk) as eng:
+            for _ in range(2):
+                Bs, objs = eng.encode_icm(X, B0, K, m, ils, J, npert, True, seed=seed)
+                assert np.array_equal(Bs, Bs_ref), "chunk %d: %d codes differ" % (chunk, (Bs != Bs_ref).sum())
+                assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0)
+
+
 def test_reference_shaped_api(lsq, oracle):
     """The Julia-shaped mirror: encode_icm_cuda / encoding_icm / encode_icm_fully / helpers."""
     d, n, m, seed = 128, 200, 8, 33

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle as O
 from test_gpu_parity import _run_c_consumer
-n, d, m = 1_000_000, 128, 8
+n, d, m = (int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000), 128, 8
 X = O.synth_data_u8(1234, n, d)
 K = np.ascontiguousarray(O.synth_data_u8(4321, m * 256, d) / np.float32(m))
 B0 = O.randinit(7, n, m, 256)
