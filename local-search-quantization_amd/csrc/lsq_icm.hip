@@ -451,8 +451,8 @@ __global__ __launch_bounds__(NT) void icm_walk_kernel(const float *__restrict__ 
         };
         prefetch_tab(0);
 
-        // The U stream is ONE flat software pipeline over (slice, iteration), DEPTH (2) items in flight per
-        // wave (3, 4 at 1024 threads and 4..8 at 512 threads measured equal or slower): the loads of the first iterations of slice s+1 are in flight
+        // The U stream is ONE flat software pipeline over (slice, iteration), DEPTH items in flight per
+        // wave (3 at 1024 threads: the most that fits 128 VGPRs without spills, 1 % faster than 2; 4..8 at 512 threads: slower at m = 8): the loads of the first iterations of slice s+1 are in flight
         // while slice s finishes.  The two item buffers have STATIC roles (loop unrolled by two, the
         // roles swap when a slice has an odd iteration count) so no register copies are issued: the
         // kernel is instruction-issue bound (ablations in DESIGN.md), every slot counts.
@@ -463,11 +463,14 @@ __global__ __launch_bounds__(NT) void icm_walk_kernel(const float *__restrict__ 
             int ci = wave * VPW + lit * step + v;
             ci = ci < nact ? ci : nact - 1;
             const int lsc = ls < NS ? ls : NS - 1;
-            const int64_t i = lo + list[ci];
-            if (ABL == 1) it.u = (f32x4){(float)i, 1.f, 2.f, 3.f};
-            else it.u = __builtin_nontemporal_load(      // streamed once per node update: non-temporal measured 3 % faster than a cached load
-                reinterpret_cast<const f32x4 *>(Usj + ((int64_t)lsc * n + i) * SL) + q);
-            const uint32_t *rp = reinterpret_cast<const uint32_t *>(rec + i * CS);
+            // wave-uniform 64-bit bases (SGPRs) + 32-bit lane offsets: one VALU instruction per address instead of a 64-bit chain
+            const uint32_t li = list[ci];
+            const char *ub = reinterpret_cast<const char *>(Usj + ((int64_t)lsc * n + lo) * SL);
+            const char *rb = reinterpret_cast<const char *>(rec + lo * CS);
+            const uint32_t uo = li * (uint32_t)(SL * 4) + (uint32_t)q * 16u;
+            if (ABL == 1) it.u = (f32x4){(float)li, 1.f, 2.f, 3.f};
+            else it.u = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(ub + uo));      // streamed once per node update: non-temporal measured 3 % faster than a cached load
+            const uint32_t *rp = reinterpret_cast<const uint32_t *>(rb + li * (uint32_t)CS);
 #pragma unroll
             for (int w = 0; w < RW; ++w) it.r[w] = rp[w];
             if (++lit >= ipw) { lit = 0; ++ls; }
@@ -482,7 +485,11 @@ __global__ __launch_bounds__(NT) void icm_walk_kernel(const float *__restrict__ 
                 for (int t = 0; t < 4; ++t) {
                     const int kk = 4 * w + t;
                     if (kk < M - 1) {
-                        const uint32_t code = (cw >> (8 * t)) & 0xffu;
+                        uint32_t code;
+                        // low byte through an opaque v_and so that the address is and + lshl_add (the optimiser's own form,
+                        // (cw << 6) & 0x3fc0 then + base, is one VALU instruction longer); the others are bfe/lshr + lshl_add
+                        if (t == 0) asm("v_and_b32 %0, 0xff, %1" : "=v"(code) : "v"(cw));
+                        else code = (cw >> (8 * t)) & 0xffu;
                         if (ABL != 2 && ABL != 4) s = s + tab[(kk * LSQ_H + code) * LPV + q];      // ascending k, plain f32 add
                         else s.x += (float)code;
                     }
@@ -493,7 +500,10 @@ __global__ __launch_bounds__(NT) void icm_walk_kernel(const float *__restrict__ 
         auto finish = [&](f32x4 s, int slice, int c0) {
             // first-argmin: in-lane over 4 candidates, then one packed LDS atomic min per lane
             float lm = fminf(fminf(s.x, s.y), fminf(s.z, s.w));
-            uint32_t li = ((s.x == lm) ? 0u : (s.y == lm) ? 1u : (s.z == lm) ? 2u : 3u) + 4u * q + (uint32_t)(SL * slice);
+            uint32_t li = (s.z == lm) ? 2u : 3u;                               // three selects, no divergent control flow
+            li = (s.y == lm) ? 1u : li;
+            li = (s.x == lm) ? 0u : li;
+            li += 4u * q + (uint32_t)(SL * slice);
             const uint32_t bits = __float_as_uint(lm + 0.0f);                  // -0 -> +0: they compare equal in the reference
             uint32_t ord = bits ^ ((uint32_t)((int32_t)bits >> 31) | 0x80000000u);   // monotone float -> uint
             if (__builtin_expect(__ballot((lm != lm) | (s.x != s.x)) != 0ull, 0)) {       // wave-uniform, rare: a NaN is present
@@ -964,7 +974,7 @@ int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const fl
                         const int32_t *order, int nnodes, int use_skip, unsigned long long *active_total, int ablation) {
     if (n <= 0 || nnodes <= 0) return LSQ_OK;
     if (m < 1 || m > LSQ_MAX_M) { lsq_set_error("m = %d out of range 1..16", m); return LSQ_EINVAL; }
-    static int big_nt = -1;              // block size for m > 8 (tuning knob LSQ_WALK_BIG_NT=1024 restores the old shape)
+    static int big_nt = -1;              // block size for m >= 14 (tuning knob LSQ_WALK_BIG_NT=1024 restores the old shape)
     if (big_nt < 0) { const char *e = getenv("LSQ_WALK_BIG_NT"); big_nt = (e && atoi(e) == 1024) ? 1024 : 512; }
     for (int done = 0; done < nnodes; done += LSQ_WALK_MAX_NODES) {
         WalkNodes nodes;
@@ -974,13 +984,15 @@ int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const fl
             if (j < 0 || j >= m) { lsq_set_error("node %d out of range 0..%d", j, m - 1); return LSQ_EINVAL; }
             nodes.j[t] = (uint8_t)j;
         }
-        // m > 8: up to 15 table reads in flight + 8..15 staged table registers per thread do not fit 128 VGPRs (measured:
-        // ~100 spilled registers, 2.5x slower) -> 512-thread blocks (256 VGPRs per wave), more U items in flight instead
+        // m >= 14: up to 15 table reads in flight + 8 staged table registers per thread do not fit 128 VGPRs (measured at
+        // m = 16: 67..100 spilled registers, 1.5..2.5x slower) -> 512-thread blocks (256 VGPRs per wave), more U items in
+        // flight instead.  m = 9..13 fit (<= 4 spills) and are 3-5 % faster with 1024 threads (measured for every m).
+#define LSQ_WALK_CASE_MID(MM) case MM: LSQ_TRY((launch_walk_t<MM, 8, 0, 2>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total))); break;
 #define LSQ_WALK_CASE_BIG(MM) case MM: \
             if (big_nt == 512) LSQ_TRY((launch_walk_t<MM, 8, 0, 4, 512>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total))); \
             else LSQ_TRY((launch_walk_t<MM, 8>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total))); \
             break;
-#define LSQ_WALK_CASE(MM, SLL) case MM: LSQ_TRY((launch_walk_t<MM, SLL>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total))); break;
+#define LSQ_WALK_CASE(MM, SLL) case MM: LSQ_TRY((launch_walk_t<MM, SLL, 0, 3>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total))); break;
         if (m <= 8 && lsq_walk_slice_width(m) == 8) {
             switch (m) {
                 LSQ_WALK_CASE(1, 8) LSQ_WALK_CASE(2, 8) LSQ_WALK_CASE(3, 8) LSQ_WALK_CASE(4, 8)
@@ -994,16 +1006,18 @@ int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const fl
             LSQ_TRY((launch_walk_t<8, 16, 3>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total)));
         } else if (m == 8 && ablation == 4) {
             LSQ_TRY((launch_walk_t<8, 16, 4>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total)));
+
         } else {
             switch (m) {
                 LSQ_WALK_CASE(1, 16) LSQ_WALK_CASE(2, 16) LSQ_WALK_CASE(3, 16) LSQ_WALK_CASE(4, 16)
                 LSQ_WALK_CASE(5, 16) LSQ_WALK_CASE(6, 16) LSQ_WALK_CASE(7, 16) LSQ_WALK_CASE(8, 16)
-                LSQ_WALK_CASE_BIG(9) LSQ_WALK_CASE_BIG(10) LSQ_WALK_CASE_BIG(11) LSQ_WALK_CASE_BIG(12)
-                LSQ_WALK_CASE_BIG(13) LSQ_WALK_CASE_BIG(14) LSQ_WALK_CASE_BIG(15) LSQ_WALK_CASE_BIG(16)
+                LSQ_WALK_CASE_MID(9) LSQ_WALK_CASE_MID(10) LSQ_WALK_CASE_MID(11) LSQ_WALK_CASE_MID(12)
+                LSQ_WALK_CASE_MID(13) LSQ_WALK_CASE_BIG(14) LSQ_WALK_CASE_BIG(15) LSQ_WALK_CASE_BIG(16)
             }
         }
 #undef LSQ_WALK_CASE
 #undef LSQ_WALK_CASE_BIG
+#undef LSQ_WALK_CASE_MID
     }
     return LSQ_OK;
 }
