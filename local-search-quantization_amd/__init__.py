@@ -16,9 +16,14 @@ from .reference_api import (  # noqa: F401
     randinit, splitarray, default_engine, linscan_lsq, eval_recall, quantize_norms, reconstruct,
     fvecs_read, ivecs_read, bvecs_read, update_codebooks, train_lsq,
 )
+from .initializers import (  # noqa: F401
+    train_pq, quantize_pq, train_opq, quantize_opq, train_chainq, encoding_viterbi, update_codebooks_chain, get_cbdims_chain,
+)
 from . import distributed  # noqa: F401
 
 __all__ = [
     "Engine", "encode_icm_cuda", "encoding_icm", "encode_icm_fully", "get_unaries", "get_binaries",
     "veccost", "qerror", "randinit", "splitarray", "node_order", "device_count", "distributed", "linscan_lsq", "eval_recall",
+    "quantize_norms", "reconstruct", "update_codebooks", "train_lsq", "train_pq", "quantize_pq", "train_opq", "quantize_opq",
+    "train_chainq", "encoding_viterbi", "update_codebooks_chain", "get_cbdims_chain", "fvecs_read", "ivecs_read", "bvecs_read",
 ]

@@ -1,0 +1,255 @@
+"""Host-side initialisers of the LSQ training pipeline: PQ, OPQ and ChainQ.
+
+Mirrors of the reference's trainers with the reference's names, argument order and Julia shapes, so that
+`demos/demo_lsq_gpu.jl` reads the same against this package:
+
+    C, B, R, err = train_opq(x_train, m, h, niter, "natural")        # src/opq/OPQ.jl:21-101
+    C, B, R, err = train_chainq(x_train, m, h, R, B, C, niter)       # src/chainq/chainq.jl:10-58
+    C, B, cbnorms, B_norms, obj = train_lsq(x_train, m, h, R, B, C, ...)   # reference_api.train_lsq (GPU encoder)
+
+These are callers of the hot path, not the path: plain numpy / scipy on the host (north_star keeps them there).
+PARITY UNPINNED: the reference delegates to Clustering.jl k-means, StatsBase sampling and IterativeSolvers LSQR,
+none vendored or version-pinned, and has no tests for them; what is mirrored is the algorithm and the interfaces.
+Shapes follow Julia: X is d x n, codes B are m x n Int16 **1-based**, codebooks are lists of (rows x h) matrices.
+"""
+import numpy as np
+
+from .engine import splitarray
+
+__all__ = ["train_pq", "quantize_pq", "qerror_pq", "train_opq", "quantize_opq", "get_cbdims_chain",
+           "update_codebooks_chain", "encoding_viterbi", "train_chainq", "kmeans"]
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _subdims(d, m):
+    """splitarray(1:d, m) as 0-based slices (src/utils.jl:152-177)."""
+    return [slice(lo, hi) for lo, hi in splitarray(d, m)]
+
+
+def _sqdist(C, X):
+    """pairwise SqEuclidean: (h, n) distances between the columns of C (r x h) and X (r x n)."""
+    cc = np.einsum("ij,ij->j", C, C)[:, None]
+    xx = np.einsum("ij,ij->j", X, X)[None, :]
+    return np.maximum(cc + xx - 2.0 * (C.T @ X), 0.0).astype(np.float32)
+
+
+def _assign(C, X):
+    """Nearest codeword per column of X, lowest index on ties (update_assignments!, src/opq/kmeans.jl:6-75)."""
+    dm = _sqdist(C, X)
+    a = dm.argmin(axis=0)
+    return a, dm[a, np.arange(X.shape[1])]
+
+
+def _centers(X, a, h, rng, old=None):
+    """Cluster means (update_centers!, src/opq/kmeans.jl:77-123); an empty cluster is re-seeded with a random point."""
+    r, n = X.shape
+    C = np.zeros((r, h), dtype=np.float32)
+    cnt = np.bincount(a, minlength=h)
+    np.add.at(C.T, a, X.T)
+    nz = cnt > 0
+    C[:, nz] /= cnt[nz]
+    for k in np.nonzero(~nz)[0]:
+        C[:, k] = X[:, rng.integers(n)] if old is None else old[:, k]
+    return C
+
+
+def kmeans(X, h, niter=25, seed=0):
+    """Lloyd k-means with k-means++ seeding on the columns of X (r x n) -> centers (r x h), assignments (n,) 0-based, total cost.
+    Stands in for Clustering.jl's `kmeans(X, h, init=:kmpp)` (src/pq/PQ.jl:60)."""
+    X = _f32(X)
+    r, n = X.shape
+    rng = np.random.default_rng(seed)
+    C = np.empty((r, h), dtype=np.float32)
+    C[:, 0] = X[:, rng.integers(n)]
+    d2 = ((X - C[:, :1]) ** 2).sum(axis=0)
+    for k in range(1, h):
+        tot = float(d2.sum())
+        idx = rng.integers(n) if tot <= 0 else int(np.searchsorted(np.cumsum(d2), rng.random() * tot))
+        C[:, k] = X[:, min(idx, n - 1)]
+        d2 = np.minimum(d2, ((X - C[:, k:k + 1]) ** 2).sum(axis=0))
+    a, cost = _assign(C, X)
+    for _ in range(niter):
+        C = _centers(X, a, h, rng)
+        a2, cost = _assign(C, X)
+        if np.array_equal(a2, a):
+            break
+        a = a2
+    return C, a, float(cost.sum())
+
+
+# ---- PQ (src/pq/PQ.jl) ---------------------------------------------------------------------------------------
+def quantize_pq(X, C, V=False):
+    """quantize_pq(X, C) -> B (m x n Int16, 1-based).  src/pq/PQ.jl:12-41"""
+    X = _f32(X)
+    sd = _subdims(X.shape[0], len(C))
+    return np.stack([_assign(_f32(C[i]), X[sd[i]])[0] + 1 for i in range(len(C))]).astype(np.int16)
+
+
+def qerror_pq(X, B, C):
+    """Mean squared reconstruction error of PQ codes (codebooks hold sub-vectors)."""
+    X = _f32(X)
+    sd = _subdims(X.shape[0], len(C))
+    err = 0.0
+    for i in range(len(C)):
+        err += float(((X[sd[i]] - _f32(C[i])[:, np.asarray(B[i], dtype=np.int64) - 1]) ** 2).sum())
+    return err / X.shape[1]
+
+
+def train_pq(X, m, h, V=False, *, seed=0):
+    """train_pq(X, m, h) -> C, B, error.  src/pq/PQ.jl:44-76 (k-means per subspace)."""
+    X = _f32(X)
+    sd = _subdims(X.shape[0], m)
+    C, B = [], []
+    for i in range(m):
+        c, a, cost = kmeans(X[sd[i]], h, seed=seed + i)
+        C.append(c)
+        B.append(a + 1)
+        if V:
+            print("codebook %d / %d: error in subspace %e" % (i + 1, m, cost / X.shape[1]))
+    B = np.stack(B).astype(np.int16)
+    return C, B, qerror_pq(X, B, C)
+
+
+# ---- OPQ (src/opq/OPQ.jl) ------------------------------------------------------------------------------------
+def quantize_opq(X, R, C, V=False):
+    """quantize_opq(X, R, C) = quantize_pq(R'X, C).  src/opq/OPQ.jl:10-19"""
+    return quantize_pq(_f32(R).T @ _f32(X), C, V)
+
+
+def _procrustes(X, CB):
+    """R = U V' with U S V' = svd(X CB')  (src/opq/OPQ.jl:78-79, src/chainq/chainq.jl:44-45)."""
+    U, _, Vt = np.linalg.svd(X.astype(np.float64) @ CB.astype(np.float64).T, full_matrices=False)
+    return (U @ Vt).astype(np.float32)
+
+
+def train_opq(X, m, h, niter, init="natural", V=False, *, seed=0):
+    """train_opq(X, m, h, niter, init) -> C, B, R, obj.  src/opq/OPQ.jl:21-101
+    C[i]: (subdim x h) codebooks of the rotated space, B: m x n Int16 1-based, R: d x d, obj: niter+1 errors."""
+    X = _f32(X)
+    d, n = X.shape
+    rng = np.random.default_rng(seed)
+    if init == "natural":
+        R = np.eye(d, dtype=np.float32)
+    elif init == "random":
+        R = np.linalg.svd(rng.standard_normal((d, d)))[0].astype(np.float32)
+    else:
+        raise ValueError("Intialization %s unknown" % init)
+    RX = R.T @ X
+    sd = _subdims(d, m)
+    C = [RX[sd[i]][:, rng.choice(n, h, replace=False)].copy() for i in range(m)]     # :46-50
+    B = np.zeros((m, n), dtype=np.int64)
+    CB = np.zeros_like(X)
+    for i in range(m):
+        B[i], _ = _assign(C[i], RX[sd[i]])
+        CB[sd[i]] = C[i][:, B[i]]
+    obj = np.zeros(niter + 1, dtype=np.float32)
+    for it in range(niter + 1):
+        obj[it] = float(((R @ CB - X) ** 2).sum()) / n
+        if V:
+            print("%3d %e" % (it, obj[it]))
+        R = _procrustes(X, CB)
+        RX = R.T @ X
+        for i in range(m):
+            C[i] = _centers(RX[sd[i]], B[i], h, rng, old=C[i])
+            B[i], _ = _assign(C[i], RX[sd[i]])
+            CB[sd[i]] = C[i][:, B[i]]
+    return C, (B + 1).astype(np.int16), R, obj
+
+
+# ---- ChainQ (src/chainq/chainq.jl, src/encodings/encode_chain.jl, src/codebook_update.jl:88-169) -------------------
+def get_cbdims_chain(d, m):
+    """Dimensions each codebook of a chain covers: consecutive codebooks overlap on one of the m-1 blocks.
+    src/codebook_update.jl:88-102.  Returns m 0-based slices."""
+    sub = splitarray(d, m - 1)
+    od = [slice(sub[0][0], sub[0][1])]
+    for i in range(1, m - 1):
+        od.append(slice(sub[i - 1][0], sub[i][1]))
+    od.append(slice(sub[-1][0], sub[-1][1]))
+    return od
+
+
+def update_codebooks_chain(X, B, h, V=False):
+    """Least-squares codebooks under the chain's dimension structure: for every dimension t only the codebooks that
+    cover t are fitted (LSQR on the corresponding columns of the one-hot code matrix).  src/codebook_update.jl:104-169"""
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.linalg import lsqr
+    X = _f32(X)
+    d, n = X.shape
+    B = np.asarray(B, dtype=np.int64)
+    m = B.shape[0]
+    od = get_cbdims_chain(d, m)
+    cols = (B - 1 + (np.arange(m) * h)[:, None]).T.reshape(-1)                     # sparsify_codes, src/utils.jl:50-69
+    S = csr_matrix((np.ones(n * m, dtype=np.float32), (np.repeat(np.arange(n), m), cols)), shape=(n, m * h)).tocsc()
+    K = np.zeros((d, m * h), dtype=np.float32)
+    tol = float(np.sqrt(np.finfo(np.float32).eps))
+    cache = {}
+    for t in range(d):
+        cbs = tuple(i for i in range(m) if od[i].start <= t < od[i].stop)
+        if cbs not in cache:
+            idx = np.concatenate([np.arange(i * h, (i + 1) * h) for i in cbs])
+            cache[cbs] = (idx, S[:, idx])
+        idx, St = cache[cbs]
+        K[t, idx] = lsqr(St, X[t].astype(np.float64), atol=tol, btol=tol, conlim=1e8)[0].astype(np.float32)
+    return [np.ascontiguousarray(K[:, i * h:(i + 1) * h]) for i in range(m)]
+
+
+def encoding_viterbi(X, C, V=False, *, block=256):
+    """Exact MAP codes of a chain (unaries + binaries between consecutive codebooks only) by dynamic programming.
+    src/encodings/encode_chain.jl:1-123; min / argmin take the lowest index on ties as the reference's scans do."""
+    X = _f32(X)
+    C = [_f32(c) for c in C]
+    d, n = X.shape
+    m, h = len(C), C[0].shape[1]
+    bins = [(2.0 * C[i].T @ C[i + 1]).astype(np.float32) for i in range(m - 1)]       # :103-106
+    sq = [np.einsum("ij,ij->j", c, c) for c in C]
+    B = np.zeros((m, n), dtype=np.int16)
+    for lo in range(0, n, block):
+        Xb = X[:, lo:lo + block]
+        nb = Xb.shape[1]
+        U = [(-2.0 * (C[i].T @ Xb) + sq[i][:, None]).T.astype(np.float32) for i in range(m)]      # (nb, h) each; utils.jl:94-122
+        back = np.zeros((m - 1, nb, h), dtype=np.int64)
+        acc = U[0]
+        for i in range(m - 1):                                                       # forward pass :37-68
+            cost = acc[:, :, None] + bins[i][None, :, :]                             # (nb, from k, to j)
+            back[i] = cost.argmin(axis=1)
+            acc = U[i + 1] + np.take_along_axis(cost, back[i][:, None, :], axis=1)[:, 0, :]
+        path = acc.argmin(axis=1)                                                    # :74
+        B[m - 1, lo:lo + nb] = path + 1
+        for i in range(m - 2, -1, -1):                                               # backward trace :77-80
+            path = back[i][np.arange(nb), path]
+            B[i, lo:lo + nb] = path + 1
+    return B
+
+
+def _qerror_full(X, B, C):
+    rec = np.zeros_like(X)
+    for i in range(len(C)):
+        rec += C[i][:, np.asarray(B[i], dtype=np.int64) - 1]
+    return float(((X - rec) ** 2).sum()) / X.shape[1]
+
+
+def train_chainq(X, m, h, R, B, C, niter, V=False):
+    """train_chainq(X, m, h, R, B, C, niter) -> C, B, R, obj.  src/chainq/chainq.jl:10-58
+    B: initial codes (e.g. OPQ's); the incoming C is only a placeholder, as in the reference (re-fitted at :27)."""
+    X = _f32(X)
+    R = _f32(R)
+    B = np.asarray(B, dtype=np.int16)
+    RX = R.T @ X
+    C = update_codebooks_chain(RX, B, h, V)                      # :27
+    B = encoding_viterbi(RX, C, V)                               # :31
+    obj = np.zeros(niter + 1, dtype=np.float32)
+    for it in range(niter + 1):
+        obj[it] = _qerror_full(RX, B, C)
+        if V:
+            print("%3d %e" % (it, obj[it]))
+        CB = np.zeros_like(X)
+        for i in range(m):
+            CB += C[i][:, B[i].astype(np.int64) - 1]
+        R = _procrustes(X, CB)                                   # :44-45
+        RX = R.T @ X
+        C = update_codebooks_chain(RX, B, h, V)
+        B = encoding_viterbi(RX, C, V)
+    return C, B, R, obj

@@ -1,0 +1,54 @@
+"""The reference's demo flow (demos/demo_lsq_gpu.jl:22-76) end to end on synthetic clustered data:
+OPQ init -> ChainQ init -> train_lsq (host LSQR + GPU ILS/ICM encoder) -> encode the base set on the GPU ->
+quantise the database norms -> ADC linear scan -> recall.  No dataset ships with the reference, so the
+checks are relative: every stage must not be worse than the one before it, and the search must find the true
+nearest neighbours far more often than chance."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+H = 256
+
+
+def clustered(d, n, k, seed, spread=0.35):
+    rng = np.random.default_rng(seed)
+    cen = rng.standard_normal((d, k)).astype(np.float32) * 3.0
+    a = rng.integers(k, size=n)
+    return (cen[:, a] + spread * rng.standard_normal((d, n))).astype(np.float32)
+
+
+def test_demo_flow_on_synthetic_data(lsq):
+    d, m, ntrain, nbase, nq, knn = 32, 4, 3000, 6000, 64, 50
+    allx = clustered(d, ntrain + nbase + nq, k=400, seed=11)
+    x_train, x_base, x_query = allx[:, :ntrain], allx[:, ntrain:ntrain + nbase], allx[:, ntrain + nbase:]
+
+    # === OPQ initialization === (demo_lsq_gpu.jl:22-26)
+    C, B, R, opq_err = lsq.train_opq(x_train, m, H, 3, "natural", seed=1)
+    # === ChainQ initialization === (:28-31)
+    C, B, R, chain_err = lsq.train_chainq(x_train, m, H, R, B, C, 2)
+    assert chain_err[-1] <= opq_err[-1] * 1.02
+    # === LSQ train === (:33-40)
+    ilsiter, icmiter, randord, npert = 4, 4, True, 2
+    C, B, cbnorms, B_norms, obj = lsq.train_lsq(x_train, m, H, R, B, C, 3, ilsiter, icmiter, randord, npert, seed=5)
+    assert obj[-1] <= obj[0] * 1.001 and obj[-1] <= chain_err[-1] * 1.02
+    assert len(C) == m and C[0].shape == (d, H) and cbnorms.shape[0] <= H
+
+    # === Encode the base set === (:42-55)
+    B_base = lsq.randinit(nbase, m, H, seed=3)
+    Bs, objs = lsq.encode_icm_cuda(x_base, B_base, C, [2, 8], icmiter, npert, randord, 2, False, seed=9)
+    assert objs[1] <= objs[0]                              # more ILS iterations never hurt (accept rule is monotone)
+    B_base = Bs[-1]
+    base_err = lsq.qerror(x_base, B_base, C)
+    assert np.isclose(base_err, objs[-1], rtol=1e-4)
+    assert base_err < 0.25 * float((x_base ** 2).sum() / nbase)
+
+    # === norms, search, recall === (:57-76)
+    dbnormsB = lsq.quantize_norms(B_base, C, cbnorms)
+    db_norms = np.asarray(cbnorms, dtype=np.float32)[dbnormsB.astype(np.int64) - 1]
+    dists, idx = lsq.linscan_lsq((B_base - 1).astype(np.uint8), x_query, C, db_norms, np.eye(d, dtype=np.float32), knn)
+    assert idx.shape == (knn, nq) and idx.min() >= 1 and idx.max() <= nbase
+    d2 = ((x_base[:, :, None] - x_query[:, None, :]) ** 2).sum(0)          # (nbase, nq) exact
+    gt = d2.argmin(0) + 1
+    rec = lsq.eval_recall(gt.astype(np.uint32), idx.astype(np.uint32), knn)
+    assert rec[knn - 1] >= 0.9 and rec[0] >= 100.0 / nbase     # 32-bit codes on tight clusters: recall@1 is low, chance is 1/6000
+    assert np.all(np.diff(rec) >= 0)
