@@ -196,6 +196,42 @@ def test_ties_pick_lowest_index(lsq, oracle):
     assert ((Bs[0][changed] - 1) % 2 == 0).all(), "a tie was resolved to the higher duplicate"
 
 
+@pytest.mark.parametrize("n", [300, 80_000])     # 300: every block is "light" (L2-gather path); 80 000: 313 vectors per block, LDS-staged path
+def test_nonfinite_inputs_follow_the_reference_scan(lsq, oracle, n):
+    """NaN / Inf in the data: the reference's argmin is a strict-'<' scan (encode_icm.jl:105-119), so a NaN candidate never
+    wins unless it sits at index 0, -0 == +0, and a NaN cost is never accepted (`<` is false).  Both node-update paths of the
+    walk kernel (packed LDS atomic keys / wave DPP argmin) and the cost kernel must reproduce the oracle bit for bit."""
+    d, m, seed = 16, 8, 91
+    X, K, B0 = make_problem(d, n, m, seed=seed, kind="gauss")
+    rng = np.random.default_rng(4)
+    bad = rng.choice(n, size=40, replace=False)
+    X[bad[:10], 0] = np.nan                              # whole unary rows NaN
+    X[bad[10:20], 3] = np.inf                            # +-Inf / NaN mix in the unaries
+    X[bad[20:30], 5] = -np.inf
+    X[bad[30:], :] = 0.0                                 # zero vectors: exact zeros and signed zeros in the sums
+    K = K.copy()
+    K[7] = 0.0
+    K[300] = -0.0
+    Bs_ref, objs_ref = oracle.encode_icm(X, B0, K, m, H, [1, 2], 3, 4, True, seed)
+    for schedule in (4, 3):
+        with lsq.Engine(0, schedule=schedule) as eng:
+            Bs, objs = eng.encode_icm(X, B0, K, m, [1, 2], 3, 4, True, seed=seed)
+        assert np.array_equal(Bs, Bs_ref), "schedule %d: %d codes differ" % (schedule, (Bs != Bs_ref).sum())
+        assert np.array_equal(np.isnan(objs), np.isnan(objs_ref))
+
+
+def test_staged_path_full_oracle_parity(lsq, oracle):
+    """A shape where every block holds more vectors than the light-block threshold (so the LDS-staged walk runs) and
+    several passes per block at a small chunk -- compared with the oracle on ALL vectors, not a sample."""
+    d, n, m, ils, J, npert, seed = 16, 150_000, 8, [2], 3, 4, 23
+    X, K, B0 = make_problem(d, n, m, seed=seed, kind="gauss")
+    Bs_ref, objs_ref = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, True, seed)
+    with lsq.Engine(0) as eng:
+        Bs, objs = eng.encode_icm(X, B0, K, m, ils, J, npert, True, seed=seed)
+    assert np.array_equal(Bs, Bs_ref), "%d codes differ" % (Bs != Bs_ref).sum()
+    assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0)
+
+
 def test_generators_match_oracle(engine, oracle):
     X = engine.synth_data_u8_dev(1234, 300, 128, global_offset=17).cpu().numpy()
     assert np.array_equal(X, oracle.synth_data_u8(1234, 300, 128, global_offset=17))

@@ -20,6 +20,8 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/write" -o bench -
 timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d "$OUT/tcc" -o bench --output-format csv -- $B --steps 1 --warmup 0 > "$OUT/tcc.log" 2>&1
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --kernel-trace -d "$OUT/sq" -o bench --output-format csv -- $B --steps 1 --warmup 0 > "$OUT/sq.log" 2>&1
 cd "$R"
+python tools/pmc_summary.py "$OUT" "$TAG"
+cp "$OUT/${TAG}_pmc_per_kernel.json" profiles/        # bench.py reads its `traffic` field from profiles/<PMC_FILE>: same build, same box
 timeout 300 python bench.py $* > "$OUT/bench_line.json" 2> "$OUT/bench.err"
 python tools/pmc_summary.py "$OUT" "$TAG"
 # keep the merge-back small: the raw per-dispatch csv files are large
