@@ -99,6 +99,22 @@ LSQ_API int lsq_get_timings(lsq_ctx *ctx, lsq_timings *out);
 LSQ_API int lsq_reset_timings(lsq_ctx *ctx);
 LSQ_API int lsq_synchronize(lsq_ctx *ctx);
 
+/* ---- single-process multi-GPU (the `ngpus` of SURVEY 8(b); what a Julia master process calls on a multi-GPU node) --------
+ * One context and one host thread per listed device; the n vectors are split with `splitarray` (src/utils.jl:152-177,
+ * the reference's own sharding of encode_icm.jl:165-173) and every shard is encoded with its global offset, so the result
+ * is bit-identical to the one-device call for any device list (RNG keyed by the global vector index).  No data-path
+ * collective: K is uploaded to every device, objective sums and counters are added on the host.  `devices` may repeat an
+ * ordinal (two shards time-share one GPU).  Options apply to every context.  One process per GPU with torch.distributed /
+ * RCCL (local-search-quantization_amd/distributed.py) is the other, multi-process way to use several GPUs. */
+typedef struct lsq_multi lsq_multi;
+LSQ_API int lsq_multi_create(lsq_multi **out, const int *devices, int ndev);
+LSQ_API int lsq_multi_destroy(lsq_multi *mg);
+LSQ_API int lsq_multi_set_option(lsq_multi *mg, const char *key, int64_t value);
+/* Same arguments, layouts and outputs as lsq_encode_icm (below), minus nsplits. */
+LSQ_API int lsq_multi_encode_icm(lsq_multi *mg, const float *RX, const int16_t *B, const float *K, int d, int64_t n, int m, int h,
+                                 const int64_t *ilsiters, int nr, int icmiter, int npert, int randord, uint64_t seed,
+                                 uint64_t global_offset, int verbose, int16_t *Bs, float *objs);
+
 /* ---- (1) the whole call ------------------------------------------------------------------
  * Replaces encode_icm_cuda(RX, B, C, ilsiters, icmiter, npert, randord, nsplits, V)
  *   -> (Bs, objs)      src/encodings/encode_icm_cuda.jl:253-296 (and _single, :22-234);

@@ -10,7 +10,7 @@ host-side mirror of the reference's operator interface for that path.
     Bs, objs = lsq.encode_icm_cuda(RX, B, C, [16], 4, 4, True, 2, False, seed=42)
 """
 from . import _lib  # noqa: F401
-from .engine import Engine, randinit as randinit_rows, node_order, splitarray as split_ranges, device_count  # noqa: F401
+from .engine import Engine, MultiEngine, randinit as randinit_rows, node_order, splitarray as split_ranges, device_count  # noqa: F401
 from .reference_api import (  # noqa: F401
     encode_icm_cuda, encoding_icm, encode_icm_fully, get_unaries, get_binaries, veccost, qerror,
     randinit, splitarray, default_engine, linscan_lsq, eval_recall, quantize_norms, reconstruct,
@@ -22,7 +22,7 @@ from .initializers import (  # noqa: F401
 from . import distributed  # noqa: F401
 
 __all__ = [
-    "Engine", "encode_icm_cuda", "encoding_icm", "encode_icm_fully", "get_unaries", "get_binaries",
+    "Engine", "MultiEngine", "encode_icm_cuda", "encoding_icm", "encode_icm_fully", "get_unaries", "get_binaries",
     "veccost", "qerror", "randinit", "splitarray", "node_order", "device_count", "distributed", "linscan_lsq", "eval_recall",
     "quantize_norms", "reconstruct", "update_codebooks", "train_lsq", "train_pq", "quantize_pq", "train_opq", "quantize_opq",
     "train_chainq", "encoding_viterbi", "update_codebooks_chain", "get_cbdims_chain", "fvecs_read", "ivecs_read", "bvecs_read",

@@ -42,6 +42,10 @@ SIGNATURES = {
     "lsq_get_timings": (_i, [_vp, C.POINTER(Timings)]),
     "lsq_reset_timings": (_i, [_vp]),
     "lsq_synchronize": (_i, [_vp]),
+    "lsq_multi_create": (_i, [C.POINTER(_vp), _vp, _i]),
+    "lsq_multi_destroy": (_i, [_vp]),
+    "lsq_multi_set_option": (_i, [_vp, C.c_char_p, _i64]),
+    "lsq_multi_encode_icm": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _i, _i, _i, _i, _u64, _u64, _i, _vp, _vp]),
     "lsq_encode_icm": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _i, _i, _i, _i, _i, _u64, _u64, _i, _vp, _vp]),
     "lsq_encode_icm_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _i, _i, _i, _i, _u64, _u64, _vp, _vp, _vp]),
     "lsq_encoding_icm": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _u64, _u32, _u64, _vp]),

@@ -7,6 +7,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "lsq_internal.h"
@@ -145,7 +147,7 @@ extern "C" int lsq_destroy(lsq_ctx *c) {
     for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : c->pool) (void)hipEventDestroy(e);
     DevBuf *bufs[] = {&c->sci, &c->T, &c->Ts, &c->U, &c->part, &c->vCur, &c->vNew, &c->active, &c->recCur, &c->recNew, &c->prev, &c->counters, &c->obj, &c->bad,
-                      &c->sX, &c->sK, &c->sB16, &c->sOut16, &c->sTight, &c->sF32};
+                      &c->sX, &c->sX2, &c->sK, &c->sB16, &c->sOut16, &c->sTight, &c->sF32};
     for (DevBuf *b : bufs) b->release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -427,13 +429,18 @@ extern "C" int lsq_encode_icm_dev(lsq_ctx *c, const float *dX, const uint8_t *dB
 }
 
 // host-buffer core shared by lsq_encode_icm / lsq_encoding_icm
+// `place` (multi-GPU shards): the shard's rows go to rows [row0, row0 + n) of snapshots that are ntot rows long, and the
+// objective sums / counters are handed back raw so that the caller can combine the shards.
+struct HostPlacement { int64_t ntot, row0; double *sums; int64_t *stats; };
+
 static int encode_host(lsq_ctx *c, const char *fn, const float *X, const int16_t *B, const float *K, int d, int64_t n, int m, int h,
                        const int64_t *ilsiters, int nr, int icmiter, int npert, int randord, uint64_t seed, uint32_t it0,
-                       uint64_t global_offset, int verbose, int16_t *Bs, float *objs) {
+                       uint64_t global_offset, int verbose, int16_t *Bs, float *objs, const HostPlacement *place = nullptr) {
     LSQ_TRY(use_device(c));
     int64_t I = 0;
     LSQ_TRY(validate_encode(fn, d, n, m, h, ilsiters, nr, icmiter, npert, &I));
-    if (!K || !objs || (n > 0 && (!X || !B || !Bs))) { lsq_set_error("%s: null pointer", fn); return LSQ_EINVAL; }
+    if (!K || (!objs && !place) || (n > 0 && (!X || !B || !Bs))) { lsq_set_error("%s: null pointer", fn); return LSQ_EINVAL; }
+    const int64_t ntot = place ? place->ntot : n, row0 = place ? place->row0 : 0;
     LSQ_TRY(begin_call(c, I, nr));
     const size_t kbytes = sizeof(float) * (size_t)m * LSQ_H * d;
     LSQ_TRY(c->sK.ensure(kbytes));
@@ -474,7 +481,7 @@ static int encode_host(lsq_ctx *c, const char *fn, const float *X, const int16_t
             LSQ_HIP(hipEventRecord(c->copy_done, c->copy_stream));
         }
         for (int r = 0; r < nr; ++r)
-            LSQ_HIP(hipMemcpyAsync(Bs + ((int64_t)r * n + off) * m, c->sOut16.as<int16_t>() + (int64_t)r * cn * m,
+            LSQ_HIP(hipMemcpyAsync(Bs + ((int64_t)r * ntot + row0 + off) * m, c->sOut16.as<int16_t>() + (int64_t)r * cn * m,
                                    sizeof(int16_t) * (size_t)cn * m, hipMemcpyDeviceToHost, c->stream));
         LSQ_HIP(hipStreamSynchronize(c->stream));      // staging buffers are reused by the next chunk
     }
@@ -484,6 +491,11 @@ static int encode_host(lsq_ctx *c, const char *fn, const float *X, const int16_t
     LSQ_HIP(hipMemcpyAsync(&bad, c->bad.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     LSQ_TRY(finish_call(c, I, nr, sums.data(), stats.data()));
     if (bad) { lsq_set_error("%s: input codes must lie in 1..%d", fn, h); return LSQ_ECODE; }
+    if (place) {
+        for (int r = 0; r < nr; ++r) place->sums[r] = sums[(size_t)r];
+        if (place->stats) for (size_t q = 0; q < stats.size(); ++q) place->stats[q] = stats[q];
+        return LSQ_OK;
+    }
     for (int r = 0; r < nr; ++r) objs[r] = (float)(n > 0 ? sums[(size_t)r] / (double)n : 0.0);
     if (verbose)
         for (int64_t it = 0; it < I; ++it)      // the two counters the reference prints (encode_icm_cuda.jl:199-204)
@@ -497,6 +509,83 @@ extern "C" int lsq_encode_icm(lsq_ctx *c, const float *RX, const int16_t *B, con
                               uint64_t global_offset, int verbose, int16_t *Bs, float *objs) {
     if (nsplits < 1) { lsq_set_error("lsq_encode_icm: nsplits must be >= 1"); return LSQ_EINVAL; }
     return encode_host(c, "lsq_encode_icm", RX, B, K, d, n, m, h, ilsiters, nr, icmiter, npert, randord, seed, 0u, global_offset, verbose, Bs, objs);
+}
+
+// ---- single-process multi-GPU: one context + one host thread per device, splitarray shards (utils.jl:152-177) -------
+struct lsq_multi { std::vector<lsq_ctx *> ctx; };
+
+extern "C" int lsq_multi_create(lsq_multi **out, const int *devices, int ndev) {
+    if (!out || !devices || ndev < 1) { lsq_set_error("lsq_multi_create: need an output pointer and at least one device"); return LSQ_EINVAL; }
+    *out = nullptr;
+    lsq_multi *mg = new lsq_multi();
+    for (int p = 0; p < ndev; ++p) {
+        lsq_ctx *c = nullptr;
+        const int rc = lsq_create(&c, devices[p]);
+        if (rc != LSQ_OK) {
+            for (lsq_ctx *q : mg->ctx) (void)lsq_destroy(q);
+            delete mg;
+            return rc;
+        }
+        mg->ctx.push_back(c);
+    }
+    *out = mg;
+    return LSQ_OK;
+}
+
+extern "C" int lsq_multi_destroy(lsq_multi *mg) {
+    if (!mg) return LSQ_OK;
+    for (lsq_ctx *q : mg->ctx) (void)lsq_destroy(q);
+    delete mg;
+    return LSQ_OK;
+}
+
+extern "C" int lsq_multi_set_option(lsq_multi *mg, const char *key, int64_t value) {
+    if (!mg) { lsq_set_error("null lsq_multi"); return LSQ_EINVAL; }
+    for (lsq_ctx *q : mg->ctx) LSQ_TRY(lsq_set_option(q, key, value));
+    return LSQ_OK;
+}
+
+extern "C" int lsq_multi_encode_icm(lsq_multi *mg, const float *RX, const int16_t *B, const float *K, int d, int64_t n, int m, int h,
+                                    const int64_t *ilsiters, int nr, int icmiter, int npert, int randord, uint64_t seed,
+                                    uint64_t global_offset, int verbose, int16_t *Bs, float *objs) {
+    if (!mg || mg->ctx.empty()) { lsq_set_error("null lsq_multi"); return LSQ_EINVAL; }
+    int64_t I = 0;
+    LSQ_TRY(validate_encode("lsq_multi_encode_icm", d, n, m, h, ilsiters, nr, icmiter, npert, &I));
+    if (!K || !objs || (n > 0 && (!RX || !B || !Bs))) { lsq_set_error("lsq_multi_encode_icm: null pointer"); return LSQ_EINVAL; }
+    const int G = (int)mg->ctx.size();
+    std::vector<std::vector<double>> sums((size_t)G, std::vector<double>((size_t)nr, 0.0));
+    std::vector<std::vector<int64_t>> stats((size_t)G, std::vector<int64_t>(2 * (size_t)I, 0));
+    std::vector<int> rc((size_t)G, LSQ_OK);
+    std::vector<std::string> err((size_t)G);
+    std::vector<std::thread> th;
+    for (int p = 0; p < G; ++p) {
+        th.emplace_back([&, p]() {
+            int64_t s0 = 0, len = 0;
+            rc[(size_t)p] = lsq_splitarray(n, G, p, &s0, &len);        // contiguous shards, the first n mod G one longer
+            if (rc[(size_t)p] == LSQ_OK && len > 0) {
+                const HostPlacement place{n, s0, sums[(size_t)p].data(), stats[(size_t)p].data()};
+                rc[(size_t)p] = encode_host(mg->ctx[(size_t)p], "lsq_multi_encode_icm", RX + s0 * d, B + s0 * m, K, d, len, m, h, ilsiters, nr,
+                                            icmiter, npert, randord, seed, 0u, global_offset + (uint64_t)s0, 0, Bs, nullptr, &place);
+            }
+            if (rc[(size_t)p] != LSQ_OK) err[(size_t)p] = lsq_last_error();      // the error string is thread-local
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int p = 0; p < G; ++p)
+        if (rc[(size_t)p] != LSQ_OK) { lsq_set_error("device shard %d: %s", p, err[(size_t)p].c_str()); return rc[(size_t)p]; }
+    for (int r = 0; r < nr; ++r) {
+        double tot = 0.0;
+        for (int p = 0; p < G; ++p) tot += sums[(size_t)p][(size_t)r];
+        objs[r] = (float)(n > 0 ? tot / (double)n : 0.0);
+    }
+    if (verbose)
+        for (int64_t it = 0; it < I; ++it) {
+            int64_t eq = 0, better = 0;
+            for (int p = 0; p < G; ++p) { eq += stats[(size_t)p][2 * (size_t)it]; better += stats[(size_t)p][2 * (size_t)it + 1]; }
+            printf(" ILS iteration %lld/%lld done. %5.2f%% new codes are equal. %5.2f%% new codes are better.\n", (long long)(it + 1),
+                   (long long)I, n ? 100.0 * (double)eq / (double)n : 0.0, n ? 100.0 * (double)better / (double)n : 0.0);
+        }
+    return LSQ_OK;
 }
 
 extern "C" int lsq_encoding_icm(lsq_ctx *c, const float *X, const int16_t *oldB, const float *K, int d, int64_t n, int m, int h,

@@ -222,6 +222,58 @@ def node_order(seed, it, m, randord=True):
     return o
 
 
+class MultiEngine:
+    """Single-process multi-GPU handle (lsq_multi_*): one context + host thread per listed device, `splitarray` shards,
+    results identical to the one-device call.  `encode_icm` has Engine.encode_icm's signature, so the reference-shaped
+    functions accept it as `engine=`:  encode_icm_cuda(RX, B, C, ..., engine=MultiEngine([0, 1, 2, 3]))."""
+
+    def __init__(self, devices, **options):
+        self._L = _lib.load()
+        devs = np.ascontiguousarray(list(devices), dtype=np.int32)
+        h = C.c_void_p()
+        _lib.check(self._L.lsq_multi_create(C.byref(h), devs.ctypes.data, int(devs.shape[0])))
+        self._h = h
+        self.devices = [int(x) for x in devs]
+        for k, v in options.items():
+            self.set_option(k, v)
+
+    def set_option(self, key, value):
+        _lib.check(self._L.lsq_multi_set_option(self._h, key.encode(), int(value)))
+
+    def encode_icm(self, X, B, K, m, ilsiters, icmiter, npert, randord, seed=0, nsplits=1, global_offset=0,
+                   verbose=False, h=H):
+        """-> Bs (nr, n, m) int16 1-based, objs (nr,) float32   [lsq_multi_encode_icm]"""
+        X, K, B = _np(X, np.float32), _np(K, np.float32), _np(B, np.int16)
+        n, d = X.shape
+        if B.shape != (n, m) or K.shape != (m * h, d):
+            raise ValueError("shape mismatch: X %s B %s K %s m=%d h=%d" % (X.shape, B.shape, K.shape, m, h))
+        ils = _np(ilsiters, np.int64).reshape(-1)
+        nr = ils.shape[0]
+        Bs = np.empty((nr, n, m), dtype=np.int16)
+        objs = np.zeros(nr, dtype=np.float32)
+        _lib.check(self._L.lsq_multi_encode_icm(self._h, X.ctypes.data, B.ctypes.data, K.ctypes.data, d, n, m, h,
+                                                ils.ctypes.data, nr, int(icmiter), int(npert), int(bool(randord)),
+                                                int(seed), int(global_offset), int(bool(verbose)), Bs.ctypes.data, objs.ctypes.data))
+        return Bs, objs
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            self._L.lsq_multi_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def splitarray(n, nparts):
     """utils.jl:152-177 -> list of (start, stop) 0-based half-open ranges."""
     L = _lib.load()

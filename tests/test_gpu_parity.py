@@ -352,3 +352,31 @@ def test_plain_c_consumer_matches_oracle(oracle, tmp_path):
     Bs_ref, objs_ref = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, True, seed)
     assert np.array_equal(Bs, Bs_ref)
     assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0)
+
+
+def test_single_process_multi_gpu_handle(lsq, oracle):
+    """lsq_multi_*: one context + host thread per listed device, `splitarray` shards with global offsets.  With the device
+    list [0, 0, 0] three shards time-share the one GPU of the test box; the result must equal the one-device call and the
+    oracle bit for bit (P8), through the reference-shaped entry point as well; errors of a shard must surface."""
+    d, n, m, ils, J, npert, seed = 32, 1003, 8, [1, 3], 3, 4, 17
+    X, K, B0 = make_problem(d, n, m, seed=seed)
+    Bs_ref, objs_ref = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, True, seed)
+    for devices in ([0], [0, 0, 0]):
+        with lsq.MultiEngine(devices) as mg:
+            Bs, objs = mg.encode_icm(X, B0, K, m, ils, J, npert, True, seed=seed)
+            assert np.array_equal(Bs, Bs_ref), "%r: %d codes differ" % (devices, (Bs != Bs_ref).sum())
+            assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0)
+            C = [np.ascontiguousarray(K[j * H:(j + 1) * H].T) for j in range(m)]
+            Bj, oj = lsq.encode_icm_cuda(np.asfortranarray(X.T), np.asfortranarray(B0.T), C, ils, J, npert, True, 2, False, seed=seed, engine=mg)
+            assert np.array_equal(np.stack([b.T for b in Bj]), Bs_ref)
+            bad = B0.copy()
+            bad[n - 1, 0] = 300                                         # lands in the last shard
+            with pytest.raises(lsq._lib.LsqError, match="shard 2|codes must lie" if len(devices) == 3 else "codes must lie"):
+                mg.encode_icm(X, bad, K, m, ils, J, npert, True, seed=seed)
+    with pytest.raises(lsq._lib.LsqError):
+        lsq.MultiEngine([99])
+    # fewer vectors than devices: empty shards are fine
+    with lsq.MultiEngine([0, 0, 0, 0]) as mg:
+        Bs, objs = mg.encode_icm(X[:2], B0[:2], K, m, [1], J, npert, True, seed=seed)
+        ref, _ = oracle.encode_icm(X[:2], B0[:2], K, m, H, [1], J, npert, True, seed)
+        assert np.array_equal(Bs, ref)
