@@ -92,6 +92,8 @@ LSQ_API int lsq_set_stream(lsq_ctx *ctx, void *hip_stream);
  *        2 same slices, one slice per block, partial minima combined by a second kernel;
  *        0 one launch per node update, table columns gathered through L2;
  *        1 fused sweeps, unaries register-resident;
+ *   "light" (schedules 3 and 4, default 256): a block with at most this many active vectors gathers its table columns
+ *        straight from L2 (one wave per vector) instead of staging slices through LDS; 0 = always stage.  Same codes.
  *   "skip" (0/1, default 1; schedules 3 and 4): a node whose conditioning codes did not change since it was
  *        last minimised is not recomputed (exact memoisation -- same codes, fewer bytes). */
 LSQ_API int lsq_set_option(lsq_ctx *ctx, const char *key, int64_t value);

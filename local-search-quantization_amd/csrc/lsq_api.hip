@@ -63,6 +63,7 @@ struct lsq_ctx {
                              // 4: LDS-walk, one launch per ILS iteration (default)
     int lane = 0;            // schedule 3, m <= 8: experimental one-lane-per-vector kernel (measured 2.5x slower: VGPR spills)
     int ablation = 0;        // timing-only kernel ablations (results are garbage when != 0)
+    int light = -1;          // schedules 3/4: light-block threshold (-1 = default)
     int skip = 1;            // schedule 3: skip node updates whose inputs did not change (exact memoisation)
     // workspace
     DevBuf sci, T, Ts, U, part, vCur, vNew, active, recCur, recNew, prev, counters, obj, bad;
@@ -172,6 +173,7 @@ extern "C" int lsq_set_option(lsq_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "skip")) c->skip = value != 0;
     else if (!strcmp(key, "lane")) c->lane = value != 0;
     else if (!strcmp(key, "ablation")) c->ablation = (int)value;
+    else if (!strcmp(key, "light")) c->light = (int)value;
     else if (!strcmp(key, "schedule")) {
         if (value < 0 || value > 4) { lsq_set_error("schedule must be 0..4"); return LSQ_EINVAL; }
         c->schedule = (int)value;
@@ -284,7 +286,7 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t c
         for (int sw = 0; sw < nsweeps; ++sw)
             for (int q = 0; q < m; ++q) seq[(size_t)sw * m + q] = order[q];
         LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>(), c->Ts.as<float>(), c->T.as<float>(), rec, valid, cn, m, seq.data(), (int)seq.size(), c->skip,
-                                    c->active.as<unsigned long long>(), c->ablation));
+                                    c->active.as<unsigned long long>(), c->ablation, c->light));
         c->icm_launches += ((int64_t)seq.size() + 63) / 64;
     } else if (c->schedule >= 3) {
         for (int sw = 0; sw < nsweeps; ++sw)
@@ -295,7 +297,7 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t c
                                                 c->active.as<unsigned long long>(), c->ablation));
                 else
                     LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>(), c->Ts.as<float>(), c->T.as<float>(), rec, valid, cn, m, &order[q], 1, c->skip,
-                                                c->active.as<unsigned long long>(), c->ablation));
+                                                c->active.as<unsigned long long>(), c->ablation, c->light));
             }
         c->icm_launches += (int64_t)nsweeps * m;
     } else if (c->schedule == 2) {

@@ -937,7 +937,7 @@ static int launch_slice_t(hipStream_t s, const float *Usj, const float *Tj, uint
 
 template <int M, int SL, int ABL = 0, int DEPTH = 2, int NT = 1024>
 static int launch_walk_t(hipStream_t s, const float *U, const float *Ts, const float *T, uint8_t *rec, unsigned short *valid, int64_t n,
-                         const WalkNodes &nodes, int use_skip, unsigned long long *active_total) {
+                         const WalkNodes &nodes, int use_skip, unsigned long long *active_total, int light) {
     constexpr int TAB = (M - 1) * LSQ_H * (SL / 4);
     constexpr int PP = LSQ_WALK_PP(M, SL);
     constexpr int LDS_BYTES = TAB * 16 + PP * 8 + PP * 2;                // slice table + packed running best + active list
@@ -955,8 +955,9 @@ static int launch_walk_t(hipStream_t s, const float *U, const float *Ts, const f
     if (per_pass < 1) per_pass = 1;
     const int64_t npass = (n + per_pass - 1) / per_pass;
     const unsigned grid = (unsigned)(npass < 256 ? npass : 256);
-    static int direct_max = -1;          // blocks with at most this many active vectors gather from L2 instead of staging (tuning knob)
-    if (direct_max < 0) { const char *e = getenv("LSQ_WALK_DIRECT"); direct_max = e ? atoi(e) : 256; }
+    static int direct_def = -1;          // blocks with at most this many active vectors gather from L2 instead of staging (option "light")
+    if (direct_def < 0) { const char *e = getenv("LSQ_WALK_DIRECT"); direct_def = e ? atoi(e) : 256; }
+    const int direct_max = light >= 0 ? light : direct_def;
     hipLaunchKernelGGL((icm_walk_kernel<M, SL, ABL, DEPTH, NT>), dim3(grid), dim3(NT), LDS_BYTES, s, U, Ts, T, rec, valid, n, nodes, (int)per_pass,
                        (use_skip && valid) ? 1 : 0, (T && ABL == 0) ? direct_max : 0, active_total);
     LSQ_HIP(hipGetLastError());
@@ -971,7 +972,7 @@ int lsq_walk_slice_width(int m) {
 
 // `order[nnodes]`: the node updates to run back to back inside the launch (1 = one node; icmiter*m = a whole ILS iteration)
 int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const float *T, uint8_t *rec, unsigned short *valid, int64_t n, int m,
-                        const int32_t *order, int nnodes, int use_skip, unsigned long long *active_total, int ablation) {
+                        const int32_t *order, int nnodes, int use_skip, unsigned long long *active_total, int ablation, int light) {
     if (n <= 0 || nnodes <= 0) return LSQ_OK;
     if (m < 1 || m > LSQ_MAX_M) { lsq_set_error("m = %d out of range 1..16", m); return LSQ_EINVAL; }
     static int big_nt = -1;              // block size for m >= 14 (tuning knob LSQ_WALK_BIG_NT=1024 restores the old shape)
@@ -987,25 +988,25 @@ int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const fl
         // m >= 14: up to 15 table reads in flight + 8 staged table registers per thread do not fit 128 VGPRs (measured at
         // m = 16: 67..100 spilled registers, 1.5..2.5x slower) -> 512-thread blocks (256 VGPRs per wave), more U items in
         // flight instead.  m = 9..13 fit (<= 4 spills) and are 3-5 % faster with 1024 threads (measured for every m).
-#define LSQ_WALK_CASE_MID(MM) case MM: LSQ_TRY((launch_walk_t<MM, 8, 0, 2>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total))); break;
+#define LSQ_WALK_CASE_MID(MM) case MM: LSQ_TRY((launch_walk_t<MM, 8, 0, 2>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light))); break;
 #define LSQ_WALK_CASE_BIG(MM) case MM: \
-            if (big_nt == 512) LSQ_TRY((launch_walk_t<MM, 8, 0, 4, 512>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total))); \
-            else LSQ_TRY((launch_walk_t<MM, 8>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total))); \
+            if (big_nt == 512) LSQ_TRY((launch_walk_t<MM, 8, 0, 4, 512>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light))); \
+            else LSQ_TRY((launch_walk_t<MM, 8>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light))); \
             break;
-#define LSQ_WALK_CASE(MM, SLL) case MM: LSQ_TRY((launch_walk_t<MM, SLL, 0, 3>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total))); break;
+#define LSQ_WALK_CASE(MM, SLL) case MM: LSQ_TRY((launch_walk_t<MM, SLL, 0, 3>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light))); break;
         if (m <= 8 && lsq_walk_slice_width(m) == 8) {
             switch (m) {
                 LSQ_WALK_CASE(1, 8) LSQ_WALK_CASE(2, 8) LSQ_WALK_CASE(3, 8) LSQ_WALK_CASE(4, 8)
                 LSQ_WALK_CASE(5, 8) LSQ_WALK_CASE(6, 8) LSQ_WALK_CASE(7, 8) LSQ_WALK_CASE(8, 8)
             }
         } else if (m == 8 && ablation == 1) {
-            LSQ_TRY((launch_walk_t<8, 16, 1>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total)));
+            LSQ_TRY((launch_walk_t<8, 16, 1>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light)));
         } else if (m == 8 && ablation == 2) {
-            LSQ_TRY((launch_walk_t<8, 16, 2>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total)));
+            LSQ_TRY((launch_walk_t<8, 16, 2>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light)));
         } else if (m == 8 && ablation == 3) {
-            LSQ_TRY((launch_walk_t<8, 16, 3>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total)));
+            LSQ_TRY((launch_walk_t<8, 16, 3>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light)));
         } else if (m == 8 && ablation == 4) {
-            LSQ_TRY((launch_walk_t<8, 16, 4>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total)));
+            LSQ_TRY((launch_walk_t<8, 16, 4>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light)));
 
         } else {
             switch (m) {

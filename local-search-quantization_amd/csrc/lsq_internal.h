@@ -107,7 +107,8 @@ int lsq_launch_tables_to_slices(hipStream_t s, const float *T, float *Ts, int m,
 // U is the slice-major unary buffer of ALL nodes; T (optional) the row-major tables for light blocks' L2 gathers; order[nnodes] = node updates run back to back inside the launch
 // (a block owns its vectors for the whole launch): 1 entry = one node update, icmiter*m entries = a whole ILS iteration.
 int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const float *T, uint8_t *rec, unsigned short *valid, int64_t n, int m,
-                        const int32_t *order, int nnodes, int use_skip, unsigned long long *active_total, int ablation);
+                        const int32_t *order, int nnodes, int use_skip, unsigned long long *active_total, int ablation, int light);
+// light: blocks with <= light active vectors gather table columns from L2 instead of staging slices (-1 = default 256)
 // one-lane-per-vector variant of the LDS-walk kernel (m <= 8, slice width 16): same contract as lsq_launch_icm_walk
 int lsq_launch_icm_lane(hipStream_t s, const float *Usj, const float *Ts, uint8_t *rec, unsigned short *valid, int64_t n, int m, int j,
                         int use_skip, unsigned long long *active_total, int ablation);

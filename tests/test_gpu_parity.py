@@ -291,6 +291,16 @@ def test_full_size_properties(lsq):
         b, sb, _ = eng.encode_icm_dev(dX[h1:].contiguous(), dB0[h1:].contiguous(), dK, m, ils, J, npert, True, seed=seed, global_offset=h1)
         assert torch.equal(torch.cat([a, b], dim=1), dBs)                      # P8
         assert np.allclose(sa + sb, sums, rtol=1e-9)
+        # the two node-update paths of the walk kernel at full size: every block staged (light = 0) vs every block gathering
+        # from L2 (light = 4096, on a quarter of the data to keep the run short), with and without the exact skip
+        q = n // 4
+        ref_q, sums_q, _ = eng.encode_icm_dev(dX[:q].contiguous(), dB0[:q].contiguous(), dK, m, ils, J, npert, True, seed=seed)
+        for light, skip in ((0, 1), (4096, 1), (4096, 0)):
+            with lsq.Engine(0, skip=skip) as e3:
+                e3.set_option("light", light)
+                got_q, s_q, _ = e3.encode_icm_dev(dX[:q].contiguous(), dB0[:q].contiguous(), dK, m, ils, J, npert, True, seed=seed)
+                assert torch.equal(got_q, ref_q), "light=%d skip=%d" % (light, skip)
+                assert np.allclose(s_q, sums_q, rtol=1e-9)
 
 
 @pytest.mark.parametrize("d,m", [(960, 8), (128, 16)])
