@@ -1,0 +1,77 @@
+// tools/ubench_lds.hip -- which LDS row layout serves 16 random 64-byte rows per ds_read_b128 with the fewest bank-conflict cycles?
+// One 1024-thread block per CU (like icm_walk_kernel), 7 dependent-free ds_read_b128 per iteration, addresses from random codes.
+// hipcc --offload-arch=gfx950 -O3 tools/ubench_lds.hip -o tools/bin/ubench_lds
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+template <int PAT>
+__device__ inline unsigned addr_of(unsigned code, unsigned q, unsigned lane) {
+    switch (PAT) {
+        case 0: return code * 64u + q * 16u;                                   // current: 64-byte rows
+        case 1: return code * 80u + q * 16u;                                   // rows padded to 80 bytes
+        case 2: return code * 96u + q * 16u;                                   // padded to 96
+        case 3: return code * 64u + ((q ^ ((code >> 2) & 3u)) * 16u);          // quads permuted by code bits
+        case 4: return code * 32u + (q & 1u) * 16u + (q >> 1) * (8192u + 64u); // two half planes, second skewed by 64 bytes
+        case 5: return lane * 16u;                                             // conflict-free reference
+        case 6: return (code & ~15u) * 64u + q * 16u;                          // few distinct rows (broadcast-heavy)
+        case 7: return code * 16u + q * (4096u + 64u);                         // four quad planes, skewed by 64 bytes each
+        default: return 0;
+    }
+}
+
+template <int PAT>
+__global__ __launch_bounds__(1024) void k(const unsigned char *codes, float *out, int iters) {
+    extern __shared__ f32x4 lds[];
+    for (int e = threadIdx.x; e < 7 * 2048; e += 1024) lds[e] = (f32x4){(float)e, 1.f, 2.f, 3.f};
+    __syncthreads();
+    const unsigned lane = threadIdx.x & 63, v = lane >> 2, q = lane & 3;
+    const unsigned char *cp = codes + ((size_t)blockIdx.x * 1024 + (threadIdx.x & ~63u) + v) * 8;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    unsigned c[7];
+    for (int t = 0; t < 7; ++t) c[t] = cp[t];
+    const char *base = reinterpret_cast<const char *>(lds);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            const unsigned a = addr_of<PAT>((c[t] + (unsigned)it * 37u) & 255u, q, lane) + (unsigned)t * 22528u;   // 7 tables of 22 KiB
+            acc = acc + *reinterpret_cast<const f32x4 *>(base + a);
+        }
+    }
+    out[(size_t)blockIdx.x * 1024 + threadIdx.x] = acc.x + acc.y + acc.z + acc.w;
+}
+
+template <int PAT>
+static void run(const unsigned char *dc, float *dout, const char *name) {
+    const int iters = 4000, lds_bytes = 160 * 1024 - 512;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k<PAT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    hipLaunchKernelGGL(k<PAT>, dim3(256), dim3(1024), lds_bytes, 0, dc, dout, 10);
+    CK(hipEventRecord(a));
+    hipLaunchKernelGGL(k<PAT>, dim3(256), dim3(1024), lds_bytes, 0, dc, dout, iters);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    const double reads = 256.0 * 16 * iters * 7;             // wave-level ds_read_b128 per launch
+    printf("%-44s %8.3f ms  %6.2f ns per wave read per CU  %7.1f TB/s aggregate\n", name, ms, ms * 1e6 / (16.0 * iters * 7), reads * 1024 / (ms * 1e-3) / 1e12);
+}
+
+int main() {
+    std::vector<unsigned char> h(256 * 1024 * 8);
+    srand(1);
+    for (auto &x : h) x = (unsigned char)(rand() & 255);
+    unsigned char *dc; float *dout;
+    CK(hipMalloc(&dc, h.size())); CK(hipMalloc(&dout, 256 * 1024 * 4));
+    CK(hipMemcpy(dc, h.data(), h.size(), hipMemcpyHostToDevice));
+    run<5>(dc, dout, "linear, conflict-free");
+    run<0>(dc, dout, "64-byte rows (current)");
+    run<1>(dc, dout, "rows padded to 80 bytes");
+    run<2>(dc, dout, "rows padded to 96 bytes");
+    run<3>(dc, dout, "64-byte rows, quads permuted by code");
+    run<4>(dc, dout, "two 32-byte half planes, skewed");
+    run<7>(dc, dout, "four 16-byte quad planes, skewed");
+    run<6>(dc, dout, "16 distinct rows only (broadcast-heavy)");
+    return 0;
+}
