@@ -458,13 +458,15 @@ __global__ __launch_bounds__(NT) void icm_walk_kernel(const float *__restrict__ 
         // kernel is instruction-issue bound (ablations in DESIGN.md), every slot counts.
         const int ipw = (wave * VPW < nact) ? (nact - wave * VPW + step - 1) / step : 0;   // iterations per slice, this wave
         int ls = 0, lit = 0;                                   // (slice, iteration) of the next load to issue
+        const bool dense = (nact == cnt);                      // block-uniform
         auto load_next = [&](Item &it) {
             // always in bounds (indices clamped): no exec-mask juggling; results of clamped lanes are discarded
             int ci = wave * VPW + lit * step + v;
             ci = ci < nact ? ci : nact - 1;
             const int lsc = ls < NS ? ls : NS - 1;
             // wave-uniform 64-bit bases (SGPRs) + 32-bit lane offsets: one VALU instruction per address instead of a 64-bit chain
-            const uint32_t li = list[ci];
+            uint32_t li = (uint32_t)ci;                        // dense block (every vector active): the list is the identity,
+            if (!dense) li = list[ci];                         // skip the LDS round trip in front of the load addresses
             const char *ub = reinterpret_cast<const char *>(Usj + ((int64_t)lsc * n + lo) * SL);
             const char *rb = reinterpret_cast<const char *>(rec + lo * CS);
             const uint32_t uo = li * (uint32_t)(SL * 4) + (uint32_t)q * 16u;
