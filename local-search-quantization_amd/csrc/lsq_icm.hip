@@ -508,11 +508,16 @@ __global__ __launch_bounds__(NT) void icm_walk_kernel(const float *__restrict__ 
             li += 4u * q + (uint32_t)(SL * slice);
             const uint32_t bits = __float_as_uint(lm + 0.0f);                  // -0 -> +0: they compare equal in the reference
             uint32_t ord = bits ^ ((uint32_t)((int32_t)bits >> 31) | 0x80000000u);   // monotone float -> uint
+            // only the lane(s) holding the minimum of the vector's LPV lanes post it (DPP mins within the quad): 4x fewer LDS
+            // atomics and no same-address serialisation (15 % of the LDS cycles); equal minima all post, the packed key orders them
+            float vm = lm;
+            if (LPV >= 2) vm = fminf(vm, dpp_self<DPP_XOR1, 0xf>(vm));
+            if (LPV >= 4) vm = fminf(vm, dpp_self<DPP_XOR2, 0xf>(vm));
+            bool post = (lm == vm);                                            // false for a NaN lane: NaN never wins ...
             if (__builtin_expect(__ballot((lm != lm) | (s.x != s.x)) != 0ull, 0)) {       // wave-uniform, rare: a NaN is present
-                if (lm != lm) ord = 0xffffffffu;                               // all four NaN: never wins
-                if ((slice == 0) & (q == 0) & (s.x != s.x)) { ord = 0u; li = 0u; }   // s[0] NaN: the strict-< scan keeps index 0
+                if ((slice == 0) & (q == 0) & (s.x != s.x)) { ord = 0u; li = 0u; post = true; }   // ... except s[0]: the strict-< scan keeps index 0
             }
-            if (c0 + v < nact) atomicMin(&best64[c0 + v], ((unsigned long long)ord << 32) | li);
+            if ((c0 + v < nact) & post) atomicMin(&best64[c0 + v], ((unsigned long long)ord << 32) | li);
         };
         auto compute = [&](const Item &cur, int slice, int c0) { finish(gather(cur), slice, c0); };
         Item buf[DEPTH];
