@@ -49,7 +49,6 @@ def parse():
     p.add_argument("--chunk", type=int, default=int(os.environ.get("LSQ_CHUNK", "0")))
     p.add_argument("--skip", type=int, default=int(os.environ.get("LSQ_SKIP", "1")),
                    help="schedules 3/4: exact memoisation of node updates whose inputs did not change (1) or recompute everything (0)")
-    p.add_argument("--lane", type=int, default=int(os.environ.get("LSQ_LANE", "0")), help="schedule 3, m<=8: one-lane-per-vector kernel (1) or 4-lanes-per-vector (0)")
     p.add_argument("--ablation", type=int, default=int(os.environ.get("LSQ_ABLATION", "0")), help="timing-only kernel ablation (results invalid when != 0)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline budget")
@@ -133,7 +132,6 @@ def main():
     n, d, m, h = args.n, args.d, args.m, 256
     eng = lsq.Engine(dev_index, profile=True, schedule=args.schedule, chunk=(args.chunk or None))
     eng.set_option("skip", args.skip)
-    eng.set_option("lane", args.lane)
     eng.set_option("ablation", args.ablation)
     goff = rank * n
     dX = eng.synth_data_u8_dev(1234, n, d, global_offset=goff)

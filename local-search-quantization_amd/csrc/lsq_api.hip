@@ -61,7 +61,6 @@ struct lsq_ctx {
     int profile = 0;
     int schedule = 4;        // 0: per-node L2-gather kernel, 1: fused sweeps, 2: LDS-slice + combine, 3: LDS-walk, one launch per node,
                              // 4: LDS-walk, one launch per ILS iteration (default)
-    int lane = 0;            // schedule 3, m <= 8: experimental one-lane-per-vector kernel (measured 2.5x slower: VGPR spills)
     int ablation = 0;        // timing-only kernel ablations (results are garbage when != 0)
     int light = -1;          // schedules 3/4: light-block threshold (-1 = default)
     int skip = 1;            // schedule 3: skip node updates whose inputs did not change (exact memoisation)
@@ -171,7 +170,6 @@ extern "C" int lsq_set_option(lsq_ctx *c, const char *key, int64_t value) {
     } else if (!strcmp(key, "profile")) c->profile = value != 0;
     else if (!strcmp(key, "own_stream")) c->stream = c->own_stream;
     else if (!strcmp(key, "skip")) c->skip = value != 0;
-    else if (!strcmp(key, "lane")) c->lane = value != 0;
     else if (!strcmp(key, "ablation")) c->ablation = (int)value;
     else if (!strcmp(key, "light")) c->light = (int)value;
     else if (!strcmp(key, "schedule")) {
@@ -280,7 +278,7 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t c
     if (c->schedule == 1) {
         LSQ_TRY(lsq_launch_icm_fused(c->stream, c->U.as<float>(), c->T.as<float>(), rec, cn, m, order, nsweeps));
         c->icm_launches += 1;
-    } else if (c->schedule == 4 && !c->lane) {
+    } else if (c->schedule == 4) {
         // the whole ILS iteration (nsweeps x m node updates) in ONE launch: a block owns its vectors throughout
         std::vector<int32_t> seq((size_t)nsweeps * m);
         for (int sw = 0; sw < nsweeps; ++sw)
@@ -290,15 +288,9 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t c
         c->icm_launches += ((int64_t)seq.size() + 63) / 64;
     } else if (c->schedule >= 3) {
         for (int sw = 0; sw < nsweeps; ++sw)
-            for (int q = 0; q < m; ++q) {
-                const int j = order[q];
-                if (c->lane && m <= 8 && lsq_walk_slice_width(m) == 16)
-                    LSQ_TRY(lsq_launch_icm_lane(c->stream, c->U.as<float>() + (int64_t)j * cn * LSQ_H, c->Ts.as<float>(), rec, valid, cn, m, j, c->skip,
-                                                c->active.as<unsigned long long>(), c->ablation));
-                else
-                    LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>(), c->Ts.as<float>(), c->T.as<float>(), rec, valid, cn, m, &order[q], 1, c->skip,
-                                                c->active.as<unsigned long long>(), c->ablation, c->light));
-            }
+            for (int q = 0; q < m; ++q)
+                LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>(), c->Ts.as<float>(), c->T.as<float>(), rec, valid, cn, m, &order[q], 1, c->skip,
+                                            c->active.as<unsigned long long>(), c->ablation, c->light));
         c->icm_launches += (int64_t)nsweeps * m;
     } else if (c->schedule == 2) {
         LSQ_TRY(c->part.ensure(sizeof(float2) * (size_t)cn * (LSQ_H / lsq_slice_width(m))));

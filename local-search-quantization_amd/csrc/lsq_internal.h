@@ -109,9 +109,6 @@ int lsq_launch_tables_to_slices(hipStream_t s, const float *T, float *Ts, int m,
 int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const float *T, uint8_t *rec, unsigned short *valid, int64_t n, int m,
                         const int32_t *order, int nnodes, int use_skip, unsigned long long *active_total, int ablation, int light);
 // light: blocks with <= light active vectors gather table columns from L2 instead of staging slices (-1 = default 256)
-// one-lane-per-vector variant of the LDS-walk kernel (m <= 8, slice width 16): same contract as lsq_launch_icm_walk
-int lsq_launch_icm_lane(hipStream_t s, const float *Usj, const float *Ts, uint8_t *rec, unsigned short *valid, int64_t n, int m, int j,
-                        int use_skip, unsigned long long *active_total, int ablation);
 // cost of `rec`; mode 0: prev[i] = cost.  mode 1 (accept): if cost < prev[i] { cur[i] = rec[i]; prev[i] = cost }
 // and counters[0] += (#cost == prev), counters[1] += (#cost < prev)   (counters: 2 x uint64 on device)
 int lsq_launch_cost(hipStream_t s, const float *X, const float *K, const uint8_t *rec, uint8_t *cur, float *prev,
