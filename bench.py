@@ -134,7 +134,18 @@ def main():
     eng.set_option("skip", args.skip)
     eng.set_option("ablation", args.ablation)
     goff = rank * n
-    dX = eng.synth_data_u8_dev(1234, n, d, global_offset=goff)
+    data_tag = "synthetic"
+    dX = None
+    sift = os.path.join(os.environ.get("LSQ_DATA_DIR", ""), "sift", "sift_base.fvecs")
+    if os.environ.get("LSQ_DATA_DIR") and os.path.exists(sift) and d == 128:
+        # use the real SIFT1M base set when it is there (it is not in this image); rank r takes rows [r n, (r+1) n)
+        rows_in_file = os.path.getsize(sift) // (4 + 4 * 128)
+        if goff + n <= rows_in_file:
+            X = lsq.fvecs_read((goff + 1, goff + n), sift)              # (d, n), 1-based inclusive bounds like the reference reader
+            dX = torch.from_numpy(np.ascontiguousarray(X.T)).to("cuda:%d" % dev_index)
+            data_tag = "sift1m_base rows %d..%d (%s)" % (goff, goff + n - 1, sift)
+    if dX is None:
+        dX = eng.synth_data_u8_dev(1234, n, d, global_offset=goff)
     dB0 = eng.randinit_dev(7, n, m, global_offset=goff)
     dK = eng.synth_codebooks_dev(4321, m, d) if rank == 0 else torch.zeros((m * h, d), dtype=torch.float32, device=dX.device)
     dBs = torch.empty((1, n, m), dtype=torch.uint8, device=dX.device)
@@ -218,7 +229,7 @@ def main():
             "metric": "vectors encoded/sec (ICM, m=%d h=%d)" % (m, h),
             "value": value, "unit": "vectors/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": data_tag,
             "config": {
                 "workload": "BASELINE configs[1]: SIFT1M-shaped base encode, %d x %d f32 per GPU, m=%d, h=%d, %d ILS iters x %d ICM sweeps, "
                             "npert=%d, randord, seed=42; inputs resident in HBM; lsq_encode_icm_dev" % (n, d, m, h, args.ils, args.icmiter, args.npert),
