@@ -14,9 +14,11 @@
 //
 // Tiling: 256 threads = 4 waves (2x2), block tile 128 rows x 128 cols, K chunks of BK staged in LDS
 // (row stride BK+1 floats -> the per-k column reads are bank-conflict-free), double-buffered: the next chunk is loaded
-// into registers while the MFMAs of the current one run, one barrier per chunk.  BK = 16 by default (three resident
-// blocks per CU); measured on one box at 10^6 x 128: BK 8/16/32/64 -> 5.9/5.7/6.4/10.6 ms (single-buffered BK = 8 was
-// 6.7 ms; d = 960, 250 K vectors: 9.4 -> 8.3 ms).  Each wave owns a
+// into registers while the MFMAs of the current one run, one barrier per chunk.  BK = 16 by default, and the kernel is
+// compiled for FOUR resident blocks per CU (amdgpu_waves_per_eu(4,4): 120 VGPRs, no spills; three blocks at the compiler's
+// own choice of 77 + 64 registers were 6 % slower -- a K = 128 tile is short, the prologue / epilogue of one block has to
+// hide under the MFMAs of the others).  Measured on one box at 10^6 x 128: 5.57 ms (BK 8/16/32/64 at three blocks:
+// 5.9/5.7/6.4/10.6 ms; single-buffered BK = 8: 6.7 ms; d = 960, 250 K vectors: 9.4 -> 8.0 ms).  Each wave owns a
 // 64x64 sub-tile = 2x2 MFMA 32x32 accumulators (64 VGPRs).  The MFMA M dimension carries the
 // ROWS of A (vectors) and N the candidates, so for a fixed accumulator register a wave stores
 // two 128-byte runs of consecutive candidates -- full-line writes of the 8 KB/vector unary rows.
@@ -77,7 +79,7 @@ __device__ inline void tile_store(const TileRegs<VEC4, BK> &t, float scale, floa
 }
 
 template <bool VEC4, int BK>
-__global__ __launch_bounds__(256) void chain_gemm_kernel(const float *__restrict__ A, const float *__restrict__ Bm,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void chain_gemm_kernel(const float *__restrict__ A, const float *__restrict__ Bm,
                                                          const float *__restrict__ addv, float alpha, int64_t M, int N,
                                                          int Kd, int h, int64_t plane_stride, int64_t row_stride,
                                                          float *__restrict__ D, int64_t row_tiles, int col_tiles, int slice,
@@ -187,20 +189,15 @@ int lsq_launch_chain_gemm(hipStream_t s, const float *A, const float *Bm, const 
     const bool vec4 = (Kd % 4 == 0) && (((uintptr_t)A | (uintptr_t)Bm) % 16 == 0);
     static int bk = -1;
     if (bk < 0) { const char *e = getenv("LSQ_GEMM_BK"); bk = e ? atoi(e) : 16; }
-    if (vec4 && bk == 64)
-        hipLaunchKernelGGL((chain_gemm_kernel<true, 64>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase);
-    else if (vec4 && bk == 8)
+    // K chunks of 8 or 16 only: both fit four resident blocks per CU (the kernel is compiled for 4 waves per SIMD)
+    if (vec4 && bk == 8)
         hipLaunchKernelGGL((chain_gemm_kernel<true, 8>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
                            plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase);
-    else if (vec4 && bk == 16)
+    else if (vec4)
         hipLaunchKernelGGL((chain_gemm_kernel<true, 16>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
                            plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase);
-    else if (vec4)
-        hipLaunchKernelGGL((chain_gemm_kernel<true, 32>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase);
     else
-        hipLaunchKernelGGL((chain_gemm_kernel<false, 32>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
+        hipLaunchKernelGGL((chain_gemm_kernel<false, 16>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
                            plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
