@@ -652,60 +652,87 @@ __global__ __launch_bounds__(256) void cost_kernel(const float *__restrict__ X, 
                                                    unsigned long long *__restrict__ counters, int64_t n, int d, int mode,
                                                    const unsigned short *__restrict__ vnew, unsigned short *__restrict__ vcur) {
     constexpr int CS = (M <= 8) ? 8 : 16;
+    constexpr int RW = CS / 4;
     constexpr int NV = 2;                     // vectors in flight per wave (memory-level parallelism)
     const int lane = threadIdx.x & 63;
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     const int64_t w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     unsigned n_eq = 0, n_lt = 0;
-    for (int64_t i0 = w * NV; i0 < n; i0 += nwaves * NV) {
-        CodeRec cr[NV];
-        int64_t ii[NV];
-        float pcv[NV], part[NV];
+    // A wave takes 64 consecutive vectors, lane l looks at vector base + l: in accept mode a vector whose candidate record
+    // equals its current record has, bit for bit, the cost it already has (same codes, same arithmetic) -- it is counted as
+    // "equal" (encode_icm_cuda.jl:199-204) without touching X or the codebooks.  ~60 % of the vectors from the second ILS
+    // iteration on.  (A NaN cost is never "equal" in the reference's comparison, so those are evaluated.)
+    for (int64_t base = w * 64; base < n; base += nwaves * 64) {
+        const int64_t il = base + lane;
+        const bool live = il < n;
+        const int64_t ic = live ? il : n - 1;
+        uint32_t rn[RW];
+        bool same = (mode == 1);
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {        // every independent load is issued up front
-            ii[v] = (i0 + v < n) ? i0 + v : n - 1;
-            cr[v] = load_rec<CS>(rec, ii[v]);
-            pcv[v] = (mode == 1) ? prev[ii[v]] : 0.0f;
-            part[v] = 0.0f;
+        for (int q = 0; q < RW; ++q) {
+            rn[q] = reinterpret_cast<const uint32_t *>(rec + ic * CS)[q];
+            if (mode == 1) same = same && (rn[q] == reinterpret_cast<const uint32_t *>(cur + ic * CS)[q]);
         }
-        for (int t0 = 0; t0 < d; t0 += 64) {
-            const int t = t0 + lane;
-            const bool valid = t < d;
-            const int tt = valid ? t : 0;
-            float xv[NV], kv[NV][M];
+        const float pl = (mode == 1) ? prev[ic] : 0.0f;
+        const bool skip = live && same && (pl == pl);
+        n_eq += (unsigned)__popcll(__ballot(skip)) * (lane == 0 ? 1u : 0u);
+        uint64_t todo = __ballot(live && !skip);
+        while (todo) {
+            CodeRec cr[NV];
+            int64_t ii[NV];
+            float pcv[NV], part[NV];
+            bool have[NV];
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                xv[v] = X[ii[v] * (int64_t)d + tt];
+            for (int v = 0; v < NV; ++v) {        // every independent load is issued up front
+                have[v] = todo != 0;
+                const int src = have[v] ? __builtin_ctzll(todo) : 0;
+                if (have[v]) todo &= todo - 1;
+                ii[v] = base + src;
+                cr[v].lo = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)rn[0], src) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)rn[1], src) << 32);
+                cr[v].hi = 0;
+                if (RW == 4) cr[v].hi = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)rn[RW - 2], src) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)rn[RW - 1], src) << 32);
+                pcv[v] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pl), src));
+                part[v] = 0.0f;
+            }
+            for (int t0 = 0; t0 < d; t0 += 64) {
+                const int t = t0 + lane;
+                const bool valid = t < d;
+                const int tt = valid ? t : 0;
+                float xv[NV], kv[NV][M];
 #pragma unroll
-                for (int k = 0; k < M; ++k) kv[v][k] = K[((int64_t)(k * LSQ_H) + cr[v].get(k)) * d + tt];
+                for (int v = 0; v < NV; ++v) {
+                    xv[v] = X[ii[v] * (int64_t)d + tt];
+#pragma unroll
+                    for (int k = 0; k < M; ++k) kv[v][k] = K[((int64_t)(k * LSQ_H) + cr[v].get(k)) * d + tt];
+                }
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    float cb = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < M; ++k) cb = cb + kv[v][k];          // k ascending from 0 (utils.jl:238-244)
+                    const float r = cb - xv[v];
+                    const float sq = r * r;                                   // never fused (-ffp-contract=off)
+                    part[v] = part[v] + (valid ? sq : 0.0f);                  // lane partial: t = lane + 64 q, q ascending
+                }
             }
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
-                float cb = 0.0f;
-#pragma unroll
-                for (int k = 0; k < M; ++k) cb = cb + kv[v][k];          // k ascending from 0 (utils.jl:238-244)
-                const float r = cb - xv[v];
-                const float sq = r * r;                                   // never fused (-ffp-contract=off)
-                part[v] = part[v] + (valid ? sq : 0.0f);                  // lane partial: t = lane + 64 q, q ascending
-            }
-        }
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const float cost = wave_sum_tree(part[v]);
-            if (i0 + v >= n) continue;
-            if (mode == 0) {
-                if (lane == 0) prev[ii[v]] = cost;
-            } else {
-                const float pc = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pcv[v])));
-                n_eq += (cost == pc);
-                if (cost < pc) {                                          // strict improvement only (encode_icm.jl:183-186)
-                    ++n_lt;
-                    if (lane == 0) {
-                        prev[ii[v]] = cost;
-                        uint64_t *q = reinterpret_cast<uint64_t *>(cur + ii[v] * CS);
-                        q[0] = cr[v].lo;
-                        if (CS == 16) q[1] = cr[v].hi;
-                        if (vcur) vcur[ii[v]] = vnew[ii[v]];
+                const float cost = wave_sum_tree(part[v]);
+                if (!have[v]) continue;
+                if (mode == 0) {
+                    if (lane == 0) prev[ii[v]] = cost;
+                } else {
+                    const float pc = pcv[v];
+                    if (lane == 0) n_eq += (cost == pc);
+                    if (cost < pc) {                                          // strict improvement only (encode_icm.jl:183-186)
+                        if (lane == 0) {
+                            ++n_lt;
+                            prev[ii[v]] = cost;
+                            uint64_t *q = reinterpret_cast<uint64_t *>(cur + ii[v] * CS);
+                            q[0] = cr[v].lo;
+                            if (CS == 16) q[1] = cr[v].hi;
+                            if (vcur) vcur[ii[v]] = vnew[ii[v]];
+                        }
                     }
                 }
             }
@@ -736,61 +763,89 @@ __global__ __launch_bounds__(256) void cost2_kernel(const float *__restrict__ X,
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     const int64_t w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     unsigned n_eq = 0, n_lt = 0;
-    for (int64_t i0 = w * 2; i0 < n; i0 += nwaves * 2) {
-        const bool live = i0 + half < n;
-        const int64_t i = live ? i0 + half : n - 1;                       // clamped: loads stay in bounds
-        uint32_t r[RW];
-        const uint32_t *rp = reinterpret_cast<const uint32_t *>(rec + i * CS);
+    // 64 consecutive vectors per wave batch; vectors whose candidate record equals the current one keep their cost (see
+    // cost_kernel) and are skipped; the others are taken two at a time, one per half-wave.
+    for (int64_t base = w * 64; base < n; base += nwaves * 64) {
+        const int64_t il = base + lane;
+        const bool livel = il < n;
+        const int64_t ic = livel ? il : n - 1;
+        uint32_t rn[RW];
+        bool same = (mode == 1);
 #pragma unroll
-        for (int q = 0; q < RW; ++q) r[q] = rp[q];
-        const float pc = (mode == 1) ? prev[i] : 0.0f;
-        const float *x = X + i * (int64_t)d;
-        const float *kb[M];
-#pragma unroll
-        for (int k = 0; k < M; ++k) kb[k] = K + ((int64_t)(k * LSQ_H) + ((r[k >> 2] >> (8 * (k & 3))) & 0xffu)) * d;
-        float p0 = 0.0f, p1 = 0.0f;
-        for (int c0 = 0; c0 < d; c0 += 128) {
-            const int ta = c0 + 2 * lp, tb = ta + 64;
-            const bool va = ta < d, vb = tb < d;
-            const int ua = va ? ta : 0, ub = vb ? tb : 0;
-            const f32x2 xa = *reinterpret_cast<const f32x2 *>(x + ua), xb = *reinterpret_cast<const f32x2 *>(x + ub);
-            f32x2 ka[M], kbv[M];
-#pragma unroll
-            for (int k = 0; k < M; ++k) {
-                ka[k] = *reinterpret_cast<const f32x2 *>(kb[k] + ua);
-                kbv[k] = *reinterpret_cast<const f32x2 *>(kb[k] + ub);
-            }
-            f32x2 ca = (f32x2){0.f, 0.f}, cb = (f32x2){0.f, 0.f};
-#pragma unroll
-            for (int k = 0; k < M; ++k) { ca = ca + ka[k]; cb = cb + kbv[k]; }      // k ascending from 0 (utils.jl:238-244)
-            const f32x2 ra = ca - xa, rb = cb - xb;
-            const f32x2 sa = ra * ra, sb = rb * rb;                                 // never fused (-ffp-contract=off)
-            p0 = p0 + (va ? sa.x : 0.0f);                                           // residue 2l':   t ascending
-            p1 = p1 + (va ? sa.y : 0.0f);                                           // residue 2l'+1
-            p0 = p0 + (vb ? sb.x : 0.0f);
-            p1 = p1 + (vb ? sb.y : 0.0f);
+        for (int q = 0; q < RW; ++q) {
+            rn[q] = reinterpret_cast<const uint32_t *>(rec + ic * CS)[q];
+            if (mode == 1) same = same && (rn[q] == reinterpret_cast<const uint32_t *>(cur + ic * CS)[q]);
         }
-        float v = p0 + p1;                                                          // tree level 1
-        v = v + dpp_self<DPP_XOR1, 0xf>(v);                                         // levels 2, 4, 8, 16: within the row
-        v = v + dpp_self<DPP_XOR2, 0xf>(v);
-        v = v + dpp_self<DPP_HALF_MIRROR, 0xf>(v);
-        v = v + dpp_self<DPP_MIRROR, 0xf>(v);
-        v = v + dpp_zero<DPP_BCAST15, 0xa>(v);                                      // level 32: rows 1 and 3 add rows 0 and 2
-        const float costA = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
-        const float costB = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-        const float cost = half ? costB : costA;
-        if (mode == 0) {
-            if (live && lp == 0) prev[i] = cost;
-        } else {
-            const bool eq = live && (cost == pc), lt = live && (cost < pc);          // strict improvement only (encode_icm.jl:183-186)
-            n_eq += (unsigned)__popcll(__ballot(eq && lp == 0));
-            n_lt += (unsigned)__popcll(__ballot(lt && lp == 0));
-            if (lt && lp == 0) {
-                prev[i] = cost;
-                uint32_t *qd = reinterpret_cast<uint32_t *>(cur + i * CS);
+        const float pl = (mode == 1) ? prev[ic] : 0.0f;
+        const bool skip = livel && same && (pl == pl);
+        const unsigned nskip = (unsigned)__popcll(__ballot(skip));              // all lanes vote, lane 0 keeps the wave's counters
+        if (lane == 0) n_eq += nskip;
+        uint64_t todo = __ballot(livel && !skip);
+        while (todo) {
+            const int sa = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const bool haveb = todo != 0;
+            const int sb = haveb ? __builtin_ctzll(todo) : sa;                // odd count: the second half repeats the first, unwritten
+            if (haveb) todo &= todo - 1;
+            const bool live = half ? haveb : true;
+            const int64_t i = base + (half ? sb : sa);
+            uint32_t r[RW];
 #pragma unroll
-                for (int q = 0; q < RW; ++q) qd[q] = r[q];
-                if (vcur) vcur[i] = vnew[i];
+            for (int q = 0; q < RW; ++q) {
+                const uint32_t ra_ = (uint32_t)__builtin_amdgcn_readlane((int)rn[q], sa), rb_ = (uint32_t)__builtin_amdgcn_readlane((int)rn[q], sb);
+                r[q] = half ? rb_ : ra_;
+            }
+            const float pca = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pl), sa));
+            const float pcb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pl), sb));
+            const float pc = half ? pcb : pca;
+            const float *x = X + i * (int64_t)d;
+            const float *kb[M];
+#pragma unroll
+            for (int k = 0; k < M; ++k) kb[k] = K + ((int64_t)(k * LSQ_H) + ((r[k >> 2] >> (8 * (k & 3))) & 0xffu)) * d;
+            float p0 = 0.0f, p1 = 0.0f;
+            for (int c0 = 0; c0 < d; c0 += 128) {
+                const int ta = c0 + 2 * lp, tb = ta + 64;
+                const bool va = ta < d, vb = tb < d;
+                const int ua = va ? ta : 0, ub = vb ? tb : 0;
+                const f32x2 xa = *reinterpret_cast<const f32x2 *>(x + ua), xb = *reinterpret_cast<const f32x2 *>(x + ub);
+                f32x2 ka[M], kbv[M];
+#pragma unroll
+                for (int k = 0; k < M; ++k) {
+                    ka[k] = *reinterpret_cast<const f32x2 *>(kb[k] + ua);
+                    kbv[k] = *reinterpret_cast<const f32x2 *>(kb[k] + ub);
+                }
+                f32x2 ca = (f32x2){0.f, 0.f}, cb = (f32x2){0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < M; ++k) { ca = ca + ka[k]; cb = cb + kbv[k]; }      // k ascending from 0 (utils.jl:238-244)
+                const f32x2 ra = ca - xa, rb = cb - xb;
+                const f32x2 sa2 = ra * ra, sb2 = rb * rb;                               // never fused (-ffp-contract=off)
+                p0 = p0 + (va ? sa2.x : 0.0f);                                          // residue 2l':   t ascending
+                p1 = p1 + (va ? sa2.y : 0.0f);                                          // residue 2l'+1
+                p0 = p0 + (vb ? sb2.x : 0.0f);
+                p1 = p1 + (vb ? sb2.y : 0.0f);
+            }
+            float v = p0 + p1;                                                          // tree level 1
+            v = v + dpp_self<DPP_XOR1, 0xf>(v);                                         // levels 2, 4, 8, 16: within the row
+            v = v + dpp_self<DPP_XOR2, 0xf>(v);
+            v = v + dpp_self<DPP_HALF_MIRROR, 0xf>(v);
+            v = v + dpp_self<DPP_MIRROR, 0xf>(v);
+            v = v + dpp_zero<DPP_BCAST15, 0xa>(v);                                      // level 32: rows 1 and 3 add rows 0 and 2
+            const float costA = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+            const float costB = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+            const float cost = half ? costB : costA;
+            if (mode == 0) {
+                if (live && lp == 0) prev[i] = cost;
+            } else {
+                const bool eq = live && (cost == pc), lt = live && (cost < pc);          // strict improvement only (encode_icm.jl:183-186)
+                const unsigned ne = (unsigned)__popcll(__ballot(eq && lp == 0)), nl = (unsigned)__popcll(__ballot(lt && lp == 0));
+                if (lane == 0) { n_eq += ne; n_lt += nl; }
+                if (lt && lp == 0) {
+                    prev[i] = cost;
+                    uint32_t *qd = reinterpret_cast<uint32_t *>(cur + i * CS);
+#pragma unroll
+                    for (int q = 0; q < RW; ++q) qd[q] = r[q];
+                    if (vcur) vcur[i] = vnew[i];
+                }
             }
         }
     }

@@ -212,12 +212,18 @@ def test_nonfinite_inputs_follow_the_reference_scan(lsq, oracle, n):
     K = K.copy()
     K[7] = 0.0
     K[300] = -0.0
-    Bs_ref, objs_ref = oracle.encode_icm(X, B0, K, m, H, [1, 2], 3, 4, True, seed)
+    import torch
+    Bs_ref, objs_ref, st_ref = oracle.encode_icm(X, B0, K, m, H, [1, 2, 4], 3, 4, True, seed, want_stats=True)
     for schedule in (4, 3):
         with lsq.Engine(0, schedule=schedule) as eng:
-            Bs, objs = eng.encode_icm(X, B0, K, m, [1, 2], 3, 4, True, seed=seed)
-        assert np.array_equal(Bs, Bs_ref), "schedule %d: %d codes differ" % (schedule, (Bs != Bs_ref).sum())
-        assert np.array_equal(np.isnan(objs), np.isnan(objs_ref))
+            Bs, objs = eng.encode_icm(X, B0, K, m, [1, 2, 4], 3, 4, True, seed=seed)
+            assert np.array_equal(Bs, Bs_ref), "schedule %d: %d codes differ" % (schedule, (Bs != Bs_ref).sum())
+            assert np.array_equal(np.isnan(objs), np.isnan(objs_ref))
+            # the "% equal / % better" counters too: a vector whose codes come back unchanged is "equal" without a cost
+            # evaluation -- unless its cost is NaN, which the reference's `==` never counts
+            dBs, _, stats = eng.encode_icm_dev(torch.from_numpy(X).cuda(), torch.from_numpy((B0 - 1).astype(np.uint8)).cuda(),
+                                               torch.from_numpy(K).cuda(), m, [4], 3, 4, True, seed=seed)
+            assert np.array_equal(stats, st_ref.astype(np.int64))
 
 
 def test_staged_path_full_oracle_parity(lsq, oracle):
