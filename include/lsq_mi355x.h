@@ -94,6 +94,8 @@ LSQ_API int lsq_set_stream(lsq_ctx *ctx, void *hip_stream);
  *        1 fused sweeps, unaries register-resident;
  *   "light" (schedules 3 and 4, default 256): a block with at most this many active vectors gathers its table columns
  *        straight from L2 (one wave per vector) instead of staging slices through LDS; 0 = always stage.  Same codes.
+ *   "fallback" (0/1, default 1; schedules 3 and 4): a candidate whose codes become equal to the vector's current codes inherits
+ *        the current state's validity bits (validity depends on the code tuple only): exact, ~12 % fewer node updates.
  *   "skip" (0/1, default 1; schedules 3 and 4): a node whose conditioning codes did not change since it was
  *        last minimised is not recomputed (exact memoisation -- same codes, fewer bytes). */
 LSQ_API int lsq_set_option(lsq_ctx *ctx, const char *key, int64_t value);

@@ -63,6 +63,7 @@ struct lsq_ctx {
                              // 4: LDS-walk, one launch per ILS iteration (default)
     int ablation = 0;        // timing-only kernel ablations (results are garbage when != 0)
     int light = -1;          // schedules 3/4: light-block threshold (-1 = default)
+    int fallback = 1;        // schedules 3/4: a candidate equal to its current record inherits that record's validity bits (exact)
     int skip = 1;            // schedule 3: skip node updates whose inputs did not change (exact memoisation)
     // workspace
     DevBuf sci, T, Ts, U, part, vCur, vNew, active, recCur, recNew, prev, counters, obj, bad;
@@ -172,6 +173,7 @@ extern "C" int lsq_set_option(lsq_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "skip")) c->skip = value != 0;
     else if (!strcmp(key, "ablation")) c->ablation = (int)value;
     else if (!strcmp(key, "light")) c->light = (int)value;
+    else if (!strcmp(key, "fallback")) c->fallback = (int)value;
     else if (!strcmp(key, "schedule")) {
         if (value < 0 || value > 4) { lsq_set_error("schedule must be 0..4"); return LSQ_EINVAL; }
         c->schedule = (int)value;
@@ -273,7 +275,9 @@ static int build_unaries(lsq_ctx *c, const float *dX, const float *dK, int d, in
                                  c->U.as<float>(), slice, cn, r0);
 }
 
-static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t cn, int m, const int32_t *order, int nsweeps) {
+// ref_rec / ref_valid: the vectors' current records and validity masks (read-only during the sweeps), or nullptr
+static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t cn, int m, const int32_t *order, int nsweeps,
+                      const uint8_t *ref_rec = nullptr, const unsigned short *ref_valid = nullptr) {
     Timer t(c, CAT_ICM);
     if (c->schedule == 1) {
         LSQ_TRY(lsq_launch_icm_fused(c->stream, c->U.as<float>(), c->T.as<float>(), rec, cn, m, order, nsweeps));
@@ -284,13 +288,13 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t c
         for (int sw = 0; sw < nsweeps; ++sw)
             for (int q = 0; q < m; ++q) seq[(size_t)sw * m + q] = order[q];
         LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>(), c->Ts.as<float>(), c->T.as<float>(), rec, valid, cn, m, seq.data(), (int)seq.size(), c->skip,
-                                    c->active.as<unsigned long long>(), c->ablation, c->light));
+                                    c->active.as<unsigned long long>(), c->ablation, c->light, c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr));
         c->icm_launches += ((int64_t)seq.size() + 63) / 64;
     } else if (c->schedule >= 3) {
         for (int sw = 0; sw < nsweeps; ++sw)
             for (int q = 0; q < m; ++q)
                 LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>(), c->Ts.as<float>(), c->T.as<float>(), rec, valid, cn, m, &order[q], 1, c->skip,
-                                            c->active.as<unsigned long long>(), c->ablation, c->light));
+                                            c->active.as<unsigned long long>(), c->ablation, c->light, c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr));
         c->icm_launches += (int64_t)nsweeps * m;
     } else if (c->schedule == 2) {
         LSQ_TRY(c->part.ensure(sizeof(float2) * (size_t)cn * (LSQ_H / lsq_slice_width(m))));
@@ -345,7 +349,7 @@ static int encode_chunk(lsq_ctx *c, const float *dXc, const float *dK, int64_t c
             Timer t(c, CAT_PERTURB);
             LSQ_TRY(lsq_launch_perturb(c->stream, cur, nw, cn, P.m, P.npert, P.seed, P.it0 + (uint32_t)it, goff, vcur, vnew));
         }
-        LSQ_TRY(run_sweeps(c, nw, vnew, cn, P.m, order, P.icmiter));
+        LSQ_TRY(run_sweeps(c, nw, vnew, cn, P.m, order, P.icmiter, cur, vcur));
         {
             Timer t(c, CAT_COST);
             LSQ_TRY(lsq_launch_cost(c->stream, dXc, dK, nw, cur, prev, counters + 2 * it, cn, P.d, P.m, 1, vnew, vcur));

@@ -311,6 +311,24 @@ constexpr int lsq_walk_pp(int M, int SL) {
 }
 #define LSQ_WALK_PP(M, SL) lsq_walk_pp(M, SL)
 
+// Validity is a property of the code tuple alone ("code j is the first argmin of node j given the other codes").  When the
+// candidate tuple, after node j took `code`, equals the vector's CURRENT tuple (the state the ILS iteration started from, whose
+// validity bits were established earlier and are read-only during the sweeps), everything known about that tuple holds for
+// the candidate too: its bits are OR-ed in.  A vector that has fallen back to a known fixed point stops being recomputed at
+// once instead of being re-verified for another sweep.  Exact: only true statements about the same tuple are imported.
+template <int RW>
+__device__ inline unsigned short known_valid(const uint32_t (&rw)[RW], int j, uint8_t code, const uint8_t *ref, const unsigned short *refv) {
+    if (!ref || !refv) return 0;
+    bool same = true;
+#pragma unroll
+    for (int w = 0; w < RW; ++w) {
+        uint32_t mine = rw[w];
+        if (w == (j >> 2)) mine = (mine & ~(0xffu << (8 * (j & 3)))) | ((uint32_t)code << (8 * (j & 3)));
+        same = same && (mine == reinterpret_cast<const uint32_t *>(ref)[w]);
+    }
+    return same ? *refv : (unsigned short)0;
+}
+
 #define LSQ_WALK_MAX_NODES 64
 struct WalkNodes { int count; uint8_t j[LSQ_WALK_MAX_NODES]; };      // kernel argument: node updates of one launch, in order
 
@@ -325,7 +343,8 @@ template <int M, int SL, int ABL = 0, int DEPTH = 2, int NT = 1024>      // NT: 
 __global__ __launch_bounds__(NT) void icm_walk_kernel(const float *__restrict__ U, const float *__restrict__ Ts, const float *__restrict__ T,
                                                         uint8_t *__restrict__ rec, unsigned short *__restrict__ valid,
                                                         int64_t n, const WalkNodes nodes, int per_pass, int use_skip, int direct_max,
-                                                        unsigned long long *__restrict__ active_total) {
+                                                        unsigned long long *__restrict__ active_total,
+                                                        const uint8_t *__restrict__ ref_rec, const unsigned short *__restrict__ ref_valid) {
     constexpr int CS = (M <= 8) ? 8 : 16;
     constexpr int NS = LSQ_H / SL;
     constexpr int LPV = SL / 4;
@@ -431,7 +450,14 @@ __global__ __launch_bounds__(NT) void icm_walk_kernel(const float *__restrict__ 
                 const uint32_t code = (uint32_t)wave_first_argmin(s, lane);
                 if (lane == 0) {
                     rec[i * CS + j] = (uint8_t)code;
-                    if (valid) valid[i] = (code != cr.get(j)) ? (unsigned short)(1u << j) : (unsigned short)(valid[i] | (1u << j));
+                    if (valid) {
+                        unsigned short vm = (code != cr.get(j)) ? (unsigned short)(1u << j) : (unsigned short)(valid[i] | (1u << j));
+                        uint32_t rw[RW];
+                        rw[0] = (uint32_t)cr.lo; rw[1] = (uint32_t)(cr.lo >> 32);
+                        if (RW == 4) { rw[RW - 2] = (uint32_t)cr.hi; rw[RW - 1] = (uint32_t)(cr.hi >> 32); }
+                        vm = (unsigned short)(vm | known_valid<RW>(rw, j, (uint8_t)code, ref_rec ? ref_rec + i * CS : nullptr, ref_valid ? ref_valid + i : nullptr));
+                        valid[i] = vm;
+                    }
                 }
             }
             __syncthreads();
@@ -566,9 +592,17 @@ __global__ __launch_bounds__(NT) void icm_walk_kernel(const float *__restrict__ 
             const int64_t i = lo + list[ci];
             const unsigned bi = (unsigned)(best64[ci] & 0xffffffffull);
             const uint8_t code = (uint8_t)(bi > 255 ? 0 : bi);
-            const uint8_t old = rec[i * CS + j];
+            // the record with byte j replaced (one aligned load instead of a byte load)
+            uint32_t rw[RW];
+#pragma unroll
+            for (int w2 = 0; w2 < RW; ++w2) rw[w2] = reinterpret_cast<const uint32_t *>(rec + i * CS)[w2];
+            const uint8_t old = (uint8_t)(rw[j >> 2] >> (8 * (j & 3)));
             rec[i * CS + j] = code;
-            if (valid) valid[i] = (code != old) ? (unsigned short)(1u << j) : (unsigned short)(valid[i] | (1u << j));
+            if (valid) {
+                unsigned short vm = (code != old) ? (unsigned short)(1u << j) : (unsigned short)(valid[i] | (1u << j));
+                vm = (unsigned short)(vm | known_valid<RW>(rw, j, code, ref_rec ? ref_rec + i * CS : nullptr, ref_valid ? ref_valid + i : nullptr));
+                valid[i] = vm;
+            }
         }
         __syncthreads();
         }   // node updates
@@ -676,6 +710,7 @@ __global__ __launch_bounds__(256) void cost_kernel(const float *__restrict__ X, 
         const float pl = (mode == 1) ? prev[ic] : 0.0f;
         const bool skip = live && same && (pl == pl);
         n_eq += (unsigned)__popcll(__ballot(skip)) * (lane == 0 ? 1u : 0u);
+        if (same && live && vcur) vcur[il] = (unsigned short)(vcur[il] | vnew[il]);      // same tuple: what the sweeps learnt about it is kept
         uint64_t todo = __ballot(live && !skip);
         while (todo) {
             CodeRec cr[NV];
@@ -780,6 +815,7 @@ __global__ __launch_bounds__(256) void cost2_kernel(const float *__restrict__ X,
         const bool skip = livel && same && (pl == pl);
         const unsigned nskip = (unsigned)__popcll(__ballot(skip));              // all lanes vote, lane 0 keeps the wave's counters
         if (lane == 0) n_eq += nskip;
+        if (same && livel && vcur) vcur[il] = (unsigned short)(vcur[il] | vnew[il]);     // same tuple: what the sweeps learnt about it is kept
         uint64_t todo = __ballot(livel && !skip);
         while (todo) {
             const int sa = __builtin_ctzll(todo);
@@ -999,7 +1035,8 @@ static int launch_slice_t(hipStream_t s, const float *Usj, const float *Tj, uint
 
 template <int M, int SL, int ABL = 0, int DEPTH = 2, int NT = 1024>
 static int launch_walk_t(hipStream_t s, const float *U, const float *Ts, const float *T, uint8_t *rec, unsigned short *valid, int64_t n,
-                         const WalkNodes &nodes, int use_skip, unsigned long long *active_total, int light) {
+                         const WalkNodes &nodes, int use_skip, unsigned long long *active_total, int light,
+                         const uint8_t *ref_rec, const unsigned short *ref_valid) {
     constexpr int TAB = (M - 1) * LSQ_H * (SL / 4);
     constexpr int PP = LSQ_WALK_PP(M, SL);
     constexpr int LDS_BYTES = TAB * 16 + PP * 8 + PP * 2;                // slice table + packed running best + active list
@@ -1021,7 +1058,8 @@ static int launch_walk_t(hipStream_t s, const float *U, const float *Ts, const f
     if (direct_def < 0) { const char *e = getenv("LSQ_WALK_DIRECT"); direct_def = e ? atoi(e) : 256; }
     const int direct_max = light >= 0 ? light : direct_def;
     hipLaunchKernelGGL((icm_walk_kernel<M, SL, ABL, DEPTH, NT>), dim3(grid), dim3(NT), LDS_BYTES, s, U, Ts, T, rec, valid, n, nodes, (int)per_pass,
-                       (use_skip && valid) ? 1 : 0, (T && ABL == 0) ? direct_max : 0, active_total);
+                       (use_skip && valid) ? 1 : 0, (T && ABL == 0) ? direct_max : 0, active_total, (use_skip && valid) ? ref_rec : nullptr,
+                       (use_skip && valid) ? ref_valid : nullptr);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }
@@ -1034,7 +1072,8 @@ int lsq_walk_slice_width(int m) {
 
 // `order[nnodes]`: the node updates to run back to back inside the launch (1 = one node; icmiter*m = a whole ILS iteration)
 int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const float *T, uint8_t *rec, unsigned short *valid, int64_t n, int m,
-                        const int32_t *order, int nnodes, int use_skip, unsigned long long *active_total, int ablation, int light) {
+                        const int32_t *order, int nnodes, int use_skip, unsigned long long *active_total, int ablation, int light,
+                        const uint8_t *ref_rec, const unsigned short *ref_valid) {
     if (n <= 0 || nnodes <= 0) return LSQ_OK;
     if (m < 1 || m > LSQ_MAX_M) { lsq_set_error("m = %d out of range 1..16", m); return LSQ_EINVAL; }
     static int big_nt = -1;              // block size for m >= 14 (tuning knob LSQ_WALK_BIG_NT=1024 restores the old shape)
@@ -1050,25 +1089,25 @@ int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const fl
         // m >= 14: up to 15 table reads in flight + 8 staged table registers per thread do not fit 128 VGPRs (measured at
         // m = 16: 67..100 spilled registers, 1.5..2.5x slower) -> 512-thread blocks (256 VGPRs per wave), more U items in
         // flight instead.  m = 9..13 fit (<= 4 spills) and are 3-5 % faster with 1024 threads (measured for every m).
-#define LSQ_WALK_CASE_MID(MM) case MM: LSQ_TRY((launch_walk_t<MM, 8, 0, 2>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light))); break;
+#define LSQ_WALK_CASE_MID(MM) case MM: LSQ_TRY((launch_walk_t<MM, 8, 0, 2>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light, ref_rec, ref_valid))); break;
 #define LSQ_WALK_CASE_BIG(MM) case MM: \
-            if (big_nt == 512) LSQ_TRY((launch_walk_t<MM, 8, 0, 4, 512>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light))); \
-            else LSQ_TRY((launch_walk_t<MM, 8>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light))); \
+            if (big_nt == 512) LSQ_TRY((launch_walk_t<MM, 8, 0, 4, 512>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light, ref_rec, ref_valid))); \
+            else LSQ_TRY((launch_walk_t<MM, 8>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light, ref_rec, ref_valid))); \
             break;
-#define LSQ_WALK_CASE(MM, SLL) case MM: LSQ_TRY((launch_walk_t<MM, SLL, 0, 3>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light))); break;
+#define LSQ_WALK_CASE(MM, SLL) case MM: LSQ_TRY((launch_walk_t<MM, SLL, 0, 3>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light, ref_rec, ref_valid))); break;
         if (m <= 8 && lsq_walk_slice_width(m) == 8) {
             switch (m) {
                 LSQ_WALK_CASE(1, 8) LSQ_WALK_CASE(2, 8) LSQ_WALK_CASE(3, 8) LSQ_WALK_CASE(4, 8)
                 LSQ_WALK_CASE(5, 8) LSQ_WALK_CASE(6, 8) LSQ_WALK_CASE(7, 8) LSQ_WALK_CASE(8, 8)
             }
         } else if (m == 8 && ablation == 1) {
-            LSQ_TRY((launch_walk_t<8, 16, 1>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light)));
+            LSQ_TRY((launch_walk_t<8, 16, 1>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light, ref_rec, ref_valid)));
         } else if (m == 8 && ablation == 2) {
-            LSQ_TRY((launch_walk_t<8, 16, 2>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light)));
+            LSQ_TRY((launch_walk_t<8, 16, 2>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light, ref_rec, ref_valid)));
         } else if (m == 8 && ablation == 3) {
-            LSQ_TRY((launch_walk_t<8, 16, 3>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light)));
+            LSQ_TRY((launch_walk_t<8, 16, 3>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light, ref_rec, ref_valid)));
         } else if (m == 8 && ablation == 4) {
-            LSQ_TRY((launch_walk_t<8, 16, 4>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light)));
+            LSQ_TRY((launch_walk_t<8, 16, 4>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light, ref_rec, ref_valid)));
 
         } else {
             switch (m) {

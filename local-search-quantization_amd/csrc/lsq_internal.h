@@ -107,7 +107,10 @@ int lsq_launch_tables_to_slices(hipStream_t s, const float *T, float *Ts, int m,
 // U is the slice-major unary buffer of ALL nodes; T (optional) the row-major tables for light blocks' L2 gathers; order[nnodes] = node updates run back to back inside the launch
 // (a block owns its vectors for the whole launch): 1 entry = one node update, icmiter*m entries = a whole ILS iteration.
 int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const float *T, uint8_t *rec, unsigned short *valid, int64_t n, int m,
-                        const int32_t *order, int nnodes, int use_skip, unsigned long long *active_total, int ablation, int light);
+                        const int32_t *order, int nnodes, int use_skip, unsigned long long *active_total, int ablation, int light,
+                        const uint8_t *ref_rec, const unsigned short *ref_valid);
+// ref_rec / ref_valid (optional, read-only): the vectors' current records and their validity masks; a candidate that becomes
+// equal to its current record inherits those bits (exact: validity depends on the code tuple only)
 // light: blocks with <= light active vectors gather table columns from L2 instead of staging slices (-1 = default 256)
 // cost of `rec`; mode 0: prev[i] = cost.  mode 1 (accept): if cost < prev[i] { cur[i] = rec[i]; prev[i] = cost }
 // and counters[0] += (#cost == prev), counters[1] += (#cost < prev)   (counters: 2 x uint64 on device)
