@@ -105,6 +105,31 @@ def test_skip_unchanged_is_exact(lsq, oracle):
         assert 0 < counts[1] < counts[0]
 
 
+def test_fallback_to_current_state_is_exact(lsq, oracle):
+    """Option "fallback": a candidate whose codes become equal to the vector's current codes inherits that state's
+    validity bits.  Pure optimisation: codes, objective and the equal / better counters identical with it on and off
+    (and equal to the oracle), strictly fewer node updates recomputed.  Several ILS iterations so that vectors do fall back."""
+    import torch
+    d, n, m, ils, J, npert, seed = 32, 20_000, 8, [6], 4, 4, 314
+    X, K, B0 = make_problem(d, n, m, seed=seed)
+    Bs_ref, objs_ref, st_ref = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, True, seed, want_stats=True)
+    dX, dK = torch.from_numpy(X).cuda(), torch.from_numpy(K).cuda()
+    dB = torch.from_numpy((B0 - 1).astype(np.uint8)).cuda()
+    counts = {}
+    for fb in (1, 0):
+        for light in (-1, 0):                                  # both node-update paths
+            with lsq.Engine(0, profile=True) as eng:
+                eng.set_option("fallback", fb)
+                eng.set_option("light", light)
+                dBs, sums, stats = eng.encode_icm_dev(dX, dB, dK, m, ils, J, npert, True, seed=seed)
+                counts[(fb, light)] = eng.timings()["icm_node_updates"]
+                assert np.array_equal(dBs.cpu().numpy().astype(np.int16) + 1, Bs_ref), "fallback=%d light=%d" % (fb, light)
+                assert np.allclose(sums / n, objs_ref, rtol=1e-5, atol=0)
+                assert np.array_equal(stats, st_ref.astype(np.int64))
+    assert counts[(1, -1)] == counts[(1, 0)] and counts[(0, -1)] == counts[(0, 0)]
+    assert counts[(1, -1)] < counts[(0, -1)]
+
+
 def test_device_api_chunking_and_offsets(lsq, oracle):
     """Results must not depend on the resident chunk size nor on how the caller shards (P8):
     encode [0,n) in one call == two calls on halves with global_offset."""
