@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 L2_PEAK_GBS = 34500.0          # same guide, L2 aggregate measured
-PMC_FILE, PMC_SCHEDULE = "r01g_pmc_per_kernel.json", 4      # committed PMC passes the `traffic` field is read from
+PMC_FILE, PMC_SCHEDULE = "r01h_pmc_per_kernel.json", 4      # committed PMC passes the `traffic` field is read from
 
 
 def parse():
