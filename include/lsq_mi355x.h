@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define LSQ_VERSION 100
+#define LSQ_VERSION 200
 
 #if defined(__GNUC__)
 #define LSQ_API __attribute__((visibility("default")))
@@ -70,6 +70,10 @@ typedef struct lsq_timings {
     double other_ms;         /* layout conversion, snapshots                         */
     int64_t icm_launches;    /* number of ICM kernel launches inside icm_ms           */
     int64_t icm_node_updates;/* vector x node updates executed inside icm_ms          */
+    /* which path the ICM blocks took (counted per block and node update, on the device; since v200): */
+    int64_t staged_blocks;   /* table slices staged through LDS, the block walked all of them (team size 1)  */
+    int64_t light_blocks;    /* few active vectors: table columns gathered from L2, one wave per vector       */
+    int64_t team_blocks;     /* table slices staged through LDS, the block walked its share (team size > 1)   */
 } lsq_timings;
 
 LSQ_API const char *lsq_last_error(void);

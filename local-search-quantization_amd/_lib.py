@@ -9,6 +9,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LSQ_LIB_PATH") or os.path.join(_HERE, "liblsq_mi355x.so")      # override: A/B builds of the same ABI
+# Same ABI built with -DLSQ_TUNING: + option "ablation", environment knobs, schedules 0..2.  Profiling tools and the tests
+# that cross-check the earlier schedules load it explicitly (Engine(..., tuning=True)); the product path never does.
+TUNING_LIB_PATH = os.environ.get("LSQ_TUNING_LIB_PATH") or os.path.join(_HERE, "liblsq_mi355x_tuning.so")
 
 LSQ_OK, LSQ_EINVAL, LSQ_EHIP, LSQ_ENOMEM, LSQ_ECODE, LSQ_ENODEV = 0, -1, -2, -3, -4, -5
 
@@ -22,7 +25,8 @@ class LsqError(RuntimeError):
 class Timings(C.Structure):
     _fields_ = [("tables_ms", C.c_double), ("unaries_ms", C.c_double), ("perturb_ms", C.c_double),
                 ("icm_ms", C.c_double), ("cost_ms", C.c_double), ("other_ms", C.c_double),
-                ("icm_launches", C.c_int64), ("icm_node_updates", C.c_int64)]
+                ("icm_launches", C.c_int64), ("icm_node_updates", C.c_int64),
+                ("staged_blocks", C.c_int64), ("light_blocks", C.c_int64), ("team_blocks", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -65,17 +69,17 @@ SIGNATURES = {
     "lsq_synth_codebooks_dev": (_i, [_vp, _u64, _i, _i, _i, _vp]),
 }
 
-_lib = None
+_libs = {}
 
 
-def load():
-    """Load the shared library (once).  Raises if it has not been built."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+def load(tuning=False):
+    """Load the shared library (once per flavour).  Raises if it has not been built."""
+    path = TUNING_LIB_PATH if tuning else LIB_PATH
+    if path not in _libs:
+        if not os.path.exists(path):
             raise RuntimeError(
                 "%s not found: the HIP extension is not built. Run `python -c \"import __graft_entry__ as g; "
-                "g.build()\"` -- there is no CPU fallback." % LIB_PATH)
+                "g.build()\"` -- there is no CPU fallback." % path)
         # torch bundles its own libamdhip64.so / libhsa-runtime64.so (SONAME libamdhip64.so.7).  Two HIP
         # runtimes in one process cannot both own the GPU ("No HIP GPUs are available" in whichever
         # initialises second), so when torch is installed it must be loaded FIRST: our DT_NEEDED
@@ -85,17 +89,17 @@ def load():
             import torch  # noqa: F401
         except ImportError:
             pass
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)       # AttributeError if the symbol is missing: loud by design
             fn.restype = res
             fn.argtypes = args
-        _lib = lib
-    return _lib
+        _libs[path] = lib
+    return _libs[path]
 
 
-def check(rc):
+def check(rc, lib=None):
     if rc != LSQ_OK:
-        msg = load().lsq_last_error()
+        msg = (lib or load()).lsq_last_error()      # thread-local inside the library that failed
         raise LsqError(rc, msg.decode("utf-8", "replace") if msg else "")
     return rc

@@ -72,7 +72,7 @@ struct lsq_ctx {
     hipEvent_t copy_done = nullptr;
     // timings
     double cat_ms[CAT_COUNT] = {0, 0, 0, 0, 0, 0};
-    int64_t icm_launches = 0, icm_node_updates = 0;
+    int64_t icm_launches = 0, icm_node_updates = 0, staged_blocks = 0, light_blocks = 0, team_blocks = 0;
     struct Pending { hipEvent_t a, b; int cat; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> pool;
@@ -171,11 +171,17 @@ extern "C" int lsq_set_option(lsq_ctx *c, const char *key, int64_t value) {
     } else if (!strcmp(key, "profile")) c->profile = value != 0;
     else if (!strcmp(key, "own_stream")) c->stream = c->own_stream;
     else if (!strcmp(key, "skip")) c->skip = value != 0;
-    else if (!strcmp(key, "ablation")) c->ablation = (int)value;
+#ifdef LSQ_TUNING
+    else if (!strcmp(key, "ablation")) c->ablation = (int)value;      // timing-only kernel variants: tuning build only
+#endif
     else if (!strcmp(key, "light")) c->light = (int)value;
     else if (!strcmp(key, "fallback")) c->fallback = (int)value;
     else if (!strcmp(key, "schedule")) {
+#ifdef LSQ_TUNING
         if (value < 0 || value > 4) { lsq_set_error("schedule must be 0..4"); return LSQ_EINVAL; }
+#else
+        if (value < 3 || value > 4) { lsq_set_error("schedule must be 3 or 4 (schedules 0..2 exist in the tuning build only)"); return LSQ_EINVAL; }
+#endif
         c->schedule = (int)value;
     } else { lsq_set_error("unknown option '%s'", key); return LSQ_EINVAL; }
     return LSQ_OK;
@@ -193,6 +199,9 @@ extern "C" int lsq_get_timings(lsq_ctx *c, lsq_timings *out) {
     out->other_ms = c->cat_ms[CAT_OTHER];
     out->icm_launches = c->icm_launches;
     out->icm_node_updates = c->icm_node_updates;
+    out->staged_blocks = c->staged_blocks;
+    out->light_blocks = c->light_blocks;
+    out->team_blocks = c->team_blocks;
     return LSQ_OK;
 }
 
@@ -200,7 +209,7 @@ extern "C" int lsq_reset_timings(lsq_ctx *c) {
     LSQ_TRY(use_device(c));
     LSQ_TRY(resolve_timings(c));
     for (double &v : c->cat_ms) v = 0.0;
-    c->icm_launches = c->icm_node_updates = 0;
+    c->icm_launches = c->icm_node_updates = c->staged_blocks = c->light_blocks = c->team_blocks = 0;
     return LSQ_OK;
 }
 
@@ -245,9 +254,22 @@ static int check_shape(const char *fn, int d, int64_t n, int m, int h) {
     return LSQ_OK;
 }
 
+// input codes must lie in 1..h (Julia 1-based).  A flat scan of n*m int16 (vectorised; ~1 ms per 10^6 x 8) done up front so
+// that an invalid call neither spends the encode nor clobbers the caller's output buffer.
+static int check_codes_host(const char *fn, const int16_t *B, int64_t n, int m, int h) {
+    const int64_t total = n * (int64_t)m;
+    unsigned bad = 0;
+    for (int64_t q = 0; q < total; ++q) bad |= (unsigned)((unsigned)(uint16_t)(B[q] - 1) >= (unsigned)h);
+    if (bad) { lsq_set_error("%s: input codes must lie in 1..%d", fn, h); return LSQ_ECODE; }
+    return LSQ_OK;
+}
+
 // ---- device core ----------------------------------------------------------------------------------
 static int u_slice_width(const lsq_ctx *c, int m) {      // layout of the unary planes for the active schedule
-    return c->schedule == 2 ? lsq_slice_width(m) : c->schedule >= 3 ? lsq_walk_slice_width(m) : 0;
+#ifdef LSQ_TUNING
+    if (c->schedule < 3) return c->schedule == 2 ? lsq_slice_width(m) : 0;
+#endif
+    return lsq_walk_slice_width(m);
 }
 
 static int prepare_tables(lsq_ctx *c, const float *dK, int d, int m) {
@@ -279,10 +301,27 @@ static int build_unaries(lsq_ctx *c, const float *dX, const float *dK, int d, in
 static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t cn, int m, const int32_t *order, int nsweeps,
                       const uint8_t *ref_rec = nullptr, const unsigned short *ref_valid = nullptr) {
     Timer t(c, CAT_ICM);
-    if (c->schedule == 1) {
-        LSQ_TRY(lsq_launch_icm_fused(c->stream, c->U.as<float>(), c->T.as<float>(), rec, cn, m, order, nsweeps));
-        c->icm_launches += 1;
-    } else if (c->schedule == 4) {
+#ifdef LSQ_TUNING
+    if (c->schedule < 3) {
+        if (c->schedule == 1) {
+            LSQ_TRY(lsq_launch_icm_fused(c->stream, c->U.as<float>(), c->T.as<float>(), rec, cn, m, order, nsweeps));
+            c->icm_launches += 1;
+        } else {
+            if (c->schedule == 2) LSQ_TRY(c->part.ensure(sizeof(float2) * (size_t)cn * (LSQ_H / lsq_slice_width(m))));
+            for (int sw = 0; sw < nsweeps; ++sw)
+                for (int q = 0; q < m; ++q) {
+                    const int j = order[q];
+                    const float *Uj = c->U.as<float>() + (int64_t)j * cn * LSQ_H;
+                    if (c->schedule == 2) LSQ_TRY(lsq_launch_icm_slice(c->stream, Uj, c->T.as<float>(), rec, c->part.as<float2>(), cn, m, j));
+                    else LSQ_TRY(lsq_launch_icm_node(c->stream, Uj, c->T.as<float>(), rec, cn, m, j));
+                }
+            c->icm_launches += (int64_t)nsweeps * m;
+        }
+        c->icm_node_updates += cn * (int64_t)nsweeps * m;
+        return LSQ_OK;
+    }
+#endif
+    if (c->schedule == 4) {
         // the whole ILS iteration (nsweeps x m node updates) in ONE launch: a block owns its vectors throughout
         std::vector<int32_t> seq((size_t)nsweeps * m);
         for (int sw = 0; sw < nsweeps; ++sw)
@@ -290,29 +329,13 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t c
         LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>(), c->Ts.as<float>(), c->T.as<float>(), rec, valid, cn, m, seq.data(), (int)seq.size(), c->skip,
                                     c->active.as<unsigned long long>(), c->ablation, c->light, c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr));
         c->icm_launches += ((int64_t)seq.size() + 63) / 64;
-    } else if (c->schedule >= 3) {
+    } else {
         for (int sw = 0; sw < nsweeps; ++sw)
             for (int q = 0; q < m; ++q)
                 LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>(), c->Ts.as<float>(), c->T.as<float>(), rec, valid, cn, m, &order[q], 1, c->skip,
                                             c->active.as<unsigned long long>(), c->ablation, c->light, c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr));
         c->icm_launches += (int64_t)nsweeps * m;
-    } else if (c->schedule == 2) {
-        LSQ_TRY(c->part.ensure(sizeof(float2) * (size_t)cn * (LSQ_H / lsq_slice_width(m))));
-        for (int sw = 0; sw < nsweeps; ++sw)
-            for (int q = 0; q < m; ++q) {
-                const int j = order[q];
-                LSQ_TRY(lsq_launch_icm_slice(c->stream, c->U.as<float>() + (int64_t)j * cn * LSQ_H, c->T.as<float>(), rec, c->part.as<float2>(), cn, m, j));
-            }
-        c->icm_launches += (int64_t)nsweeps * m;
-    } else {
-        for (int sw = 0; sw < nsweeps; ++sw)
-            for (int q = 0; q < m; ++q) {
-                const int j = order[q];
-                LSQ_TRY(lsq_launch_icm_node(c->stream, c->U.as<float>() + (int64_t)j * cn * LSQ_H, c->T.as<float>(), rec, cn, m, j));
-            }
-        c->icm_launches += (int64_t)nsweeps * m;
     }
-    if (c->schedule < 3) c->icm_node_updates += cn * (int64_t)nsweeps * m;      // schedule 3 counts on the device (skips)
     return LSQ_OK;
 }
 
@@ -380,8 +403,8 @@ static int begin_call(lsq_ctx *c, int64_t I, int nr) {
     LSQ_TRY(c->counters.ensure(sizeof(unsigned long long) * 2 * (size_t)std::max<int64_t>(I, 1)));
     LSQ_TRY(c->obj.ensure(sizeof(double) * (size_t)std::max(nr, 1)));
     LSQ_TRY(c->bad.ensure(sizeof(int)));
-    LSQ_TRY(c->active.ensure(sizeof(unsigned long long)));
-    LSQ_HIP(hipMemsetAsync(c->active.p, 0, sizeof(unsigned long long), c->stream));
+    LSQ_TRY(c->active.ensure(sizeof(unsigned long long) * LSQ_WALK_COUNTERS));
+    LSQ_HIP(hipMemsetAsync(c->active.p, 0, sizeof(unsigned long long) * LSQ_WALK_COUNTERS, c->stream));
     LSQ_HIP(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long) * 2 * (size_t)std::max<int64_t>(I, 1), c->stream));
     LSQ_HIP(hipMemsetAsync(c->obj.p, 0, sizeof(double) * (size_t)std::max(nr, 1), c->stream));
     LSQ_HIP(hipMemsetAsync(c->bad.p, 0, sizeof(int), c->stream));
@@ -392,10 +415,15 @@ static int finish_call(lsq_ctx *c, int64_t I, int nr, double *obj_sums, int64_t 
     std::vector<unsigned long long> cnt(2 * (size_t)std::max<int64_t>(I, 1));
     LSQ_HIP(hipMemcpyAsync(obj_sums, c->obj.p, sizeof(double) * (size_t)nr, hipMemcpyDeviceToHost, c->stream));
     LSQ_HIP(hipMemcpyAsync(cnt.data(), c->counters.p, sizeof(unsigned long long) * cnt.size(), hipMemcpyDeviceToHost, c->stream));
-    unsigned long long act = 0;
-    LSQ_HIP(hipMemcpyAsync(&act, c->active.p, sizeof(act), hipMemcpyDeviceToHost, c->stream));
+    unsigned long long act[LSQ_WALK_COUNTERS] = {0, 0, 0, 0};
+    LSQ_HIP(hipMemcpyAsync(act, c->active.p, sizeof(act), hipMemcpyDeviceToHost, c->stream));
     LSQ_HIP(hipStreamSynchronize(c->stream));
-    if (c->schedule >= 3) c->icm_node_updates += (int64_t)act;
+    if (c->schedule >= 3) {
+        c->icm_node_updates += (int64_t)act[0];
+        c->staged_blocks += (int64_t)act[1];
+        c->light_blocks += (int64_t)act[2];
+        c->team_blocks += (int64_t)act[3];
+    }
     if (stats) for (int64_t q = 0; q < 2 * I; ++q) stats[q] = (int64_t)cnt[(size_t)q];
     return LSQ_OK;
 }
@@ -439,6 +467,7 @@ static int encode_host(lsq_ctx *c, const char *fn, const float *X, const int16_t
     LSQ_TRY(validate_encode(fn, d, n, m, h, ilsiters, nr, icmiter, npert, &I));
     if (!K || (!objs && !place) || (n > 0 && (!X || !B || !Bs))) { lsq_set_error("%s: null pointer", fn); return LSQ_EINVAL; }
     const int64_t ntot = place ? place->ntot : n, row0 = place ? place->row0 : 0;
+    LSQ_TRY(check_codes_host(fn, B, n, m, h));      // before any device work: an invalid call costs nothing and never touches Bs
     LSQ_TRY(begin_call(c, I, nr));
     const size_t kbytes = sizeof(float) * (size_t)m * LSQ_H * d;
     LSQ_TRY(c->sK.ensure(kbytes));
@@ -636,7 +665,7 @@ extern "C" int lsq_encode_icm_fully(lsq_ctx *c, int16_t *B, const float *X, cons
     int32_t order[LSQ_MAX_M];
     LSQ_TRY(lsq_node_order(seed, it, m, randord, order));
     LSQ_TRY(c->vNew.ensure(sizeof(unsigned short) * (size_t)n));
-    LSQ_TRY(c->active.ensure(sizeof(unsigned long long)));
+    LSQ_TRY(c->active.ensure(sizeof(unsigned long long) * LSQ_WALK_COUNTERS));
     LSQ_HIP(hipMemsetAsync(c->vNew.p, 0, sizeof(unsigned short) * (size_t)n, c->stream));
     LSQ_TRY(lsq_launch_perturb(c->stream, c->recCur.as<uint8_t>(), c->recNew.as<uint8_t>(), n, m, npert, seed, it, (uint64_t)(idx_first - 1), nullptr, nullptr));
     LSQ_TRY(run_sweeps(c, c->recNew.as<uint8_t>(), c->vNew.as<unsigned short>(), n, m, order, niter));

@@ -187,8 +187,7 @@ int lsq_launch_chain_gemm(hipStream_t s, const float *A, const float *Bm, const 
     const int64_t blocks = ((row_tiles + 7) / 8) * 8 * col_tiles;
     if (blocks > 0x7fffffffLL) { lsq_set_error("chain_gemm: grid too large"); return LSQ_EINVAL; }
     const bool vec4 = (Kd % 4 == 0) && (((uintptr_t)A | (uintptr_t)Bm) % 16 == 0);
-    static int bk = -1;
-    if (bk < 0) { const char *e = getenv("LSQ_GEMM_BK"); bk = e ? atoi(e) : 16; }
+    const int bk = LSQ_KNOB("LSQ_GEMM_BK", 16);
     // K chunks of 8 or 16 only: both fit four resident blocks per CU (the kernel is compiled for 4 waves per SIMD)
     if (vec4 && bk == 8)
         hipLaunchKernelGGL((chain_gemm_kernel<true, 8>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,

@@ -1,9 +1,9 @@
-// lsq_icm.hip -- the ILS/ICM encoder kernels for gfx950 (wave64, one wave per vector).
+// lsq_icm.hip -- the ILS/ICM encoder kernels for gfx950 (wave64).
 //
 // Replaces (does NOT translate) the reference's CUDA kernels src/encodings/cuda/cudautils.cu:
-//   condition_icm3 (:236-339)  -> icm_node_kernel / icm_fused_kernel
+//   condition_icm3 (:236-339)  -> icm_walk_kernel  (LDS-staged table slices, slice-major unary stream)
 //   perturb        (:27-80)    -> perturb_kernel   (Philox counter RNG, no state buffer)
-//   veccost2       (:145-183)  -> cost_kernel      (fused with the accept rule)
+//   veccost2       (:145-183)  -> cost_kernel / cost2_kernel (fused with the accept rule)
 //   setup_kernel / vec_add     -> gone (counter-based RNG; ||c||^2 is the GEMM epilogue)
 // Semantics follow the reference CPU path (src/encodings/encode_icm.jl), restated in
 // oracle/lsq_oracle.c: conditioning adds in ascending k (plain f32 adds), argmin = LOWEST index
@@ -11,297 +11,22 @@
 // better.
 //
 // Data layout in HBM:
-//   U   [m][n][256] f32   unary rows; U_j[i] is one 1 KiB wave load (float4 per lane)
+//   U   [m][256/SL][n][SL] f32  slice-major unary planes: one wave load = 1 KiB = 64/(SL/4) vectors x SL candidates
 //   T   [m][m][256][256] f32; T[j][k][b][:] = the 1 KiB column added to node j when codebook k
-//       holds code b.  Block-row j (all k, b) is ONE contiguous 256 KiB*m region, so the live set
-//       of a node-j launch is (m-1) x 256 KiB, L2-resident per XCD (1.75 MiB at m = 8).
+//       holds code b (row-major; light blocks gather whole columns from L2)
+//   Ts  [m][256/SL][m-1][256][SL] f32: the same columns regrouped per slice (one contiguous block per staged slice)
 //   rec [n][cs] u8        code records, cs = 8 (m <= 8) or 16: one aligned 8/16-byte load
 //   X   [n][d] f32,  K [m*256][d] f32  (the Julia buffers, read in place)
-//
-// One wave = one vector: lane l owns candidates 4l..4l+3; a table column or unary row is exactly
-// one coalesced `global_load_dwordx4`.  The wave-level argmin is a 6-step DPP min + one ballot.
+// The three earlier schedules (per-node L2 gathers, fused sweeps, slices + combine) live in lsq_icm_legacy.hip and are
+// compiled into the tuning build only.
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
 
-#include "lsq_internal.h"
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "lsq_wave.h"
 
 namespace {
-
-// ---- wave64 cross-lane helpers (DPP; no LDS traffic) -------------------------------------------
-template <int CTRL, int ROW_MASK>
-__device__ inline float dpp_self(float v) {          // disabled lanes keep their own value
-    const int iv = __float_as_int(v);
-    return __int_as_float(__builtin_amdgcn_update_dpp(iv, iv, CTRL, ROW_MASK, 0xf, false));
-}
-template <int CTRL, int ROW_MASK>
-__device__ inline float dpp_zero(float v) {          // disabled lanes receive +0
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
-}
-
-enum { DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140, DPP_BCAST15 = 0x142, DPP_BCAST31 = 0x143 };
-
-// minimum over the 64 lanes (NaN-ignoring, like the reference's strict-< scan), wave-uniform result
-__device__ inline float wave_min(float v) {
-    v = fminf(v, dpp_self<DPP_XOR1, 0xf>(v));
-    v = fminf(v, dpp_self<DPP_XOR2, 0xf>(v));
-    v = fminf(v, dpp_self<DPP_HALF_MIRROR, 0xf>(v));
-    v = fminf(v, dpp_self<DPP_MIRROR, 0xf>(v));
-    v = fminf(v, dpp_self<DPP_BCAST15, 0xa>(v));
-    v = fminf(v, dpp_self<DPP_BCAST31, 0xc>(v));
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-
-// sum over the 64 lanes as a balanced pairwise tree, adjacent pairs first -- the exact order
-// of oracle cost_one() ([build-defined 2]); f32 add is commutative so the mirrored DPP sources
-// give the same bits.  Result valid in lane 63, returned wave-uniform.
-__device__ inline float wave_sum_tree(float v) {
-    v = v + dpp_self<DPP_XOR1, 0xf>(v);
-    v = v + dpp_self<DPP_XOR2, 0xf>(v);
-    v = v + dpp_self<DPP_HALF_MIRROR, 0xf>(v);
-    v = v + dpp_self<DPP_MIRROR, 0xf>(v);
-    v = v + dpp_zero<DPP_BCAST15, 0xa>(v);
-    v = v + dpp_zero<DPP_BCAST31, 0xc>(v);
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-
-__device__ inline uint64_t readfirstlane64(uint64_t v) {
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    return ((uint64_t)hi << 32) | lo;
-}
-
-struct CodeRec {           // wave-uniform code record (lives in SGPRs)
-    uint64_t lo, hi;
-    __device__ inline uint32_t get(int k) const { return (uint32_t)((k < 8 ? lo >> (8 * k) : hi >> (8 * (k - 8))) & 0xffu); }
-    __device__ inline void set(int k, uint32_t v) {
-        if (k < 8) lo = (lo & ~(0xffull << (8 * k))) | ((uint64_t)v << (8 * k));
-        else       hi = (hi & ~(0xffull << (8 * (k - 8)))) | ((uint64_t)v << (8 * (k - 8)));
-    }
-};
-
-template <int CS>
-__device__ inline CodeRec load_rec(const uint8_t *rec, int64_t i) {
-    CodeRec r;
-    const uint64_t *p = reinterpret_cast<const uint64_t *>(rec + i * CS);
-    r.lo = readfirstlane64(p[0]);
-    r.hi = (CS == 16) ? readfirstlane64(p[1]) : 0ull;
-    return r;
-}
-
-// lowest index of the minimum of the wave's 256 conditioned values (encode_icm.jl:105-119)
-__device__ inline int wave_first_argmin(f32x4 s, int lane) {
-    const float lm = fminf(fminf(s.x, s.y), fminf(s.z, s.w));
-    const float wm = wave_min(lm);
-    const int inl = (s.x == wm) ? 0 : (s.y == wm) ? 1 : (s.z == wm) ? 2 : 3;
-    const uint64_t mask = __ballot(lm == wm);
-    int best = 0;
-    if (mask != 0) {
-        const int L = __builtin_ctzll(mask);
-        best = 4 * L + __builtin_amdgcn_readlane(inl, L);
-    }
-    // strict '<' scan semantics: if s[0] is NaN nothing ever replaces it
-    const float s0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s.x)));
-    if (s0 != s0) best = 0;
-    (void)lane;
-    return best;
-}
-
-// ---- ICM node update, one launch per node (schedule 0) -----------------------------------------
-// Streams U_j (1 KiB/vector, non-temporal) from HBM, gathers (M-1) 1 KiB columns of block-row j
-// from L2, writes one code byte.  encode_icm.jl:76-119 for all vectors of the chunk.
-template <int M>
-__global__ __launch_bounds__(256) void icm_node_kernel(const float *__restrict__ Uj, const float *__restrict__ Tj,
-                                                       uint8_t *__restrict__ rec, int64_t n, int j) {
-    constexpr int CS = (M <= 8) ? 8 : 16;
-    const int lane = threadIdx.x & 63;
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
-    int64_t i = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-    for (; i < n; i += nwaves) {
-        const CodeRec cr = load_rec<CS>(rec, i);
-        f32x4 s = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(Uj + i * LSQ_H) + lane);
-        f32x4 c[M > 1 ? M - 1 : 1];
-#pragma unroll
-        for (int kk = 0; kk < M - 1; ++kk) {
-            const int k = kk + (kk >= j ? 1 : 0);
-            const float *col = Tj + ((int64_t)(k * LSQ_H) + cr.get(k)) * LSQ_H;
-            c[kk] = reinterpret_cast<const f32x4 *>(col)[lane];
-        }
-#pragma unroll
-        for (int kk = 0; kk < M - 1; ++kk) s = s + c[kk];      // ascending k, plain f32 adds
-        const int best = wave_first_argmin(s, lane);
-        if (lane == 0) rec[i * CS + j] = (uint8_t)best;
-    }
-}
-
-// ---- fused sweeps (schedule 1): unaries register-resident, all nsweeps*M node updates ---------
-struct NodeOrder { int v[LSQ_MAX_M]; };
-
-template <int M, int J>
-__device__ inline void fused_node(const f32x4 (&u)[M], const float *__restrict__ T, CodeRec &cr, int lane) {
-    f32x4 s = u[J];
-    f32x4 c[M > 1 ? M - 1 : 1];
-    const float *Tj = T + (int64_t)J * M * LSQ_H * LSQ_H;
-#pragma unroll
-    for (int kk = 0; kk < M - 1; ++kk) {
-        constexpr int dummy = 0; (void)dummy;
-        const int k = kk + (kk >= J ? 1 : 0);
-        const float *col = Tj + ((int64_t)(k * LSQ_H) + cr.get(k)) * LSQ_H;
-        c[kk] = reinterpret_cast<const f32x4 *>(col)[lane];
-    }
-#pragma unroll
-    for (int kk = 0; kk < M - 1; ++kk) s = s + c[kk];
-    cr.set(J, (uint32_t)wave_first_argmin(s, lane));
-}
-
-template <int M, int J>
-struct FusedDispatch {
-    __device__ static inline void run(int j, const f32x4 (&u)[M], const float *T, CodeRec &cr, int lane) {
-        if (j == J) fused_node<M, J>(u, T, cr, lane);
-        else FusedDispatch<M, J + 1>::run(j, u, T, cr, lane);
-    }
-};
-template <int M>
-struct FusedDispatch<M, M> {
-    __device__ static inline void run(int, const f32x4 (&)[M], const float *, CodeRec &, int) {}
-};
-
-template <int M>
-__global__ __launch_bounds__(256) void icm_fused_kernel(const float *__restrict__ U, const float *__restrict__ T,
-                                                        uint8_t *__restrict__ rec, int64_t n, NodeOrder order, int nsweeps) {
-    constexpr int CS = (M <= 8) ? 8 : 16;
-    const int lane = threadIdx.x & 63;
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
-    int64_t i = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-    for (; i < n; i += nwaves) {
-        CodeRec cr = load_rec<CS>(rec, i);
-        f32x4 u[M];
-#pragma unroll
-        for (int j = 0; j < M; ++j)
-            u[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(U + ((int64_t)j * n + i) * LSQ_H) + lane);
-        for (int sw = 0; sw < nsweeps; ++sw)
-#pragma unroll 1
-            for (int q = 0; q < M; ++q) FusedDispatch<M, 0>::run(order.v[q], u, T, cr, lane);
-        if (lane == 0) {
-            uint64_t *p = reinterpret_cast<uint64_t *>(rec + i * CS);
-            p[0] = cr.lo;
-            if (CS == 16) p[1] = cr.hi;
-        }
-    }
-}
-
-// ---- LDS-slice schedule (schedule 2) ---------------------------------------------------------------
-// Why: on gfx950 the HBM-miss stream of U_j and the L2-hit table gathers of icm_node_kernel do not
-// overlap -- their times ADD (measured: 164 us + 240 us -> 470 us per 10^6-vector launch; tools/
-// ubench_icm.hip).  So the vector-memory path is given to the U stream alone and the
-// table columns come from LDS:
-//   * a 1024-thread block owns one SLICE of SL candidates (16 for m <= 10, 8 above) of node j and
-//     stages T_j[k][b][a0..a0+SL) for all k != j, b into LDS: (m-1)*256*SL*4 B (112 KiB at m = 8);
-//   * U_j is stored slice-major, Us[slice][i][SL], so one wave load = 1 KiB contiguous = 64/(SL/4)
-//     vectors x SL candidates (lane = (SL/4)*v + q: candidates 4q..4q+3 of vector v);
-//   * per vector the block emits the partial (min, index-in-slice) of its SL candidates; a second
-//     tiny kernel (icm_combine_kernel) takes the lowest-index global minimum over the 256/SL slices.
-// Conditioning order, plain f32 adds and first-index argmin are exactly those of icm_node_kernel.
-template <int M, int SL>
-__global__ __launch_bounds__(1024) void icm_slice_kernel(const float *__restrict__ Usj, const float *__restrict__ Tj,
-                                                         const uint8_t *__restrict__ rec, float2 *__restrict__ part,
-                                                         int64_t n, int j, int nranges) {
-    constexpr int CS = (M <= 8) ? 8 : 16;
-    constexpr int NS = LSQ_H / SL;          // slices
-    constexpr int LPV = SL / 4;             // lanes per vector
-    constexpr int VPW = 64 / LPV;           // vectors per wave iteration
-    constexpr int CW = (M - 1 + 3) / 4;     // compacted code words (conditioning codes in ascending k, j skipped)
-    constexpr int RW = CS / 4;              // record words
-    extern __shared__ f32x4 lds_tab[];      // [(M-1)*256][LPV]
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int slice = blockIdx.x % NS, range = blockIdx.x / NS;
-
-    for (int e = threadIdx.x; e < (M - 1) * LSQ_H * LPV; e += 1024) {
-        const int q = e % LPV, eb = e / LPV, kk = eb >> 8, b = eb & 255;
-        const int k = kk + (kk >= j ? 1 : 0);
-        lds_tab[e] = *reinterpret_cast<const f32x4 *>(Tj + ((int64_t)(k * LSQ_H) + b) * LSQ_H + slice * SL + q * 4);
-    }
-    // v_perm_b32 selectors: compact word w takes bytes k(4w..4w+3) - 4w (0..4) of record words (w, w+1)
-    uint32_t sel[CW > 0 ? CW : 1];
-#pragma unroll
-    for (int w = 0; w < CW; ++w) {
-        uint32_t sv = 0;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int kk = 4 * w + t;
-            const int k = kk + (kk >= j ? 1 : 0);
-            sv |= (uint32_t)((kk < M - 1 ? k - 4 * w : 0) & 7) << (8 * t);
-        }
-        sel[w] = sv;
-    }
-    __syncthreads();
-
-    const int64_t per = (n + nranges - 1) / nranges;
-    const int64_t lo = range * per, hi = (lo + per < n) ? lo + per : n;
-    const int v = lane / LPV, q = lane % LPV;
-    const float *Ub = Usj + (int64_t)slice * n * SL;
-    const int64_t step = 16 * VPW;
-
-    struct Item { f32x4 u; uint32_t r[RW]; };
-    auto load_item = [&](int64_t i0, Item &it) {
-        const int64_t i = i0 + v;
-        if (i < hi) {
-            it.u = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(Ub + i * SL) + q);
-            const uint32_t *rp = reinterpret_cast<const uint32_t *>(rec + i * CS);
-#pragma unroll
-            for (int w = 0; w < RW; ++w) it.r[w] = rp[w];
-        } else {
-            it.u = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int w = 0; w < RW; ++w) it.r[w] = 0u;
-        }
-    };
-
-    int64_t i0 = lo + (int64_t)wave * VPW;
-    Item a, b;
-    load_item(i0, a);
-    load_item(i0 + step, b);
-    for (; i0 < hi; i0 += step) {
-        const Item cur = a;
-        a = b;
-        load_item(i0 + 2 * step, b);          // two iterations of U in flight per wave
-
-        f32x4 s = cur.u;
-#pragma unroll
-        for (int w = 0; w < CW; ++w) {
-            const uint32_t hiw = (w + 1 < RW) ? cur.r[w + 1] : 0u;
-            const uint32_t cw = __builtin_amdgcn_perm(hiw, cur.r[w], sel[w]);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int kk = 4 * w + t;
-                if (kk < M - 1) {
-                    const uint32_t code = (cw >> (8 * t)) & 0xffu;
-                    s = s + lds_tab[(kk * LSQ_H + code) * LPV + q];      // ascending k, plain f32 add
-                }
-            }
-        }
-        // partial first-argmin over this vector's SL candidates: in-lane 4, then across its LPV lanes
-        float lm = fminf(fminf(s.x, s.y), fminf(s.z, s.w));
-        int li = ((s.x == lm) ? 0 : (s.y == lm) ? 1 : (s.z == lm) ? 2 : 3) + 4 * q;
-        if (lm != lm) { lm = __builtin_inff(); li = 1000; }              // all-NaN lane: never wins
-        if (slice == 0 && q == 0 && s.x != s.x) { lm = -__builtin_inff(); li = 0; }   // s[0] NaN: strict-< scan keeps index 0
-        {
-            float ov = dpp_self<DPP_XOR1, 0xf>(lm);
-            int oi = __builtin_amdgcn_update_dpp(li, li, DPP_XOR1, 0xf, 0xf, false);
-            if (ov < lm || (ov == lm && oi < li)) { lm = ov; li = oi; }
-            if (LPV == 4) {
-                ov = dpp_self<DPP_XOR2, 0xf>(lm);
-                oi = __builtin_amdgcn_update_dpp(li, li, DPP_XOR2, 0xf, 0xf, false);
-                if (ov < lm || (ov == lm && oi < li)) { lm = ov; li = oi; }
-            }
-        }
-        if (q == 0 && i0 + v < hi) part[(int64_t)slice * n + i0 + v] = make_float2(lm, __int_as_float(li));
-    }
-}
 
 // vectors per block pass of the LDS-walk kernel: table + 10 B per vector must fit the 160 KiB LDS
 constexpr int lsq_walk_pp(int M, int SL) {
@@ -429,7 +154,10 @@ __global__ __launch_bounds__(NT) void icm_walk_kernel(const float *__restrict__ 
         }
         const int nact = nact_s;
         if (nact == 0) { __syncthreads(); continue; }          // block-uniform (the barrier protects nact_s / wave_tot reuse)
-        if (threadIdx.x == 0 && active_total) atomicAdd(active_total, (unsigned long long)nact);
+        if (threadIdx.x == 0 && active_total) {            // [0] node updates recomputed, [1] staged / [2] light block-node-updates
+            atomicAdd(active_total, (unsigned long long)nact);
+            atomicAdd(active_total + (nact <= direct_max ? 2 : 1), 1ull);
+        }
         if (nact <= direct_max) {
             // LIGHT block (few active vectors: small n, or a late sweep): staging the whole (m-1) x 256 KiB table through
             // LDS would cost more than the vectors need.  One wave per vector instead, the (m-1) 1 KiB table columns
@@ -625,22 +353,6 @@ __global__ __launch_bounds__(256) void tables_to_slices_kernel(const float *__re
     const int k = kk + (kk >= j ? 1 : 0);
     reinterpret_cast<f32x4 *>(Ts)[e] =
         *reinterpret_cast<const f32x4 *>(T + (((int64_t)j * m + k) * LSQ_H + b) * LSQ_H + slice * SL + qq * 4);
-}
-
-template <int SL>
-__global__ __launch_bounds__(256) void icm_combine_kernel(const float2 *__restrict__ part, uint8_t *__restrict__ rec, int64_t n, int cs, int j) {
-    constexpr int NS = LSQ_H / SL;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float2 p = part[i];
-    float best = p.x;
-    int bi = __float_as_int(p.y);
-#pragma unroll
-    for (int sl = 1; sl < NS; ++sl) {
-        p = part[(int64_t)sl * n + i];
-        if (p.x < best) { best = p.x; bi = SL * sl + __float_as_int(p.y); }      // strict <: lowest slice wins ties
-    }
-    rec[i * cs + j] = (uint8_t)(bi > 255 ? 0 : bi);
 }
 
 // ---- perturbation (cudautils.cu:27-80 / encode_icm.jl:55-70), one thread per vector ------------
@@ -976,7 +688,26 @@ inline unsigned wave_grid(int64_t n) {      // persistent grid: 4 waves per bloc
 }
 inline unsigned thread_grid(int64_t n) { return (unsigned)((n + 255) / 256); }
 
+// One-time, per-device opt-in to > 64 KiB of dynamic LDS for one kernel instantiation.  lsq_multi_* runs one host thread
+// per device through the launchers, so the "done" flags are guarded (unsynchronised function-local statics).
+struct LdsOptIn {
+    std::mutex mu;
+    bool done[64] = {};
+};
+template <class Kern>
+int optin_lds(LdsOptIn &st, Kern kernel, int bytes) {
+    int dev = 0;
+    LSQ_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(st.mu);
+    if (dev < 0 || dev >= 64 || !st.done[dev]) {
+        LSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        if (dev >= 0 && dev < 64) st.done[dev] = true;
+    }
+    return LSQ_OK;
+}
+
 }  // namespace
+
 
 #define LSQ_DISPATCH_M(m, EXPR)                                                              \
     switch (m) {                                                                             \
@@ -991,48 +722,6 @@ inline unsigned thread_grid(int64_t n) { return (unsigned)((n + 255) / 256); }
         default: lsq_set_error("m = %d out of range 1..16", m); return LSQ_EINVAL;          \
     }
 
-int lsq_launch_icm_node(hipStream_t s, const float *Uj, const float *T, uint8_t *rec, int64_t n, int m, int j) {
-    if (n <= 0) return LSQ_OK;
-    const float *Tj = T + (int64_t)j * m * LSQ_H * LSQ_H;
-    LSQ_DISPATCH_M(m, hipLaunchKernelGGL(icm_node_kernel<M_>, dim3(wave_grid(n)), dim3(256), 0, s, Uj, Tj, rec, n, j));
-    LSQ_HIP(hipGetLastError());
-    return LSQ_OK;
-}
-
-int lsq_launch_icm_fused(hipStream_t s, const float *U, const float *T, uint8_t *rec, int64_t n, int m,
-                         const int32_t *order_host, int nsweeps) {
-    if (n <= 0) return LSQ_OK;
-    NodeOrder o;
-    for (int q = 0; q < LSQ_MAX_M; ++q) o.v[q] = q < m ? order_host[q] : 0;
-    LSQ_DISPATCH_M(m, hipLaunchKernelGGL(icm_fused_kernel<M_>, dim3(wave_grid(n)), dim3(256), 0, s, U, T, rec, n, o, nsweeps));
-    LSQ_HIP(hipGetLastError());
-    return LSQ_OK;
-}
-
-template <int M, int SL>
-static int launch_slice_t(hipStream_t s, const float *Usj, const float *Tj, uint8_t *rec, float2 *part, int64_t n, int j) {
-    constexpr int NS = LSQ_H / SL;
-    constexpr int LDS_BYTES = (M - 1) * LSQ_H * SL * 4;
-    static bool attr_set[64] = {false};
-    int dev = 0;
-    LSQ_HIP(hipGetDevice(&dev));
-    if (dev < 64 && !attr_set[dev]) {      // > 64 KiB of dynamic LDS needs the opt-in (per device)
-        LSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&icm_slice_kernel<M, SL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set[dev] = true;
-    }
-    const int64_t per_iter = 16 * (64 / (SL / 4));            // vectors per block iteration
-    int64_t nranges = (n + 4 * per_iter - 1) / (4 * per_iter);
-    const int64_t max_ranges = 512 / NS;                       // ~2 blocks per CU over the launch (1 resident: LDS)
-    if (nranges > max_ranges) nranges = max_ranges;
-    if (nranges < 1) nranges = 1;
-    hipLaunchKernelGGL((icm_slice_kernel<M, SL>), dim3((unsigned)(NS * nranges)), dim3(1024), LDS_BYTES, s, Usj, Tj, rec, part, n, j, (int)nranges);
-    LSQ_HIP(hipGetLastError());
-    const int cs = (M <= 8) ? 8 : 16;
-    hipLaunchKernelGGL((icm_combine_kernel<SL>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, rec, n, cs, j);
-    LSQ_HIP(hipGetLastError());
-    return LSQ_OK;
-}
-
 template <int M, int SL, int ABL = 0, int DEPTH = 2, int NT = 1024>
 static int launch_walk_t(hipStream_t s, const float *U, const float *Ts, const float *T, uint8_t *rec, unsigned short *valid, int64_t n,
                          const WalkNodes &nodes, int use_skip, unsigned long long *active_total, int light,
@@ -1041,22 +730,16 @@ static int launch_walk_t(hipStream_t s, const float *U, const float *Ts, const f
     constexpr int PP = LSQ_WALK_PP(M, SL);
     constexpr int LDS_BYTES = TAB * 16 + PP * 8 + PP * 2;                // slice table + packed running best + active list
     static_assert(LDS_BYTES + 256 <= 160 * 1024, "slice table + running best must fit the 160 KiB LDS");
-    static bool attr_set[64] = {false};
-    int dev = 0;
-    LSQ_HIP(hipGetDevice(&dev));
-    if (dev < 64 && !attr_set[dev]) {
-        LSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&icm_walk_kernel<M, SL, ABL, DEPTH, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set[dev] = true;
-    }
+    static LdsOptIn optin;
+    LSQ_TRY(optin_lds(optin, &icm_walk_kernel<M, SL, ABL, DEPTH, NT>, LDS_BYTES));
     const int64_t rounds = (n + 256 * (int64_t)PP - 1) / (256 * (int64_t)PP);          // passes per CU
     int64_t per_pass = (n + 256 * rounds - 1) / (256 * rounds);
     if (per_pass > PP) per_pass = PP;
     if (per_pass < 1) per_pass = 1;
     const int64_t npass = (n + per_pass - 1) / per_pass;
     const unsigned grid = (unsigned)(npass < 256 ? npass : 256);
-    static int direct_def = -1;          // blocks with at most this many active vectors gather from L2 instead of staging (option "light")
-    if (direct_def < 0) { const char *e = getenv("LSQ_WALK_DIRECT"); direct_def = e ? atoi(e) : 256; }
-    const int direct_max = light >= 0 ? light : direct_def;
+    // blocks with at most this many active vectors gather from L2 instead of staging (option "light"; thresholds 96..1024 measured)
+    const int direct_max = light >= 0 ? light : LSQ_KNOB("LSQ_WALK_DIRECT", 256);
     hipLaunchKernelGGL((icm_walk_kernel<M, SL, ABL, DEPTH, NT>), dim3(grid), dim3(NT), LDS_BYTES, s, U, Ts, T, rec, valid, n, nodes, (int)per_pass,
                        (use_skip && valid) ? 1 : 0, (T && ABL == 0) ? direct_max : 0, active_total, (use_skip && valid) ? ref_rec : nullptr,
                        (use_skip && valid) ? ref_valid : nullptr);
@@ -1065,9 +748,7 @@ static int launch_walk_t(hipStream_t s, const float *U, const float *Ts, const f
 }
 
 int lsq_walk_slice_width(int m) {
-    static int forced = -1;
-    if (forced < 0) { const char *e = getenv("LSQ_WALK_SL"); forced = (e && atoi(e) == 8) ? 8 : 0; }
-    return (m <= 8 && forced != 8) ? 16 : 8;
+    return (m <= 8 && LSQ_KNOB("LSQ_WALK_SL", 16) != 8) ? 16 : 8;
 }
 
 // `order[nnodes]`: the node updates to run back to back inside the launch (1 = one node; icmiter*m = a whole ILS iteration)
@@ -1076,8 +757,6 @@ int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const fl
                         const uint8_t *ref_rec, const unsigned short *ref_valid) {
     if (n <= 0 || nnodes <= 0) return LSQ_OK;
     if (m < 1 || m > LSQ_MAX_M) { lsq_set_error("m = %d out of range 1..16", m); return LSQ_EINVAL; }
-    static int big_nt = -1;              // block size for m >= 14 (tuning knob LSQ_WALK_BIG_NT=1024 restores the old shape)
-    if (big_nt < 0) { const char *e = getenv("LSQ_WALK_BIG_NT"); big_nt = (e && atoi(e) == 1024) ? 1024 : 512; }
     for (int done = 0; done < nnodes; done += LSQ_WALK_MAX_NODES) {
         WalkNodes nodes;
         nodes.count = (nnodes - done < LSQ_WALK_MAX_NODES) ? nnodes - done : LSQ_WALK_MAX_NODES;
@@ -1089,34 +768,36 @@ int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const fl
         // m >= 14: up to 15 table reads in flight + 8 staged table registers per thread do not fit 128 VGPRs (measured at
         // m = 16: 67..100 spilled registers, 1.5..2.5x slower) -> 512-thread blocks (256 VGPRs per wave), more U items in
         // flight instead.  m = 9..13 fit (<= 4 spills) and are 3-5 % faster with 1024 threads (measured for every m).
-#define LSQ_WALK_CASE_MID(MM) case MM: LSQ_TRY((launch_walk_t<MM, 8, 0, 2>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light, ref_rec, ref_valid))); break;
-#define LSQ_WALK_CASE_BIG(MM) case MM: \
-            if (big_nt == 512) LSQ_TRY((launch_walk_t<MM, 8, 0, 4, 512>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light, ref_rec, ref_valid))); \
-            else LSQ_TRY((launch_walk_t<MM, 8>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light, ref_rec, ref_valid))); \
-            break;
-#define LSQ_WALK_CASE(MM, SLL) case MM: LSQ_TRY((launch_walk_t<MM, SLL, 0, 3>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light, ref_rec, ref_valid))); break;
+#define LSQ_WALK_ARGS s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light, ref_rec, ref_valid
+#define LSQ_WALK_CASE_MID(MM) case MM: LSQ_TRY((launch_walk_t<MM, 8, 0, 2>(LSQ_WALK_ARGS))); break;
+#define LSQ_WALK_CASE_BIG(MM) case MM: LSQ_TRY((launch_walk_t<MM, 8, 0, 4, 512>(LSQ_WALK_ARGS))); break;
+#define LSQ_WALK_CASE(MM, SLL) case MM: LSQ_TRY((launch_walk_t<MM, SLL, 0, 3>(LSQ_WALK_ARGS))); break;
+#ifdef LSQ_TUNING      // timing-only variants and alternative shapes: profiling library only (results of the ablations are garbage)
+        bool handled = true;
         if (m <= 8 && lsq_walk_slice_width(m) == 8) {
             switch (m) {
                 LSQ_WALK_CASE(1, 8) LSQ_WALK_CASE(2, 8) LSQ_WALK_CASE(3, 8) LSQ_WALK_CASE(4, 8)
                 LSQ_WALK_CASE(5, 8) LSQ_WALK_CASE(6, 8) LSQ_WALK_CASE(7, 8) LSQ_WALK_CASE(8, 8)
             }
-        } else if (m == 8 && ablation == 1) {
-            LSQ_TRY((launch_walk_t<8, 16, 1>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light, ref_rec, ref_valid)));
-        } else if (m == 8 && ablation == 2) {
-            LSQ_TRY((launch_walk_t<8, 16, 2>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light, ref_rec, ref_valid)));
-        } else if (m == 8 && ablation == 3) {
-            LSQ_TRY((launch_walk_t<8, 16, 3>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light, ref_rec, ref_valid)));
-        } else if (m == 8 && ablation == 4) {
-            LSQ_TRY((launch_walk_t<8, 16, 4>(s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light, ref_rec, ref_valid)));
-
-        } else {
-            switch (m) {
-                LSQ_WALK_CASE(1, 16) LSQ_WALK_CASE(2, 16) LSQ_WALK_CASE(3, 16) LSQ_WALK_CASE(4, 16)
-                LSQ_WALK_CASE(5, 16) LSQ_WALK_CASE(6, 16) LSQ_WALK_CASE(7, 16) LSQ_WALK_CASE(8, 16)
-                LSQ_WALK_CASE_MID(9) LSQ_WALK_CASE_MID(10) LSQ_WALK_CASE_MID(11) LSQ_WALK_CASE_MID(12)
-                LSQ_WALK_CASE_MID(13) LSQ_WALK_CASE_BIG(14) LSQ_WALK_CASE_BIG(15) LSQ_WALK_CASE_BIG(16)
-            }
+        } else if (m == 8 && ablation == 1) { LSQ_TRY((launch_walk_t<8, 16, 1>(LSQ_WALK_ARGS)));
+        } else if (m == 8 && ablation == 2) { LSQ_TRY((launch_walk_t<8, 16, 2>(LSQ_WALK_ARGS)));
+        } else if (m == 8 && ablation == 3) { LSQ_TRY((launch_walk_t<8, 16, 3>(LSQ_WALK_ARGS)));
+        } else if (m == 8 && ablation == 4) { LSQ_TRY((launch_walk_t<8, 16, 4>(LSQ_WALK_ARGS)));
+        } else if (m >= 14 && LSQ_KNOB("LSQ_WALK_BIG_NT", 512) == 1024) {
+            switch (m) { case 14: LSQ_TRY((launch_walk_t<14, 8>(LSQ_WALK_ARGS))); break; case 15: LSQ_TRY((launch_walk_t<15, 8>(LSQ_WALK_ARGS))); break;
+                         case 16: LSQ_TRY((launch_walk_t<16, 8>(LSQ_WALK_ARGS))); break; }
+        } else handled = false;
+        if (handled) continue;
+#else
+        (void)ablation;
+#endif
+        switch (m) {
+            LSQ_WALK_CASE(1, 16) LSQ_WALK_CASE(2, 16) LSQ_WALK_CASE(3, 16) LSQ_WALK_CASE(4, 16)
+            LSQ_WALK_CASE(5, 16) LSQ_WALK_CASE(6, 16) LSQ_WALK_CASE(7, 16) LSQ_WALK_CASE(8, 16)
+            LSQ_WALK_CASE_MID(9) LSQ_WALK_CASE_MID(10) LSQ_WALK_CASE_MID(11) LSQ_WALK_CASE_MID(12)
+            LSQ_WALK_CASE_MID(13) LSQ_WALK_CASE_BIG(14) LSQ_WALK_CASE_BIG(15) LSQ_WALK_CASE_BIG(16)
         }
+#undef LSQ_WALK_ARGS
 #undef LSQ_WALK_CASE
 #undef LSQ_WALK_CASE_BIG
 #undef LSQ_WALK_CASE_MID
@@ -1132,30 +813,6 @@ int lsq_launch_tables_to_slices(hipStream_t s, const float *T, float *Ts, int m,
     else hipLaunchKernelGGL(tables_to_slices_kernel<8>, dim3(grid), dim3(256), 0, s, T, Ts, m);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
-}
-
-int lsq_launch_icm_slice(hipStream_t s, const float *Usj, const float *T, uint8_t *rec, float2 *part, int64_t n, int m, int j) {
-    if (n <= 0) return LSQ_OK;
-    const float *Tj = T + (int64_t)j * m * LSQ_H * LSQ_H;
-    switch (m) {
-        case 1: return launch_slice_t<1, 16>(s, Usj, Tj, rec, part, n, j);
-        case 2: return launch_slice_t<2, 16>(s, Usj, Tj, rec, part, n, j);
-        case 3: return launch_slice_t<3, 16>(s, Usj, Tj, rec, part, n, j);
-        case 4: return launch_slice_t<4, 16>(s, Usj, Tj, rec, part, n, j);
-        case 5: return launch_slice_t<5, 16>(s, Usj, Tj, rec, part, n, j);
-        case 6: return launch_slice_t<6, 16>(s, Usj, Tj, rec, part, n, j);
-        case 7: return launch_slice_t<7, 16>(s, Usj, Tj, rec, part, n, j);
-        case 8: return launch_slice_t<8, 16>(s, Usj, Tj, rec, part, n, j);
-        case 9: return launch_slice_t<9, 16>(s, Usj, Tj, rec, part, n, j);
-        case 10: return launch_slice_t<10, 16>(s, Usj, Tj, rec, part, n, j);
-        case 11: return launch_slice_t<11, 8>(s, Usj, Tj, rec, part, n, j);
-        case 12: return launch_slice_t<12, 8>(s, Usj, Tj, rec, part, n, j);
-        case 13: return launch_slice_t<13, 8>(s, Usj, Tj, rec, part, n, j);
-        case 14: return launch_slice_t<14, 8>(s, Usj, Tj, rec, part, n, j);
-        case 15: return launch_slice_t<15, 8>(s, Usj, Tj, rec, part, n, j);
-        case 16: return launch_slice_t<16, 8>(s, Usj, Tj, rec, part, n, j);
-        default: lsq_set_error("m = %d out of range 1..16", m); return LSQ_EINVAL;
-    }
 }
 
 #define LSQ_CS_LAUNCH(m, KERNEL, GRID, ...)                                                       \
@@ -1175,8 +832,7 @@ int lsq_launch_perturb(hipStream_t s, const uint8_t *src, uint8_t *dst, int64_t 
 int lsq_launch_cost(hipStream_t s, const float *X, const float *K, const uint8_t *rec, uint8_t *cur, float *prev,
                     unsigned long long *counters, int64_t n, int d, int m, int mode, const unsigned short *vnew, unsigned short *vcur) {
     if (n <= 0) return LSQ_OK;
-    static int use_v2 = -1;
-    if (use_v2 < 0) { const char *e = getenv("LSQ_COST_V2"); use_v2 = e ? atoi(e) : 1; }
+    const int use_v2 = LSQ_KNOB("LSQ_COST_V2", 1);
     // half a wave per vector with 8-byte loads: measured 13 % faster at d = 128, 7 % slower at d = 960 (same box)
     if (use_v2 && d % 2 == 0 && d <= 256 && ((uintptr_t)X | (uintptr_t)K) % 8 == 0) {
         LSQ_DISPATCH_M(m, hipLaunchKernelGGL(cost2_kernel<M_>, dim3(wave_grid((n + 1) / 2)), dim3(256), 0, s, X, K, rec, cur, prev, counters, n, d, mode, vnew, vcur));

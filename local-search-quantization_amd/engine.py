@@ -5,6 +5,7 @@ Row-major conventions (the Julia buffers seen from numpy, see include/lsq_mi355x
 torch is used only as the owner of device memory and streams; every computation happens inside
 liblsq_mi355x.so.
 """
+import contextlib
 import ctypes as C
 
 import numpy as np
@@ -20,10 +21,11 @@ def _np(a, dtype):
 
 
 class Engine:
-    def __init__(self, device=0, chunk=None, profile=False, schedule=None, skip=None):
-        self._L = _lib.load()
+    def __init__(self, device=0, chunk=None, profile=False, schedule=None, skip=None, tuning=False):
+        """tuning=True loads liblsq_mi355x_tuning.so (same ABI + option "ablation", environment knobs, schedules 0..2)."""
+        self._L = _lib.load(tuning=tuning)
         h = C.c_void_p()
-        _lib.check(self._L.lsq_create(C.byref(h), int(device)))
+        self._check(self._L.lsq_create(C.byref(h), int(device)))
         self._h = h
         self.device = int(device)
         if chunk is not None:
@@ -34,6 +36,9 @@ class Engine:
             self.set_option("skip", int(bool(skip)))
         if profile:
             self.set_option("profile", 1)
+
+    def _check(self, rc):
+        return _lib.check(rc, self._L)
 
     # -- lifetime -------------------------------------------------------------------------
     def close(self):
@@ -55,25 +60,34 @@ class Engine:
 
     # -- options / timing -----------------------------------------------------------------
     def set_option(self, key, value):
-        _lib.check(self._L.lsq_set_option(self._h, key.encode(), int(value)))
+        self._check(self._L.lsq_set_option(self._h, key.encode(), int(value)))
 
     def set_stream(self, hip_stream_ptr):
-        _lib.check(self._L.lsq_set_stream(self._h, C.c_void_p(hip_stream_ptr or 0)))
+        self._check(self._L.lsq_set_stream(self._h, C.c_void_p(hip_stream_ptr or 0)))
 
-    def use_torch_stream(self):
+    @contextlib.contextmanager
+    def _on_torch_stream(self):
+        """Bind the context to torch's CURRENT stream for the duration of one call, then return to the context's own stream.
+        The torch stream object is held for as long as its raw handle is bound, so a temporary stream
+        (`with torch.cuda.stream(torch.cuda.Stream())`) can never leave a dangling hipStream_t behind."""
         import torch
-        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        stream = torch.cuda.current_stream(self.device)
+        self.set_stream(stream.cuda_stream)
+        try:
+            yield stream
+        finally:
+            self.set_option("own_stream", 1)
 
     def synchronize(self):
-        _lib.check(self._L.lsq_synchronize(self._h))
+        self._check(self._L.lsq_synchronize(self._h))
 
     def timings(self):
         t = _lib.Timings()
-        _lib.check(self._L.lsq_get_timings(self._h, C.byref(t)))
+        self._check(self._L.lsq_get_timings(self._h, C.byref(t)))
         return t.as_dict()
 
     def reset_timings(self):
-        _lib.check(self._L.lsq_reset_timings(self._h))
+        self._check(self._L.lsq_reset_timings(self._h))
 
     # -- (1) whole call, host buffers -------------------------------------------------------
     def encode_icm(self, X, B, K, m, ilsiters, icmiter, npert, randord, seed=0, nsplits=1, global_offset=0,
@@ -86,7 +100,7 @@ class Engine:
         nr = ils.shape[0]
         Bs = np.empty((nr, n, m), dtype=np.int16)
         objs = np.zeros(nr, dtype=np.float32)
-        _lib.check(self._L.lsq_encode_icm(self._h, X.ctypes.data, B.ctypes.data, K.ctypes.data, d, n, m, h,
+        self._check(self._L.lsq_encode_icm(self._h, X.ctypes.data, B.ctypes.data, K.ctypes.data, d, n, m, h,
                                           ils.ctypes.data, nr, int(icmiter), int(npert), int(bool(randord)),
                                           int(nsplits), int(seed), int(global_offset), int(bool(verbose)),
                                           Bs.ctypes.data, objs.ctypes.data))
@@ -110,11 +124,11 @@ class Engine:
         dBs = out if out is not None else torch.empty((nr, n, m), dtype=torch.uint8, device=dX.device)
         obj = np.zeros(nr, dtype=np.float64)
         stats = np.zeros((I, 2), dtype=np.int64)
-        self.use_torch_stream()
-        _lib.check(self._L.lsq_encode_icm_dev(self._h, dX.data_ptr(), dB0.data_ptr(), dK.data_ptr(), d, n, m, h,
-                                              ils.ctypes.data, nr, int(icmiter), int(npert), int(bool(randord)),
-                                              int(seed), int(global_offset), dBs.data_ptr(), obj.ctypes.data,
-                                              stats.ctypes.data))
+        with self._on_torch_stream():
+            self._check(self._L.lsq_encode_icm_dev(self._h, dX.data_ptr(), dB0.data_ptr(), dK.data_ptr(), d, n, m, h,
+                                                   ils.ctypes.data, nr, int(icmiter), int(npert), int(bool(randord)),
+                                                   int(seed), int(global_offset), dBs.data_ptr(), obj.ctypes.data,
+                                                   stats.ctypes.data))
         return dBs, obj, stats
 
     # -- (2) CPU-path shaped ---------------------------------------------------------------
@@ -123,7 +137,7 @@ class Engine:
         n, d = X.shape
         self._check_shapes(X, K, oldB, m, h)
         out = np.empty((n, m), dtype=np.int16)
-        _lib.check(self._L.lsq_encoding_icm(self._h, X.ctypes.data, oldB.ctypes.data, K.ctypes.data, d, n, m, h,
+        self._check(self._L.lsq_encoding_icm(self._h, X.ctypes.data, oldB.ctypes.data, K.ctypes.data, d, n, m, h,
                                             int(niter), int(bool(randord)), int(npert), int(seed), int(it),
                                             int(global_offset), out.ctypes.data))
         return out
@@ -135,7 +149,7 @@ class Engine:
             raise ValueError("B must be a C-contiguous int16 (n, m) array (it is updated in place)")
         n, d = X.shape
         self._check_shapes(X, K, B, m, h)
-        _lib.check(self._L.lsq_encode_icm_fully(self._h, B.ctypes.data, X.ctypes.data, K.ctypes.data, d, n, m, h,
+        self._check(self._L.lsq_encode_icm_fully(self._h, B.ctypes.data, X.ctypes.data, K.ctypes.data, d, n, m, h,
                                                 int(niter), int(bool(randord)), int(npert), int(idx_first), int(seed), int(it)))
         return B
 
@@ -144,14 +158,14 @@ class Engine:
         X, K = _np(X, np.float32), _np(K, np.float32)
         n, d = X.shape
         U = np.empty((m, n, h), dtype=np.float32)
-        _lib.check(self._L.lsq_get_unaries(self._h, X.ctypes.data, K.ctypes.data, d, n, m, h, U.ctypes.data))
+        self._check(self._L.lsq_get_unaries(self._h, X.ctypes.data, K.ctypes.data, d, n, m, h, U.ctypes.data))
         return U
 
     def get_binaries(self, K, m, h=H):
         K = _np(K, np.float32)
         d = K.shape[1]
         T = np.empty((m, m, h, h), dtype=np.float32)
-        _lib.check(self._L.lsq_get_binaries(self._h, K.ctypes.data, d, m, h, T.ctypes.data))
+        self._check(self._L.lsq_get_binaries(self._h, K.ctypes.data, d, m, h, T.ctypes.data))
         return T
 
     def veccost(self, X, B, K, m, h=H):
@@ -159,7 +173,7 @@ class Engine:
         n, d = X.shape
         self._check_shapes(X, K, B, m, h)
         out = np.empty(n, dtype=np.float32)
-        _lib.check(self._L.lsq_veccost(self._h, X.ctypes.data, B.ctypes.data, K.ctypes.data, d, n, m, h, out.ctypes.data))
+        self._check(self._L.lsq_veccost(self._h, X.ctypes.data, B.ctypes.data, K.ctypes.data, d, n, m, h, out.ctypes.data))
         return out
 
     def qerror(self, X, B, K, m, h=H):
@@ -167,35 +181,35 @@ class Engine:
         n, d = X.shape
         self._check_shapes(X, K, B, m, h)
         out = C.c_double(0.0)
-        _lib.check(self._L.lsq_qerror(self._h, X.ctypes.data, B.ctypes.data, K.ctypes.data, d, n, m, h, C.byref(out)))
+        self._check(self._L.lsq_qerror(self._h, X.ctypes.data, B.ctypes.data, K.ctypes.data, d, n, m, h, C.byref(out)))
         return float(out.value)
 
     def perturb(self, B, npert, seed=0, it=0, global_offset=0, h=H):
         B = _np(B, np.int16).copy()
         n, m = B.shape
-        _lib.check(self._L.lsq_perturb(self._h, B.ctypes.data, n, m, h, int(npert), int(seed), int(it), int(global_offset)))
+        self._check(self._L.lsq_perturb(self._h, B.ctypes.data, n, m, h, int(npert), int(seed), int(it), int(global_offset)))
         return B
 
     # -- (4) device generators -------------------------------------------------------------
     def synth_data_u8_dev(self, seed, n, d, device=None, global_offset=0):
         import torch
         X = torch.empty((n, d), dtype=torch.float32, device=device or ("cuda:%d" % self.device))
-        self.use_torch_stream()
-        _lib.check(self._L.lsq_synth_data_u8_dev(self._h, int(seed), int(global_offset), n, d, X.data_ptr()))
+        with self._on_torch_stream():
+            self._check(self._L.lsq_synth_data_u8_dev(self._h, int(seed), int(global_offset), n, d, X.data_ptr()))
         return X
 
     def randinit_dev(self, seed, n, m, device=None, global_offset=0, h=H):
         import torch
         B = torch.empty((n, m), dtype=torch.uint8, device=device or ("cuda:%d" % self.device))
-        self.use_torch_stream()
-        _lib.check(self._L.lsq_randinit_dev(self._h, int(seed), int(global_offset), n, m, h, B.data_ptr()))
+        with self._on_torch_stream():
+            self._check(self._L.lsq_randinit_dev(self._h, int(seed), int(global_offset), n, m, h, B.data_ptr()))
         return B
 
     def synth_codebooks_dev(self, seed, m, d, device=None, h=H):
         import torch
         K = torch.empty((m * h, d), dtype=torch.float32, device=device or ("cuda:%d" % self.device))
-        self.use_torch_stream()
-        _lib.check(self._L.lsq_synth_codebooks_dev(self._h, int(seed), m, h, d, K.data_ptr()))
+        with self._on_torch_stream():
+            self._check(self._L.lsq_synth_codebooks_dev(self._h, int(seed), m, h, d, K.data_ptr()))
         return K
 
     @staticmethod

@@ -80,7 +80,7 @@ def test_encode_icm_matches_oracle(lsq, oracle, cfg, schedule):
     d, n, m, ils, J, npert, randord, seed, kind = cfg
     X, K, B0 = make_problem(d, n, m, seed=seed, kind=kind)
     Bs_ref, objs_ref, st_ref = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, randord, seed, want_stats=True)
-    with lsq.Engine(0, schedule=schedule) as eng:
+    with lsq.Engine(0, schedule=schedule, tuning=schedule < 3) as eng:
         Bs, objs = eng.encode_icm(X, B0, K, m, ils, J, npert, randord, seed=seed)
     assert np.array_equal(Bs, Bs_ref), "%d of %d codes differ" % ((Bs != Bs_ref).sum(), Bs.size)
     assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0)
@@ -240,7 +240,7 @@ def test_nonfinite_inputs_follow_the_reference_scan(lsq, oracle, n):
     import torch
     Bs_ref, objs_ref, st_ref = oracle.encode_icm(X, B0, K, m, H, [1, 2, 4], 3, 4, True, seed, want_stats=True)
     for schedule in (4, 3):
-        with lsq.Engine(0, schedule=schedule) as eng:
+        with lsq.Engine(0, schedule=schedule, tuning=schedule < 3) as eng:
             Bs, objs = eng.encode_icm(X, B0, K, m, [1, 2, 4], 3, 4, True, seed=seed)
             assert np.array_equal(Bs, Bs_ref), "schedule %d: %d codes differ" % (schedule, (Bs != Bs_ref).sum())
             assert np.array_equal(np.isnan(objs), np.isnan(objs_ref))
@@ -294,7 +294,7 @@ def test_full_size_properties(lsq):
     and invariance to sharding / chunking / schedule."""
     import torch
     n, d, m, ils, J, npert, seed = 1_000_000, 128, 8, [1, 3], 4, 4, 42
-    with lsq.Engine(0) as eng, lsq.Engine(0, chunk=300_000, schedule=2) as eng2:
+    with lsq.Engine(0) as eng, lsq.Engine(0, chunk=300_000, schedule=2, tuning=True) as eng2:
         dX = eng.synth_data_u8_dev(1234, n, d)
         dB0 = eng.randinit_dev(7, n, m)
         dK = eng.synth_codebooks_dev(4321, m, d)
