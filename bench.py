@@ -7,17 +7,29 @@
 
 A "step" = one full `encode_icm_cuda`-equivalent call: pair tables + unary build +
 16 ILS iterations x (perturb + 4 sweeps x m node updates + cost + accept) over this rank's batch,
-inputs already resident in HBM, through the C-ABI (lsq_encode_icm_dev).  Workload = BASELINE.json
+inputs already resident in HBM, through the C-ABI (lsq_encode_icm_dev).  Default workload = BASELINE.json
 configs[1]: SIFT1M-shaped base set (10^6 x 128 f32, synthetic: Philox uniform integers 0..255),
 m = 8, h = 256, ILS 16, icmiter 4, npert 4, randord -- per GPU (weak scaling: every rank encodes its
 own 10^6-vector shard of a global index space; the only data-path collective is the RCCL broadcast
 of the 1 MiB codebook matrix from rank 0, inside the timed step).
 
-Prints ONE JSON line on rank 0 with the driver's contract fields plus `roofline` (dominant kernel:
-the ICM node update) and `cpu_baseline` (the oracle's structure-faithful port of the reference CPU
-path, timed on this box's host cores on a bounded sample; rank 0, N=1 only).
+Other BASELINE configs through flags (same JSON line, `config.workload` names what ran):
+    cfg3  --codebooks 16
+    cfg4  --scaling strong --total 1000000 --dim 960     (GIST-shaped; `splitarray` shards: 125 000 vectors per GPU at N = 8)
+    cfg5  --vectors 12500000                              (weak scaling, 12.5 M vectors per GPU generated on the device, 12 resident chunks)
+
+Prints ONE JSON line on rank 0 with the driver's contract fields plus
+  `roofline`         dominant kernel (the ICM node update): algorithmic HBM bytes / HIP-event launch time vs 8 TB/s, the LDS-side
+                     gather rate vs the guide's 150 TB/s, the M1 compulsory-bytes fraction, PMC traffic when the committed
+                     profile was taken from THIS build (hash of the loaded .so), else null;
+  `sample_parity`    two 256-vector blocks of the timed output re-computed with the CPU oracle after the timed region;
+  `north_star_point` the same workload at north_star's own operating point (4 ILS iterations), with its CPU baseline;
+  `end_to_end`       the host-buffer entry point lsq_encode_icm on pageable host memory (H2D of X, D2H of the codes included);
+  `cpu_baseline`     the oracle's structure-faithful port of the reference CPU path on this box's host cores (bounded sample),
+                     plus cfg1 at its exact shape; rank 0, N=1 only.
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
@@ -29,9 +41,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-L2_PEAK_GBS = 34500.0          # same guide, L2 aggregate measured
-PMC_FILE, PMC_SCHEDULE = "r01h_pmc_per_kernel.json", 4      # committed PMC passes the `traffic` field is read from
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (~6.3 TB/s achievable)
+HBM_ACHIEVABLE_GBS = 6300.0
+LDS_PEAK_GBS = 150000.0        # same guide, section LDS: ds_read_b64/b128 aggregate with every CU streaming
+PMC_GLOB = "r02*_pmc_per_kernel.json"      # committed PMC passes; `traffic` is read from the newest one whose build hash matches
 
 
 def parse():
@@ -39,32 +52,48 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=3)
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--vectors", dest="n", type=int, default=1_000_000, help="vectors per GPU")
+    p.add_argument("--vectors", dest="n", type=int, default=1_000_000, help="vectors per GPU (weak scaling)")
+    p.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    p.add_argument("--total", type=int, default=1_000_000, help="strong scaling: total vectors, split with splitarray over the ranks")
     p.add_argument("--dim", dest="d", type=int, default=128)
     p.add_argument("--codebooks", dest="m", type=int, default=8)
     p.add_argument("--ils", type=int, default=16)
     p.add_argument("--icmiter", type=int, default=4)
     p.add_argument("--npert", type=int, default=4)
-    p.add_argument("--schedule", type=int, default=int(os.environ.get("LSQ_SCHEDULE", "4")))
+    p.add_argument("--schedule", type=int, default=int(os.environ.get("LSQ_SCHEDULE", "-1")), help="-1 = library default")
     p.add_argument("--chunk", type=int, default=int(os.environ.get("LSQ_CHUNK", "0")))
     p.add_argument("--skip", type=int, default=int(os.environ.get("LSQ_SKIP", "1")),
-                   help="schedules 3/4: exact memoisation of node updates whose inputs did not change (1) or recompute everything (0)")
-    p.add_argument("--ablation", type=int, default=int(os.environ.get("LSQ_ABLATION", "0")), help="timing-only kernel ablation (results invalid when != 0)")
+                   help="exact memoisation of node updates whose inputs did not change (1) or recompute everything (0)")
+    p.add_argument("--option", action="append", default=[], help="extra engine option key=value (repeatable)")
+    p.add_argument("--tuning", action="store_true", help="load liblsq_mi355x_tuning.so (ablations / knobs / schedules 0..2); never the headline")
+    p.add_argument("--ablation", type=int, default=int(os.environ.get("LSQ_ABLATION", "0")), help="tuning build only; results invalid when != 0")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline budget")
+    p.add_argument("--no-extra-legs", action="store_true", help="skip sample_parity / north_star_point / end_to_end / the busy tail")
+    p.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget for the cfg2 sample")
+    p.add_argument("--min-gpu-seconds", type=float, default=6.0,
+                   help="after the timed region keep running identical UNTIMED steps until the GPU legs have lasted this long "
+                        "(lets a 5 s utilisation sampler see the device busy; reported as steady_state)")
+    p.add_argument("--multi-leg", action="store_true", help="also time the single-process multi-GPU entry point (lsq_multi_*) on all visible devices")
     return p.parse_args()
 
 
+def lib_hash(path):
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(args):
-    """Time the oracle's structure-faithful restatement of encoding_icm (reference
-    src/encodings/encode_icm.jl:131-189 loop nest, one OpenMP thread per `julia -p` worker) on a
-    bounded sample of the same workload.  Never part of the measured GPU path."""
+    """Time the oracle's structure-faithful restatement of encoding_icm (reference src/encodings/encode_icm.jl:131-189 loop
+    nest, one OpenMP thread per `julia -p` worker) on bounded samples.  Never part of the measured GPU path.
+      * cfg2 sample: a 100 000-vector subset split over the workers, as many of the 16 ILS iterations as fit the
+        budget, scaled linearly (the control flow is data-independent);
+      * cfg1 exactly: n = 10 000, d = 128, m = 8, one call = one ILS iteration with 4 sweeps (demo_lsq.jl:34);
+      * the cache-blocked per-vector variant, so the ratio is not inflated by the reference's loop order alone."""
     import oracle as O
     O.build()
     cores = O.num_threads()
     d, m, h = args.d, args.m, 256
-    nw = 4096                                 # vectors per worker (ub = 4 MiB, unaries = 32 MiB per worker)
-    n = nw * cores
+    n = 100_000
     X = O.synth_data_u8(1234, n, d)
     pool = O.synth_data_u8(4321, m * h, d)
     K = np.ascontiguousarray(pool / np.float32(m))
@@ -78,31 +107,86 @@ def cpu_baseline(args):
         B = O.encoding_icm_faithful(X, B, K, m, h, args.icmiter, True, args.npert, 42, it, nworkers=cores)
     t_iter = (time.perf_counter() - t0) / iters
     vps = n / (t_iter * args.ils)             # full encode = args.ils ILS iterations
-    # also the cache-blocked per-vector CPU variant (one vector's unaries stay in L1/L2, tables shared
-    # in L3), so the GPU/CPU ratio is not inflated by the reference's whole-array loop order alone.
+    out = {
+        "value": vps, "unit": "vectors/s", "cores": cores, "kind": "port",
+        "sample": "100 000-vector subset (%d per worker x %d OpenMP workers), %d of %d ILS iterations timed (%.3f s each), "
+                  "scaled linearly to %d iterations; oracle/lsq_oracle.c orc_encoding_icm_faithful "
+                  "(CPU restatement of the reference algorithm, not Julia)" % (n // cores, cores, iters, args.ils, t_iter, args.ils),
+        "seconds_per_ils_iteration": t_iter,
+    }
+    # cfg1 at its exact shape (d = 128, m = 8 whatever the GPU flags say): ilsiter = 8 chained calls, first one discarded
+    n1 = 10_000
+    X1 = O.synth_data_u8(1234, n1, 128)
+    K1 = np.ascontiguousarray(O.synth_data_u8(4321, 8 * h, 128) / np.float32(8))
+    B1 = O.randinit(7, n1, 8, h)
+    B1 = O.encoding_icm_faithful(X1, B1, K1, 8, h, 4, True, 4, 42, 0, nworkers=cores)
+    t0 = time.perf_counter()
+    for it in range(1, 8):
+        B1 = O.encoding_icm_faithful(X1, B1, K1, 8, h, 4, True, 4, 42, it, nworkers=cores)
+    t_call = (time.perf_counter() - t0) / 7
+    out["cfg1"] = {"value": n1 / t_call, "unit": "vectors/s per encoding_icm call (1 ILS iteration, 4 sweeps)", "cores": cores,
+                   "sample": "BASELINE configs[0] exactly: n = 10 000, d = 128, m = 8, h = 256; 7 chained calls timed (%.4f s each)" % t_call}
+    # cache-blocked per-vector variant (one vector's unaries stay in L1/L2, tables shared in L3)
     nb = 64 * cores
     Xb, Bb = X[:nb], O.randinit(7, nb, m, h)
     t0 = time.perf_counter()
     O.encode_icm(Xb, Bb, K, m, h, [args.ils], args.icmiter, args.npert, True, 42)
     tb = time.perf_counter() - t0
-    reps = int(max(1, min(16, 4.0 // max(tb, 1e-9))))
+    reps = int(max(1, min(12, 4.0 // max(tb, 1e-9))))
     nb2 = min(n, nb * reps)
     Xb, Bb = X[:nb2], O.randinit(7, nb2, m, h)
     t0 = time.perf_counter()
     O.encode_icm(Xb, Bb, K, m, h, [args.ils], args.icmiter, args.npert, True, 42)
     tb = time.perf_counter() - t0
-    blocked = {"value": nb2 / tb, "unit": "vectors/s", "cores": cores,
-               "sample": "%d vectors x %d ILS iterations in %.2f s; oracle/lsq_oracle.c orc_encode_icm (per-vector, "
-                         "cache-blocked loop order; not the reference's)" % (nb2, args.ils, tb)}
-    return {
-        "blocked_variant": blocked,
-        "value": vps, "unit": "vectors/s", "cores": cores, "kind": "port",
-        "sample": "%d vectors (%d per worker x %d OpenMP workers), %d of %d ILS iterations timed (%.2f s each), "
-                  "scaled linearly to %d iterations; oracle/lsq_oracle.c orc_encoding_icm_faithful "
-                  "(CPU restatement of the reference algorithm, not Julia)" % (n, nw, cores, iters, args.ils, t_iter, args.ils),
-    }
+    out["blocked_variant"] = {"value": nb2 / tb, "unit": "vectors/s", "cores": cores,
+                              "sample": "%d vectors x %d ILS iterations in %.2f s; oracle/lsq_oracle.c orc_encode_icm (per-vector, "
+                                        "cache-blocked loop order; not the reference's)" % (nb2, args.ils, tb)}
+    return out
 
 
+def sample_parity(eng, dX, dB0, dK, dBs, n, m, args, goff):
+    """Untimed: two contiguous 256-vector blocks of the TIMED output vs the CPU oracle run on exactly those vectors
+    (valid because results depend on the global vector index only).  -> (ok, detail)"""
+    import oracle as O
+    O.build()
+    K = dK.cpu().numpy()
+    bad, checked = 0, 0
+    for a in sorted({0, max(0, n // 2 - 128)}):
+        b = min(n, a + 256)
+        X = dX[a:b].cpu().numpy()
+        B0 = dB0[a:b].cpu().numpy().astype(np.int16) + 1
+        ref, _ = O.encode_icm(X, B0, K, m, 256, [args.ils], args.icmiter, args.npert, True, 42, global_offset=goff + a)
+        got = dBs[0][a:b].cpu().numpy().astype(np.int16) + 1
+        bad += int((ref[0] != got).any(axis=1).sum())
+        checked += b - a
+    return bad == 0, "%d vectors of the timed output re-encoded by oracle/lsq_oracle.c: %d differ" % (checked, bad)
+
+
+def pmc_traffic(lib_sha):
+    """HBM traffic per ICM launch from the newest committed PMC profile taken from THIS build (its `_build.lib_sha16` must equal
+    the hash of the loaded .so); None when there is none -- a stale profile is never reported next to fresh timings."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", PMC_GLOB))):
+        try:
+            pmc = json.load(open(f))
+        except Exception:
+            continue
+        if pmc.get("_build", {}).get("lib_sha16") != lib_sha:
+            continue
+        wk = [k for k in pmc if k.startswith("icm_walk_kernel") and "FETCH_SIZE" in pmc[k] and "WRITE_SIZE" in pmc[k]]
+        if not wk:
+            continue
+        # FETCH_SIZE / WRITE_SIZE are reported in KiB; FETCH_SIZE x 2 = the guide's gfx950 correction for wide streaming reads
+        tot = sum((2.0 * pmc[k]["FETCH_SIZE"]["mean_per_dispatch"] * pmc[k]["FETCH_SIZE"]["dispatches"]
+                   + pmc[k]["WRITE_SIZE"]["mean_per_dispatch"] * pmc[k]["WRITE_SIZE"]["dispatches"]) * 1024.0 for k in wk)
+        disp = sum(pmc[k]["FETCH_SIZE"]["dispatches"] for k in wk)
+        best = {"bytes_per_icm_launch": tot / max(disp, 1), "icm_launches_profiled": disp, "source": "profiles/" + os.path.basename(f),
+                "workload": pmc.get("_build", {}).get("bench_args", "")}
+    return best
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
     import torch
@@ -129,16 +213,30 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
-    n, d, m, h = args.n, args.d, args.m, 256
-    eng = lsq.Engine(dev_index, profile=True, schedule=args.schedule, chunk=(args.chunk or None))
+    d, m, h = args.d, args.m, 256
+    if args.scaling == "strong":                       # cfg4: one dataset, `splitarray` shards (src/utils.jl:152-177)
+        goff, stop = lsq.split_ranges(args.total, world)[rank]
+        n = stop - goff
+        n_total = args.total
+    else:                                              # weak: every rank encodes its own n vectors of a global index space
+        n, goff, n_total = args.n, rank * args.n, args.n * world
+    eng = lsq.Engine(dev_index, profile=True, chunk=(args.chunk or None), tuning=args.tuning)
+    if args.schedule >= 0:
+        eng.set_option("schedule", args.schedule)
     eng.set_option("skip", args.skip)
-    eng.set_option("ablation", args.ablation)
-    goff = rank * n
+    if args.tuning:
+        eng.set_option("ablation", args.ablation)
+    for kv in args.option:
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
+    lib_path = lsq._lib.TUNING_LIB_PATH if args.tuning else lsq._lib.LIB_PATH
+    lib_sha = lib_hash(lib_path)
+
     data_tag = "synthetic"
     dX = None
     sift = os.path.join(os.environ.get("LSQ_DATA_DIR", ""), "sift", "sift_base.fvecs")
     if os.environ.get("LSQ_DATA_DIR") and os.path.exists(sift) and d == 128:
-        # use the real SIFT1M base set when it is there (it is not in this image); rank r takes rows [r n, (r+1) n)
+        # use the real SIFT1M base set when it is there (it is not in this image); rank r takes rows [goff, goff + n)
         rows_in_file = os.path.getsize(sift) // (4 + 4 * 128)
         if goff + n <= rows_in_file:
             X = lsq.fvecs_read((goff + 1, goff + n), sift)              # (d, n), 1-based inclusive bounds like the reference reader
@@ -146,15 +244,19 @@ def main():
             data_tag = "sift1m_base rows %d..%d (%s)" % (goff, goff + n - 1, sift)
     if dX is None:
         dX = eng.synth_data_u8_dev(1234, n, d, global_offset=goff)
+        if d == 960:
+            dX.mul_(0.3 / 255.0)                       # GIST-like range; the encode path is value-independent
     dB0 = eng.randinit_dev(7, n, m, global_offset=goff)
     dK = eng.synth_codebooks_dev(4321, m, d) if rank == 0 else torch.zeros((m * h, d), dtype=torch.float32, device=dX.device)
+    if d == 960 and rank == 0:
+        dK.mul_(0.3 / 255.0)
     dBs = torch.empty((1, n, m), dtype=torch.uint8, device=dX.device)
     torch.cuda.synchronize()
 
-    def step():
+    def step(ils=args.ils):
         if dist is not None:
             dist.broadcast(dK, src=0)                  # RCCL over xGMI: the one data-path collective
-        return eng.encode_icm_dev(dX, dB0, dK, m, [args.ils], args.icmiter, args.npert, True, seed=42,
+        return eng.encode_icm_dev(dX, dB0, dK, m, [ils], args.icmiter, args.npert, True, seed=42,
                                   global_offset=goff, out=dBs)
 
     def fence():
@@ -163,6 +265,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    t_gpu0 = time.perf_counter()
     for _ in range(args.warmup):
         step()
     fence()
@@ -171,84 +274,153 @@ def main():
     for _ in range(args.steps):
         _, sums, stats = step()
     fence()
-    dt = time.perf_counter() - t0
+    dt_local = dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dX.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     tm = eng.timings()
 
+    # ---- per-rank roofline numbers (every rank computes its own; rank 0 reports all of them) -------------------------
+    cs = 8 if m <= 8 else 16
+    launches = max(tm["icm_launches"], 1)
+    avg_launch_s = tm["icm_ms"] * 1e-3 / launches
+    nu_per_launch = tm["icm_node_updates"] / launches
+    hbm_bytes = nu_per_launch * (4 * h + cs + 1)      # M2 data-flow: U_j row (4h B) + code record read + 1 code byte, per RECOMPUTED node update
+    achieved = hbm_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+    mine = {"rank": rank, "device": dev_index, "vectors": n, "global_offset": goff, "ms_per_step": dt_local / args.steps * 1e3,
+            "vectors_per_s": n * args.steps / dt_local, "hbm_frac": achieved / HBM_PEAK_GBS, "icm_ms_per_step": tm["icm_ms"] / args.steps}
+    ranks = [mine]
+    if dist is not None:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
+
     if rank == 0:
-        total_vectors = n * world * args.steps
-        value = total_vectors / dt
-        launches = max(tm["icm_launches"], 1)
-        avg_launch_s = tm["icm_ms"] * 1e-3 / launches
-        node_updates_per_launch = tm["icm_node_updates"] / launches
-        cs = 8 if m <= 8 else 16
-        if args.schedule != 1:
-            # per vector per node-update launch: U_j row (4h B) + code record read + 1 code byte written
-            hbm_bytes = node_updates_per_launch * (4 * h + cs + 1)
-        else:
-            # fused sweeps: per vector per launch all m unary rows + code record read/write
-            hbm_bytes = (n if args.chunk == 0 else min(n, args.chunk)) * (4 * h * m + 2 * cs)
-        table_bytes = node_updates_per_launch * (m - 1) * 4 * h        # table columns: on-chip (L2 gathers or LDS reads)
-        achieved = hbm_bytes / avg_launch_s / 1e9
-        resolved = n * (args.icmiter * m if args.schedule in (1, 4) else 1)    # vector x node updates one launch resolves
+        value = n_total * args.steps / dt
+        table_bytes = nu_per_launch * (m - 1) * 4 * h        # (m-1) x 1 KiB of table columns per node update: LDS reads (or L2 gathers in light blocks)
+        total_nu = n * args.ils * args.icmiter * m           # node updates one step resolves on this rank
+        m1_bytes = n * (4 * d + 2 * m + 2 * m + 4 + 4 * m * h + 4 * m * h + 4 * d)      # SURVEY 8(d) model M1 per step
+        step_s = dt / args.steps
         roof = {
-            "kernel": {0: "icm_node_kernel<%d>", 1: "icm_fused_kernel<%d>", 2: "icm_slice_kernel<%d,SL> + icm_combine_kernel", 3: "icm_walk_kernel<%d,SL>", 4: "icm_walk_kernel<%d,SL>"}[args.schedule] % m,
+            "kernel": "icm_walk_kernel<%d,SL>" % m,
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "frac_of_achievable_6300": achieved / HBM_ACHIEVABLE_GBS,
             "traffic": None,
             "avg_launch_us": avg_launch_s * 1e6, "launches": int(tm["icm_launches"]),
             "algorithmic_bytes_per_launch": hbm_bytes,
             "bytes_per_node_update": 4 * h + cs + 1,
-            "node_updates_recomputed_per_launch": node_updates_per_launch,
-            "node_updates_resolved_per_launch": resolved,
-            "recomputed_fraction": node_updates_per_launch / resolved,
-            "note": "achieved counts only node updates that were actually recomputed; with skip=1 the others are resolved by "
-                    "exact memoisation (inputs unchanged since the node was last minimised) and move no bytes",
+            "node_updates_recomputed_per_launch": nu_per_launch,
+            "recomputed_fraction": tm["icm_node_updates"] / max(total_nu * args.steps, 1),
+            "blocks": {"staged": int(tm["staged_blocks"]), "light": int(tm["light_blocks"]), "team": int(tm["team_blocks"])},
+            "data_flow": "M2 (SURVEY 8(d)): the unary row of a node is re-read from HBM at every recomputed node update; `achieved` counts only "
+                         "node updates that were actually recomputed (memoised ones move no bytes).  It is a fraction of the traffic this "
+                         "design chose to create, not of the compulsory bytes -- see m1_compulsory.",
+            "gather": {"achieved": table_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0, "peak": LDS_PEAK_GBS, "unit": "GB/s",
+                       "frac": (table_bytes / avg_launch_s / 1e9 / LDS_PEAK_GBS) if avg_launch_s > 0 else 0.0,
+                       "note": "(m-1) x 1 KiB of pair-table columns per recomputed node update, read from LDS-staged slices with ds_read_b128 "
+                               "(16 random 64-byte rows per wave read: ~2.1-way bank conflicts are intrinsic to the lookup); peak = guide's aggregate"},
+            "m1_compulsory": {"bytes_per_step": m1_bytes, "achieved": m1_bytes / step_s / 1e9, "unit": "GB/s",
+                              "frac": m1_bytes / step_s / 1e9 / HBM_PEAK_GBS,
+                              "note": "SURVEY 8(d) model M1 (X once, codes in/out, unaries written once and read once, X re-read for the cost) / whole step time"},
         }
-        # HBM traffic per launch from the committed rocprofv3 PMC passes of this build (separate --pmc FETCH_SIZE and
-        # --pmc WRITE_SIZE runs of this same command; FETCH_SIZE x2 = the gfx950 correction for wide streaming reads,
-        # /opt/skills/guides/MI355X_MICROARCH.md section HBM).  Not measurable live inside the benchmark process.
-        try:
-            if args.schedule == PMC_SCHEDULE and args.skip and n == 1_000_000 and d == 128 and m == 8 and args.ils == 16 and args.icmiter == 4:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
-                wk = [k for k in pmc if k.startswith("icm_walk_kernel")][0]
-                roof["traffic"] = (2.0 * pmc[wk]["FETCH_SIZE"]["mean_per_dispatch"] + pmc[wk]["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0
-                roof["traffic_source"] = "profiles/" + PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, per dispatch)"
-        except Exception:
-            roof["traffic"] = None
-        if args.schedule in (0, 1):
-            roof["l2_gather"] = {"achieved": table_bytes / avg_launch_s / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s",
-                                 "frac": table_bytes / avg_launch_s / 1e9 / L2_PEAK_GBS}
-        else:
-            roof["lds_table_reads"] = {"achieved": table_bytes / avg_launch_s / 1e9, "peak": 150000.0, "unit": "GB/s",
-                                       "frac": table_bytes / avg_launch_s / 1e9 / 150000.0,
-                                       "note": "(m-1) x 1 KiB of table columns per node update come from LDS-staged slices (ds_read_b128 aggregate peak)"}
+        tr = pmc_traffic(lib_sha)
+        if tr is not None:
+            roof["traffic"] = tr["bytes_per_icm_launch"]
+            roof["traffic_source"] = tr
+        workload = ("BASELINE configs[1]" if (d, m, args.scaling, n) == (128, 8, "weak", 1_000_000) else
+                    "BASELINE configs[2]" if (d, m, args.scaling, n) == (128, 16, "weak", 1_000_000) else
+                    "BASELINE configs[3]" if (d, m, args.scaling) == (960, 8, "strong") else
+                    "BASELINE configs[4]" if (d, m, args.scaling, n) == (128, 8, "weak", 12_500_000) else "custom")
         out = {
             "metric": "vectors encoded/sec (ICM, m=%d h=%d)" % (m, h),
             "value": value, "unit": "vectors/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": data_tag,
             "config": {
-                "workload": "BASELINE configs[1]: SIFT1M-shaped base encode, %d x %d f32 per GPU, m=%d, h=%d, %d ILS iters x %d ICM sweeps, "
-                            "npert=%d, randord, seed=42; inputs resident in HBM; lsq_encode_icm_dev" % (n, d, m, h, args.ils, args.icmiter, args.npert),
-                "vectors_per_gpu": n, "d": d, "m": m, "h": h, "ils_iters": args.ils, "icm_iters": args.icmiter, "npert": args.npert,
-                "schedule": {0: "per-node launches, L2 gathers (M2 data-flow)", 1: "fused sweeps per ILS iteration (M1 data-flow)",
-                             2: "per-node launches, LDS-staged table slices + combine, slice-major U stream (M2 data-flow)",
-                             3: "per-node launches, one block walks all LDS-staged slices, slice-major U stream (M2 data-flow)",
-                             4: "one launch per ILS iteration (icmiter x m node updates back to back; a block owns its vectors and walks "
-                                "all LDS-staged slices), slice-major U stream (M2 data-flow)"}[args.schedule],
-                "skip_unchanged_nodes": bool(args.skip) and args.schedule >= 3,
-                "parallelism": "%d x independent shards, RCCL broadcast of codebooks" % world,
+                "workload": "%s: %s base encode, %s, m=%d, h=%d, %d ILS iters x %d ICM sweeps, npert=%d, randord, seed=42; inputs resident "
+                            "in HBM; lsq_encode_icm_dev" % (workload, "SIFT1M-shaped" if d == 128 else "GIST1M-shaped" if d == 960 else "synthetic",
+                                                            ("%d x %d f32 per GPU" % (n, d)) if args.scaling == "weak" else
+                                                            ("%d x %d f32 in total, splitarray shards over %d GPUs" % (n_total, d, world)),
+                                                            m, h, args.ils, args.icmiter, args.npert),
+                "vectors_per_gpu": n if args.scaling == "weak" else [r["vectors"] for r in ranks], "vectors_total": n_total,
+                "d": d, "m": m, "h": h, "ils_iters": args.ils, "icm_iters": args.icmiter, "npert": args.npert,
+                "skip_unchanged_nodes": bool(args.skip),
+                "parallelism": "%d x independent shards (one process per GPU), RCCL broadcast of codebooks, no collective in the sweep" % world,
+                "rccl_ranks": world, "library": os.path.basename(lib_path), "lib_sha16": lib_sha,
             },
+            "ranks": ranks,
             "objective": float(sums[0] / n), "last_ils_pct_better": float(100.0 * stats[-1, 1] / n),
             "roofline": roof,
             "time_breakdown_ms_per_step": {k: tm[k] / args.steps for k in ("tables_ms", "unaries_ms", "perturb_ms", "icm_ms", "cost_ms", "other_ms")},
         }
+        if args.tuning and args.ablation:
+            out["INVALID"] = "ablation %d: timing-only variant, results are garbage" % args.ablation
+
+    # ---- extra legs: rank 0 of a single-GPU run only -----------------------------------------------------------------------
+    if rank == 0 and world == 1 and not args.no_extra_legs:
+        ok, detail = sample_parity(eng, dX, dB0, dK, dBs, n, m, args, goff)
+        out["sample_parity"] = ok
+        out["sample_parity_detail"] = detail
+        # end to end through the host-buffer entry point (pageable numpy buffers): H2D of X / K / codes, encode, D2H of the codes
+        if n * d * 4 <= 8 << 30:
+            Xh, Kh = dX.cpu().numpy(), dK.cpu().numpy()
+            Bh = dB0.cpu().numpy().astype(np.int16) + 1
+            eng.encode_icm(Xh[:1000], Bh[:1000], Kh, m, [1], args.icmiter, args.npert, True, seed=42)       # staging buffers allocated
+            best = None
+            for _ in range(2):
+                t0 = time.perf_counter()
+                Bs_h, objs_h = eng.encode_icm(Xh, Bh, Kh, m, [args.ils], args.icmiter, args.npert, True, seed=42, global_offset=goff)
+                e = time.perf_counter() - t0
+                best = e if best is None else min(best, e)
+            same = bool(np.array_equal(Bs_h[0].astype(np.int16) - 1, dBs[0].cpu().numpy().astype(np.int16)))      # dBs: output of the timed loop
+            out["end_to_end"] = {"value": n / best, "unit": "vectors/s", "ms_per_call": best * 1e3,
+                                 "note": "lsq_encode_icm on pageable host buffers: upload of X (%.0f MB), K and int16 codes, the whole encode, "
+                                         "download of the int16 codes; best of 2 calls; never reported as `value`" % (n * d * 4 / 1e6)}
+            out["end_to_end"]["same_codes_as_device_path"] = same
+            del Xh, Bh
+        # north_star's own operating point: 4 ILS iterations
+        ns_ils = 4
+        step(ns_ils)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(ns_ils)
+        torch.cuda.synchronize()
+        ns_dt = (time.perf_counter() - t0) / args.steps
+        out["north_star_point"] = {"ils_iters": ns_ils, "value": n / ns_dt, "unit": "vectors/s", "ms_per_step": ns_dt * 1e3,
+                                   "note": "north_star quotes its >= 50x target at 4 ILS iterations; same workload otherwise"}
+        if args.multi_leg:
+            devs = list(range(ndev)) if ndev > 1 else [0, 0]
+            Xh, Kh = dX.cpu().numpy(), dK.cpu().numpy()
+            Bh = dB0.cpu().numpy().astype(np.int16) + 1
+            with lsq.MultiEngine(devs) as mg:
+                mg.encode_icm(Xh[:4000], Bh[:4000], Kh, m, [1], args.icmiter, args.npert, True, seed=42)
+                t0 = time.perf_counter()
+                mg.encode_icm(Xh, Bh, Kh, m, [args.ils], args.icmiter, args.npert, True, seed=42, global_offset=goff)
+                e = time.perf_counter() - t0
+            out["lsq_multi"] = {"devices": devs, "value": n / e, "unit": "vectors/s", "ms_per_call": e * 1e3,
+                                "note": "single-process multi-GPU entry point (one context + host thread per listed device, splitarray shards, host buffers)"}
+            del Xh, Bh
+        # keep the device busy long enough for an external utilisation sampler; doubles as a steady-state check of `value`
+        extra, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t_gpu0 < args.min_gpu_seconds and extra < 400:
+            step()
+            extra += 1
+        torch.cuda.synchronize()
+        if extra:
+            out["steady_state"] = {"extra_untimed_steps": extra, "ms_per_step": (time.perf_counter() - t1) / extra * 1e3}
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
-            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+            cb = cpu_baseline(args)
+            out["cpu_baseline"] = cb
+            out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
+            if "north_star_point" in out:
+                ns = out["north_star_point"]
+                ns["cpu_baseline"] = {"value": cb["value"] * args.ils / ns["ils_iters"], "unit": "vectors/s", "cores": cb["cores"], "kind": "port",
+                                      "sample": "same measurement as cpu_baseline (%.3f s per ILS iteration of the 100 000-vector sample), "
+                                                "scaled to %d iterations" % (cb["seconds_per_ils_iteration"], ns["ils_iters"])}
+                ns["speedup_vs_cpu_baseline"] = ns["value"] / ns["cpu_baseline"]["value"]
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

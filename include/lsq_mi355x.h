@@ -104,6 +104,10 @@ LSQ_API int lsq_set_stream(lsq_ctx *ctx, void *hip_stream);
  *        last minimised is not recomputed (exact memoisation -- same codes, fewer bytes). */
 LSQ_API int lsq_set_option(lsq_ctx *ctx, const char *key, int64_t value);
 LSQ_API int lsq_get_timings(lsq_ctx *ctx, lsq_timings *out);
+/* Node updates actually recomputed (not memoised) per POSITION in an ILS iteration's node sequence, position = sweep * m + rank in
+ * the visiting order (mod 64), summed over ILS iterations, chunks and calls since the last lsq_reset_timings: the device-side
+ * counterpart of the reference's per-iteration "% equal / % better" prints, for the sweeps.  out[count], count <= 64. */
+LSQ_API int lsq_get_walk_trace(lsq_ctx *ctx, int64_t *out, int count);
 LSQ_API int lsq_reset_timings(lsq_ctx *ctx);
 LSQ_API int lsq_synchronize(lsq_ctx *ctx);
 

@@ -44,6 +44,7 @@ SIGNATURES = {
     "lsq_set_stream": (_i, [_vp, _vp]),
     "lsq_set_option": (_i, [_vp, C.c_char_p, _i64]),
     "lsq_get_timings": (_i, [_vp, C.POINTER(Timings)]),
+    "lsq_get_walk_trace": (_i, [_vp, _vp, _i]),
     "lsq_reset_timings": (_i, [_vp]),
     "lsq_synchronize": (_i, [_vp]),
     "lsq_multi_create": (_i, [C.POINTER(_vp), _vp, _i]),

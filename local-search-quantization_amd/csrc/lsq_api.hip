@@ -73,6 +73,7 @@ struct lsq_ctx {
     // timings
     double cat_ms[CAT_COUNT] = {0, 0, 0, 0, 0, 0};
     int64_t icm_launches = 0, icm_node_updates = 0, staged_blocks = 0, light_blocks = 0, team_blocks = 0;
+    int64_t trace[LSQ_WALK_TRACE] = {0};
     struct Pending { hipEvent_t a, b; int cat; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> pool;
@@ -205,11 +206,18 @@ extern "C" int lsq_get_timings(lsq_ctx *c, lsq_timings *out) {
     return LSQ_OK;
 }
 
+extern "C" int lsq_get_walk_trace(lsq_ctx *c, int64_t *out, int count) {
+    if (!c || !out || count < 0) { lsq_set_error("lsq_get_walk_trace: bad arguments"); return LSQ_EINVAL; }
+    for (int q = 0; q < count; ++q) out[q] = q < LSQ_WALK_TRACE ? c->trace[q] : 0;
+    return LSQ_OK;
+}
+
 extern "C" int lsq_reset_timings(lsq_ctx *c) {
     LSQ_TRY(use_device(c));
     LSQ_TRY(resolve_timings(c));
     for (double &v : c->cat_ms) v = 0.0;
     c->icm_launches = c->icm_node_updates = c->staged_blocks = c->light_blocks = c->team_blocks = 0;
+    for (int64_t &v : c->trace) v = 0;
     return LSQ_OK;
 }
 
@@ -326,13 +334,13 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t c
         std::vector<int32_t> seq((size_t)nsweeps * m);
         for (int sw = 0; sw < nsweeps; ++sw)
             for (int q = 0; q < m; ++q) seq[(size_t)sw * m + q] = order[q];
-        LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>(), c->Ts.as<float>(), c->T.as<float>(), rec, valid, cn, m, seq.data(), (int)seq.size(), c->skip,
+        LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>(), c->Ts.as<float>(), c->T.as<float>(), rec, valid, cn, m, seq.data(), (int)seq.size(), 0, c->skip,
                                     c->active.as<unsigned long long>(), c->ablation, c->light, c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr));
         c->icm_launches += ((int64_t)seq.size() + 63) / 64;
     } else {
         for (int sw = 0; sw < nsweeps; ++sw)
             for (int q = 0; q < m; ++q)
-                LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>(), c->Ts.as<float>(), c->T.as<float>(), rec, valid, cn, m, &order[q], 1, c->skip,
+                LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>(), c->Ts.as<float>(), c->T.as<float>(), rec, valid, cn, m, &order[q], 1, sw * m + q, c->skip,
                                             c->active.as<unsigned long long>(), c->ablation, c->light, c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr));
         c->icm_launches += (int64_t)nsweeps * m;
     }
@@ -415,7 +423,7 @@ static int finish_call(lsq_ctx *c, int64_t I, int nr, double *obj_sums, int64_t 
     std::vector<unsigned long long> cnt(2 * (size_t)std::max<int64_t>(I, 1));
     LSQ_HIP(hipMemcpyAsync(obj_sums, c->obj.p, sizeof(double) * (size_t)nr, hipMemcpyDeviceToHost, c->stream));
     LSQ_HIP(hipMemcpyAsync(cnt.data(), c->counters.p, sizeof(unsigned long long) * cnt.size(), hipMemcpyDeviceToHost, c->stream));
-    unsigned long long act[LSQ_WALK_COUNTERS] = {0, 0, 0, 0};
+    unsigned long long act[LSQ_WALK_COUNTERS] = {0};
     LSQ_HIP(hipMemcpyAsync(act, c->active.p, sizeof(act), hipMemcpyDeviceToHost, c->stream));
     LSQ_HIP(hipStreamSynchronize(c->stream));
     if (c->schedule >= 3) {
@@ -423,6 +431,7 @@ static int finish_call(lsq_ctx *c, int64_t I, int nr, double *obj_sums, int64_t 
         c->staged_blocks += (int64_t)act[1];
         c->light_blocks += (int64_t)act[2];
         c->team_blocks += (int64_t)act[3];
+        for (int q = 0; q < LSQ_WALK_TRACE; ++q) c->trace[q] += (int64_t)act[4 + q];
     }
     if (stats) for (int64_t q = 0; q < 2 * I; ++q) stats[q] = (int64_t)cnt[(size_t)q];
     return LSQ_OK;

@@ -55,7 +55,7 @@ __device__ inline unsigned short known_valid(const uint32_t (&rw)[RW], int j, ui
 }
 
 #define LSQ_WALK_MAX_NODES 64
-struct WalkNodes { int count; uint8_t j[LSQ_WALK_MAX_NODES]; };      // kernel argument: node updates of one launch, in order
+struct WalkNodes { int count; int pos0; uint8_t j[LSQ_WALK_MAX_NODES]; };      // pos0: position of j[0] in the ILS iteration's node sequence (trace counters)      // kernel argument: node updates of one launch, in order
 
 // ---- LDS-walk schedule (schedules 3 and 4) ----------------------------------------------------------------
 // Same arithmetic as icm_slice_kernel, but ONE block walks all 256/SL slices for its own range of
@@ -157,6 +157,7 @@ __global__ __launch_bounds__(NT) void icm_walk_kernel(const float *__restrict__ 
         if (threadIdx.x == 0 && active_total) {            // [0] node updates recomputed, [1] staged / [2] light block-node-updates
             atomicAdd(active_total, (unsigned long long)nact);
             atomicAdd(active_total + (nact <= direct_max ? 2 : 1), 1ull);
+            atomicAdd(active_total + 4 + ((nodes.pos0 + nu) & (LSQ_WALK_TRACE - 1)), (unsigned long long)nact);
         }
         if (nact <= direct_max) {
             // LIGHT block (few active vectors: small n, or a late sweep): staging the whole (m-1) x 256 KiB table through
@@ -753,13 +754,14 @@ int lsq_walk_slice_width(int m) {
 
 // `order[nnodes]`: the node updates to run back to back inside the launch (1 = one node; icmiter*m = a whole ILS iteration)
 int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const float *T, uint8_t *rec, unsigned short *valid, int64_t n, int m,
-                        const int32_t *order, int nnodes, int use_skip, unsigned long long *active_total, int ablation, int light,
+                        const int32_t *order, int nnodes, int pos0, int use_skip, unsigned long long *active_total, int ablation, int light,
                         const uint8_t *ref_rec, const unsigned short *ref_valid) {
     if (n <= 0 || nnodes <= 0) return LSQ_OK;
     if (m < 1 || m > LSQ_MAX_M) { lsq_set_error("m = %d out of range 1..16", m); return LSQ_EINVAL; }
     for (int done = 0; done < nnodes; done += LSQ_WALK_MAX_NODES) {
         WalkNodes nodes;
         nodes.count = (nnodes - done < LSQ_WALK_MAX_NODES) ? nnodes - done : LSQ_WALK_MAX_NODES;
+        nodes.pos0 = pos0 + done;
         for (int t = 0; t < nodes.count; ++t) {
             const int j = order[done + t];
             if (j < 0 || j >= m) { lsq_set_error("node %d out of range 0..%d", j, m - 1); return LSQ_EINVAL; }

@@ -10,7 +10,8 @@
 
 #define LSQ_H 256          // candidates per codebook: one wave x float4 per lane
 #define LSQ_MAX_M 16
-#define LSQ_WALK_COUNTERS 4      // device counters of the walk kernel: node updates recomputed, staged / light / team block-node-updates
+#define LSQ_WALK_TRACE 64        // per-position (sweep * m + rank in the node order, mod 64) recomputed node updates
+#define LSQ_WALK_COUNTERS (4 + LSQ_WALK_TRACE)      // device counters of the walk kernel: [0] node updates recomputed, [1..3] staged / light / team block-node-updates, [4..] trace
 
 // ---- tuning knobs -------------------------------------------------------------------------
 // Tuning knobs (environment variables) exist in the tuning build only; the shipped library uses the measured defaults.
@@ -119,7 +120,7 @@ int lsq_launch_tables_to_slices(hipStream_t s, const float *T, float *Ts, int m,
 // U is the slice-major unary buffer of ALL nodes; T (optional) the row-major tables for light blocks' L2 gathers; order[nnodes] = node updates run back to back inside the launch
 // (a block owns its vectors for the whole launch): 1 entry = one node update, icmiter*m entries = a whole ILS iteration.
 int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const float *T, uint8_t *rec, unsigned short *valid, int64_t n, int m,
-                        const int32_t *order, int nnodes, int use_skip, unsigned long long *active_total, int ablation, int light,
+                        const int32_t *order, int nnodes, int pos0, int use_skip, unsigned long long *active_total, int ablation, int light,
                         const uint8_t *ref_rec, const unsigned short *ref_valid);
 // ref_rec / ref_valid (optional, read-only): the vectors' current records and their validity masks; a candidate that becomes
 // equal to its current record inherits those bits (exact: validity depends on the code tuple only)

@@ -86,6 +86,12 @@ class Engine:
         self._check(self._L.lsq_get_timings(self._h, C.byref(t)))
         return t.as_dict()
 
+    def walk_trace(self, count=64):
+        """recomputed node updates per position (sweep * m + rank in the visiting order) since reset_timings  [lsq_get_walk_trace]"""
+        out = np.zeros(count, dtype=np.int64)
+        self._check(self._L.lsq_get_walk_trace(self._h, out.ctypes.data, int(count)))
+        return out
+
     def reset_timings(self):
         self._check(self._L.lsq_reset_timings(self._h))
 

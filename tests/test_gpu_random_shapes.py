@@ -1,6 +1,11 @@
 """Randomised parity sweep: shapes, iteration counts and options drawn from a fixed seed, every case compared with the
 oracle on all vectors (codes bit-exact, objective 1e-5).  Complements the hand-picked cases of test_gpu_parity.py: odd
-dimensions, every m in 1..16, n around the block / pass / light-block boundaries, multi-snapshot calls, offsets."""
+dimensions, every m in 1..16, n around the block / pass / light-block boundaries, multi-snapshot calls, offsets.
+
+Which node-update path a case exercises is CONTROLLED and ASSERTED (all 40 cases used to run the L2-gather path):
+cases with t % 3 == 0 force staging (option "light" = 0), cases with t % 3 == 1 use large n (66 000 / 140 000, one chunk, at least
+one sweep) so that blocks stage naturally, the rest keep the defaults (mostly light blocks).  The device counters of
+`lsq_timings` must agree with the intent."""
 import numpy as np
 import pytest
 
@@ -27,17 +32,32 @@ def _cases():
         randord = bool(rng.integers(2))
         kind = "gauss" if rng.integers(2) else "sift"
         off = int(rng.choice([0, 0, 12345, 2 ** 33 + 7]))
-        out.append((t, d, n, m, ils, J, npert, randord, kind, off))
+        mode = ("forced", "natural", "default")[t % 3]
+        if mode == "natural":                           # every block above the light threshold (n / 256 > 256): 66 000 or 140 000, d small
+            n, d, J = int(rng.choice([66_000, 140_000])), min(d, 16), max(J, 1)
+            if m > 8:
+                ils, J = ils[:1], min(J, 2)             # keep the oracle side in seconds
+        out.append((t, d, n, m, ils, J, npert, randord, kind, off, mode))
     return out
 
 
-@pytest.mark.parametrize("case", _cases(), ids=lambda c: "c%d_d%d_n%d_m%d" % c[:4])
+@pytest.mark.parametrize("case", _cases(), ids=lambda c: "c%d_d%d_n%d_m%d_%s" % (c[:4] + (c[10],)))
 def test_random_shape_matches_oracle(lsq, oracle, case):
-    t, d, n, m, ils, J, npert, randord, kind, off = case
+    t, d, n, m, ils, J, npert, randord, kind, off, mode = case
     X, K, B0 = make_problem(d, n, m, seed=100 + t, kind=kind)
     Bs_ref, objs_ref = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, randord, 7 * t + 1, global_offset=off)
-    chunk = None if t % 3 else max(1, n // 3 + 1)          # every third case: several resident chunks
+    chunk = max(1, n // 3 + 1) if (mode != "natural" and t % 2 == 0) else None      # several resident chunks in half of the other cases
     with lsq.Engine(0, chunk=chunk) as eng:
+        if mode == "forced":
+            eng.set_option("light", 0)
         Bs, objs = eng.encode_icm(X, B0, K, m, ils, J, npert, randord, seed=7 * t + 1, global_offset=off)
+        tm = eng.timings()
     assert np.array_equal(Bs, Bs_ref), "%d of %d codes differ" % ((Bs != Bs_ref).sum(), Bs.size)
     assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0)
+    staged, light = tm["staged_blocks"] + tm["team_blocks"], tm["light_blocks"]
+    if J == 0:
+        assert staged == 0 and light == 0                  # no sweeps: perturbation + accept only
+    elif mode == "forced":
+        assert light == 0 and staged > 0, (staged, light)
+    elif mode == "natural":
+        assert staged > 0, (staged, light)

@@ -1,0 +1,170 @@
+"""GPU parity of the LDS-STAGED node-update path of the walk kernel, for every codebook count and every kernel instantiation
+family, compared with the oracle on ALL vectors (the staged path used to be oracle-tested for m = 8 only,
+because a block with <= 256 active vectors -- any n <= 65 536 -- takes the L2-gather path instead).
+
+Two ways to make blocks stage:  option "light" = 0 (always stage, any n)  and  natural staging (n large enough that every
+block holds more than 256 active vectors).  Each test asserts WHICH path ran through the device counters exported in
+`lsq_timings` (staged_blocks / light_blocks / team_blocks).
+
+Instantiation families (csrc/lsq_icm.hip, lsq_launch_icm_walk): m = 1..8 -> <M,16,DEPTH 3,1024 threads>;
+m = 9..13 -> <M,8,DEPTH 2,1024>; m = 14..16 -> <M,8,DEPTH 4,512>.  The reference demos use m = 7 (demo_lsq_gpu.jl:15);
+BASELINE cfg3 is m = 16.  Conditioning / argmin semantics under test: encode_icm.jl:72-125.
+"""
+import numpy as np
+import pytest
+
+from conftest import make_problem
+
+pytestmark = pytest.mark.gpu
+H = 256
+
+
+def _paths(eng):
+    t = eng.timings()
+    return t["staged_blocks"], t["light_blocks"], t["team_blocks"]
+
+
+@pytest.mark.parametrize("m", list(range(1, 17)))
+def test_forced_staging_every_m(lsq, oracle, m):
+    """light = 0: every block stages its table slices through LDS, whatever its active count.  n = 3000 over 256 CUs is
+    ~12 vectors per block (ragged), J = 3 sweeps, random node order; the four skip x fallback combinations must all
+    give the oracle's codes on every vector."""
+    d, n, ils, J, npert, seed = 16, 3000 + 7 * m, [1, 2], 3, min(4, m), 500 + m
+    X, K, B0 = make_problem(d, n, m, seed=seed, kind="gauss")
+    Bs_ref, objs_ref, st_ref = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, True, seed, want_stats=True)
+    for schedule in (4, 3):
+        for skip in (1, 0):
+            for fb in (1, 0):
+                if schedule == 3 and (skip, fb) != (1, 1):
+                    continue
+                with lsq.Engine(0, schedule=schedule, skip=skip) as eng:
+                    eng.set_option("light", 0)
+                    eng.set_option("fallback", fb)
+                    Bs, objs = eng.encode_icm(X, B0, K, m, ils, J, npert, True, seed=seed)
+                    staged, light, team = _paths(eng)
+                tag = "m=%d schedule=%d skip=%d fallback=%d" % (m, schedule, skip, fb)
+                assert np.array_equal(Bs, Bs_ref), "%s: %d of %d codes differ" % (tag, (Bs != Bs_ref).sum(), Bs.size)
+                assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0), tag
+                assert light == 0 and staged + team > 0, "%s: staged=%d light=%d team=%d" % (tag, staged, light, team)
+
+
+@pytest.mark.parametrize("m,n", [(7, 90_000), (12, 80_000), (16, 80_000), (3, 120_000)])
+def test_natural_staging_per_family(lsq, oracle, m, n):
+    """n >= 80 000: at least 313 vectors per block, above the light-block threshold, so the first sweeps stage naturally
+    (late sweeps of a block may still go light: both paths then serve the same vectors within one call).  One case per
+    instantiation family + the demos' m = 7."""
+    d, ils, J, npert, seed = 16, [2], 2 if m >= 12 else 3, min(4, m), 900 + m
+    X, K, B0 = make_problem(d, n, m, seed=seed, kind="gauss")
+    Bs_ref, objs_ref = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, True, seed)
+    with lsq.Engine(0) as eng:
+        Bs, objs = eng.encode_icm(X, B0, K, m, ils, J, npert, True, seed=seed)
+        staged, light, team = _paths(eng)
+    assert np.array_equal(Bs, Bs_ref), "%d of %d codes differ" % ((Bs != Bs_ref).sum(), Bs.size)
+    assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0)
+    assert staged + team > 0, "no block staged: staged=%d light=%d team=%d" % (staged, light, team)
+
+
+def test_cfg1_exact_shape_chained_calls(lsq, oracle):
+    """BASELINE configs[0] at its exact shape: n = 10 000, d = 128, m = 8, h = 256, 4 ICM sweeps, npert 4, random order --
+    what `train_lsq` runs (demos/demo_lsq.jl:34): `ilsiter` = 8 chained calls of encoding_icm, each with the accept rule
+    (encode_icm.jl:131-189).  Every call's output is compared with the oracle's reference-loop-nest restatement on all vectors."""
+    d, n, m, J, npert, seed = 128, 10_000, 8, 4, 4, 2024
+    X, K, B0 = make_problem(d, n, m, seed=seed, kind="sift")
+    Bg, Bo = B0.copy(), B0.copy()
+    with lsq.Engine(0) as eng:
+        for it in range(8):
+            Bg = eng.encoding_icm(X, Bg, K, m, J, True, npert, seed=seed, it=it)
+            Bo = oracle.encoding_icm_faithful(X, Bo, K, m, H, J, True, npert, seed, it, nworkers=oracle.num_threads())
+            assert np.array_equal(Bg, Bo), "ILS call %d: %d codes differ" % (it, (Bg != Bo).sum())
+        q = eng.qerror(X, Bg, K, m)
+    assert abs(q - oracle.qerror(X, Bo, K, m, H)) <= 1e-5 * q
+
+
+def _sample_rows_vs_oracle(oracle, X, K, B0, got, m, ils, J, npert, seed, rows, goff=0):
+    for i in rows:
+        ref, _ = oracle.encode_icm(X[i:i + 1], B0[i:i + 1], K, m, H, ils, J, npert, True, seed, global_offset=goff + int(i))
+        assert np.array_equal(ref[-1, 0], got[i]), "vector %d differs: %s vs %s" % (i, ref[-1, 0], got[i])
+
+
+def test_cfg3_m16_staged_sample_and_full_size_properties(lsq, oracle):
+    """BASELINE configs[2] (m = 16, d = 128): (a) 300 000 vectors -- 1172 per block, every first-sweep block stages with the
+    <16,8,4,512> instantiation -- a random sample of vectors must equal the oracle run on exactly those vectors (results
+    depend on the global index only, P8); (b) the full 10^6 vectors through the size-independent properties (monotone cost,
+    strict accept, objective = mean cost, invariance to chunking / sharding)."""
+    import torch
+    d, m, ils, J, npert, seed = 128, 16, [1, 2], 4, 4, 16
+    with lsq.Engine(0) as eng:
+        n = 300_000
+        dX = eng.synth_data_u8_dev(31, n, d)
+        dB0 = eng.randinit_dev(32, n, m)
+        dK = eng.synth_codebooks_dev(33, m, d)
+        dBs, sums, _ = eng.encode_icm_dev(dX, dB0, dK, m, ils, J, npert, True, seed=seed)
+        staged, light, team = _paths(eng)
+        assert staged + team > 0
+        X, K = dX.cpu().numpy(), dK.cpu().numpy()
+        B0 = dB0.cpu().numpy().astype(np.int16) + 1
+        got = dBs[1].cpu().numpy().astype(np.int16) + 1
+        rng = np.random.default_rng(3)
+        rows = np.sort(np.concatenate([rng.choice(n, size=40, replace=False), [0, n - 1]]))
+        _sample_rows_vs_oracle(oracle, X, K, B0, got, m, ils, J, npert, seed, rows)
+        del dX, dB0, dBs
+        # (b) full size
+        n = 1_000_000
+        dX = eng.synth_data_u8_dev(31, n, d)
+        dB0 = eng.randinit_dev(32, n, m)
+        dBs, sums, stats = eng.encode_icm_dev(dX, dB0, dK, m, ils, J, npert, True, seed=seed)
+        torch.cuda.synchronize()
+        X = dX.cpu().numpy()
+        B0 = dB0.cpu().numpy().astype(np.int16) + 1
+        B1 = dBs[0].cpu().numpy().astype(np.int16) + 1
+        B2 = dBs[1].cpu().numpy().astype(np.int16) + 1
+        c0, c1, c2 = (eng.veccost(X, B, K, m) for B in (B0, B1, B2))
+        assert np.all(c1 <= c0) and np.all(c2 <= c1)
+        assert np.array_equal(B1[c1 == c0], B0[c1 == c0]) and np.array_equal(B2[c2 == c1], B1[c2 == c1])
+        assert abs(sums[1] / n - c2.astype(np.float64).mean()) <= 1e-6 * sums[1] / n
+        assert stats[0, 1] == int((c1 < c0).sum()) and stats[1, 1] == int((c2 < c1).sum())
+        rows = np.sort(rng.choice(n, size=16, replace=False))
+        _sample_rows_vs_oracle(oracle, X, K, B0, B2, m, ils, J, npert, seed, rows)
+        h1 = 333_337
+        with lsq.Engine(0, chunk=250_000) as e2:
+            a, sa, _ = e2.encode_icm_dev(dX[:h1].contiguous(), dB0[:h1].contiguous(), dK, m, ils, J, npert, True, seed=seed, global_offset=0)
+            b, sb, _ = e2.encode_icm_dev(dX[h1:].contiguous(), dB0[h1:].contiguous(), dK, m, ils, J, npert, True, seed=seed, global_offset=h1)
+        assert torch.equal(torch.cat([a, b], dim=1), dBs)
+        assert np.allclose(sa + sb, sums, rtol=1e-9)
+
+
+def test_cfg5_chunk_walk(lsq, oracle):
+    """BASELINE configs[4] per-GPU mechanics at reduced length: 3 x 10^6 + 17 vectors generated ON THE DEVICE from the global
+    Philox stream (rank offset 12.5 M, as rank 1 of the 8-GPU job would use), walked in resident chunks of 2^20 (the default).
+    Checks: sampled rows around every chunk boundary and at random == the oracle on exactly those vectors; objective = mean cost;
+    identical codes with another chunk size (P8)."""
+    import torch
+    d, m, ils, J, npert, seed = 128, 8, [2], 4, 4, 5
+    n, goff = 3_000_017, 12_500_000
+    with lsq.Engine(0) as eng, lsq.Engine(0, chunk=700_001) as e2:
+        dX = eng.synth_data_u8_dev(1234, n, d, global_offset=goff)
+        dB0 = eng.randinit_dev(7, n, m, global_offset=goff)
+        dK = eng.synth_codebooks_dev(4321, m, d)
+        dBs, sums, stats = eng.encode_icm_dev(dX, dB0, dK, m, ils, J, npert, True, seed=seed, global_offset=goff)
+        staged, light, team = _paths(eng)
+        assert staged + team > 0
+        dBs2, sums2, stats2 = e2.encode_icm_dev(dX, dB0, dK, m, ils, J, npert, True, seed=seed, global_offset=goff)
+        assert torch.equal(dBs, dBs2) and np.allclose(sums, sums2, rtol=1e-9) and np.array_equal(stats, stats2)
+        K = dK.cpu().numpy()
+        rng = np.random.default_rng(9)
+        rows = [0, n - 1] + [c * (1 << 20) + o for c in (1, 2) for o in (-1, 0, 1)] + list(rng.choice(n, size=20, replace=False))
+        rows = np.array(sorted(set(int(r) for r in rows)))
+        idx = torch.from_numpy(rows).to(dX.device)
+        Xs = dX[idx].cpu().numpy()
+        B0s = dB0[idx].cpu().numpy().astype(np.int16) + 1
+        gots = dBs[0][idx].cpu().numpy().astype(np.int16) + 1
+        for q, i in enumerate(rows):
+            assert np.array_equal(Xs[q], oracle.synth_data_u8(1234, 1, d, global_offset=goff + int(i))[0])      # the generator keys on the global index
+            ref, _ = oracle.encode_icm(Xs[q:q + 1], B0s[q:q + 1], K, m, H, ils, J, npert, True, seed, global_offset=goff + int(i))
+            assert np.array_equal(ref[0, 0], gots[q]), "vector %d differs" % i
+        # objective = mean cost of the returned codes (P10), on the first million
+        q = 1_000_000
+        c = eng.veccost(dX[:q].cpu().numpy(), dBs[0][:q].cpu().numpy().astype(np.int16) + 1, K, m)
+        dq, sq, _ = eng.encode_icm_dev(dX[:q].contiguous(), dB0[:q].contiguous(), dK, m, ils, J, npert, True, seed=seed, global_offset=goff)
+        assert torch.equal(dq[0], dBs[0][:q])
+        assert abs(sq[0] / q - c.astype(np.float64).mean()) <= 1e-6 * sq[0] / q

@@ -1,4 +1,4 @@
-"""tools/pmc_summary.py DIR TAG -- condense the rocprofv3 passes of tools/profile_round.sh into the files kept under profiles/:
+"""tools/pmc_summary.py DIR TAG [bench args...] -- condense the rocprofv3 passes of tools/profile_round.sh into the files kept under profiles/:
    TAG_bench_kernel_stats.csv  (rocprofv3's own --stats summary, copied)
    TAG_pmc_per_kernel.json     (mean counter value per dispatch per kernel; FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them)
    TAG_bench_line.json         (bench.py's JSON line of the same build)"""
@@ -39,6 +39,12 @@ def main():
                 out.setdefault(short(row["Name"]), {})["stats"] = {
                     "calls": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3, "pct": float(row["Percentage"]),
                     "min_us": float(row["MinNs"]) / 1e3, "max_us": float(row["MaxNs"]) / 1e3}
+    # which build the counters belong to: bench.py reports `traffic` only when this hash equals the hash of the library it loaded
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "local-search-quantization_amd", "liblsq_mi355x.so")
+    out["_build"] = {"lib_sha16": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16] if os.path.exists(lib) else None,
+                     "bench_args": " ".join(sys.argv[3:])}
     json.dump(out, open(os.path.join(d, "%s_pmc_per_kernel.json" % tag), "w"), indent=1, sort_keys=True)
     bl = os.path.join(d, "bench_line.json")
     if os.path.exists(bl):
