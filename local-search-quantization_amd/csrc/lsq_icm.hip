@@ -54,22 +54,62 @@ __device__ inline unsigned short known_valid(const uint32_t (&rw)[RW], int j, ui
     return same ? *refv : (unsigned short)0;
 }
 
-#define LSQ_WALK_MAX_NODES 64
-struct WalkNodes { int count; int pos0; uint8_t j[LSQ_WALK_MAX_NODES]; };      // pos0: position of j[0] in the ILS iteration's node sequence (trace counters)      // kernel argument: node updates of one launch, in order
+// Result of a node update for vector i: code j <- the index part of the packed minimum key; validity bookkeeping (exact skip):
+// a changed code invalidates every other node, an unchanged one confirms node j; what is known about the vector's current
+// state is imported when the candidate tuple equals it (known_valid).
+template <int CS>
+__device__ inline void apply_node_result(uint8_t *__restrict__ rec, unsigned short *__restrict__ valid, int64_t i, int j, unsigned long long key,
+                                         const uint8_t *__restrict__ ref_rec, const unsigned short *__restrict__ ref_valid) {
+    constexpr int RW = CS / 4;
+    const unsigned bi = (unsigned)(key & 0xffffffffull);
+    const uint8_t code = (uint8_t)(bi > 255 ? 0 : bi);
+    uint32_t rw[RW];                                     // the record before the update (one aligned load instead of a byte load)
+#pragma unroll
+    for (int w2 = 0; w2 < RW; ++w2) rw[w2] = reinterpret_cast<const uint32_t *>(rec + i * CS)[w2];
+    const uint8_t old = (uint8_t)(rw[j >> 2] >> (8 * (j & 3)));
+    rec[i * CS + j] = code;
+    if (valid) {
+        unsigned short vm = (code != old) ? (unsigned short)(1u << j) : (unsigned short)(valid[i] | (1u << j));
+        vm = (unsigned short)(vm | known_valid<RW>(rw, j, code, ref_rec ? ref_rec + i * CS : nullptr, ref_valid ? ref_valid + i : nullptr));
+        valid[i] = vm;
+    }
+}
 
-// ---- LDS-walk schedule (schedules 3 and 4) ----------------------------------------------------------------
-// Same arithmetic as icm_slice_kernel, but ONE block walks all 256/SL slices for its own range of
-// <= 4096 vectors, keeping the running (min value, index) of every vector in LDS.  This removes the
-// partial-result round trip through HBM (2 x 8 B x 256/SL per vector and node update) and the combine
-// launch; the price is re-staging the (m-1) x 256 x SL x 4 B slice table from L2 once per slice.
-// Ts is the slice-major copy of the pair tables, Ts[j][slice][kk][b][SL] (kk = rank of k among k != j),
-// so that staging is one contiguous, fully coalesced copy.
-template <int M, int SL, int ABL = 0, int DEPTH = 2, int NT = 1024>      // NT: threads per block (1024 or 512); DEPTH: U items in flight per wave (<= 8); ABL: timing-only ablations (1: no U stream, 2: no table adds, 3: no slice barriers, 4: U stream only -- no table adds, staging or barriers), option "ablation"
+#define LSQ_WALK_MAX_NODES 64
+struct WalkNodes { int count; int pos0; uint8_t j[LSQ_WALK_MAX_NODES]; };      // kernel argument: the node updates of one launch, in order; pos0 = position of j[0] in the ILS iteration's node sequence (trace counters)
+
+// ---- adaptive ("team") mode of a ONE-node launch ---------------------------------------------------------------------------
+// Why: a block that walks all 256/SL slices pulls the node's whole (m-1) x 256 KiB table L2 -> LDS whatever its number of active
+// vectors: 448 MiB per node update over 256 CUs = 34-41 us at the ~13 TB/s the L2s deliver when every CU reads the same lines
+// (profiles/r02a_sweep_breakdown.json: sweep 4 with 6 % of the vectors active still takes 51 us; n = 10^5 runs at 0.4x the rate of
+// n = 10^6).  A TEAM of S blocks shares a vector range S times longer instead: member g stages only slices [g NS/S, (g+1) NS/S) and
+// posts one packed partial key per active vector; icm_apply_scan_kernel (next launch) takes the lowest-index minimum over the S
+// partials and builds the next node's active lists.  S is chosen ON THE DEVICE from the node's active count, identically by every
+// block of both kernels: S = 1 (this kernel's ordinary path, block-local apply) while the active vectors fill the blocks.
+// Segment b = vectors [b per_pass, (b+1) per_pass) -- the range a block owns when S = 1; team r owns segments [r S, (r+1) S).
+#define LSQ_SEG_STRIDE 4096          // entries per segment list (>= per_pass)
+#define LSQ_TEAM_MAX 16
+struct TeamArgs {
+    const unsigned *segcount;        // [npass] active vectors of this node per segment       (written by icm_apply_scan_kernel)
+    const unsigned short *seglist;   // [npass][LSQ_SEG_STRIDE] their indices within the segment, ascending
+    unsigned long long *part;        // [smax][n] packed partial keys, member-major
+    int npass;                       // number of segments
+    int smax;                        // largest team size allowed: 1, 2, 4, 8 or 16 (option "team")
+    int cap;                         // active vectors per team the size choice aims at (< PP: room for imbalance; an overflowing team runs in chunks)
+};
+// ---- LDS-walk kernel -------------------------------------------------------------------------------------------------------
+// ONE block walks the 256/SL slices of a node for its own range of <= 4096 vectors, keeping the running (min value, index) of
+// every vector in LDS as a packed 64-bit key.  Ts is the slice-major copy of the pair tables, Ts[j][slice][kk][b][SL]
+// (kk = rank of k among k != j), so that staging one slice is one contiguous, fully coalesced copy of (m-1) x 256 x SL x 4 B.
+// NT: threads per block (1024 or 512); DEPTH: U items in flight per wave (<= 8); ABL (tuning build only): timing-only ablations
+// (1: no U stream, 2: no table adds, 3: no slice barriers, 4: U stream only); ADAPT: one-node launch with device-chosen team size.
+template <int M, int SL, int ABL = 0, int DEPTH = 2, int NT = 1024, bool ADAPT = false>
 __global__ __launch_bounds__(NT) void icm_walk_kernel(const float *__restrict__ U, const float *__restrict__ Ts, const float *__restrict__ T,
                                                         uint8_t *__restrict__ rec, unsigned short *__restrict__ valid,
                                                         int64_t n, const WalkNodes nodes, int per_pass, int use_skip, int direct_max,
                                                         unsigned long long *__restrict__ active_total,
-                                                        const uint8_t *__restrict__ ref_rec, const unsigned short *__restrict__ ref_valid) {
+                                                        const uint8_t *__restrict__ ref_rec, const unsigned short *__restrict__ ref_valid,
+                                                        const TeamArgs team) {
     constexpr int CS = (M <= 8) ? 8 : 16;
     constexpr int NS = LSQ_H / SL;
     constexpr int LPV = SL / 4;
@@ -97,6 +137,204 @@ __global__ __launch_bounds__(NT) void icm_walk_kernel(const float *__restrict__ 
 
     struct Item { f32x4 u; uint32_t r[RW]; };
 
+    // Walks slices [s_begin, s_end) of node j for the `nact` vectors listed in list[] (indices relative to `lo`; dense = the list is
+    // the identity) and leaves every vector's packed running minimum in best64[] (initialised by the caller).  Ends with a barrier.
+    auto walk_slices = [&](const int j, const int64_t lo, const int nact, const bool dense, const int s_begin, const int s_end) {
+        const float *__restrict__ Usj = U + (int64_t)j * n * LSQ_H;
+        const float *__restrict__ Tsj = Ts + (int64_t)j * NS * TAB * 4;
+        uint32_t sel[CW > 0 ? CW : 1];      // v_perm_b32 selectors: compact word w takes the conditioning codes k(4w..4w+3) (ascending k, j skipped)
+#pragma unroll
+        for (int w = 0; w < CW; ++w) {
+            uint32_t sv = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int kk = 4 * w + t;
+                const int k = kk + (kk >= j ? 1 : 0);
+                sv |= (uint32_t)((kk < M - 1 ? k - 4 * w : 0) & 7) << (8 * t);
+            }
+            sel[w] = sv;
+        }
+        constexpr int NST = (TAB + NT - 1) / NT;               // float4 table entries staged per thread
+        f32x4 nxt[NST > 0 ? NST : 1];
+        auto prefetch_tab = [&](int sl) {
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(Tsj) + (int64_t)sl * TAB;
+#pragma unroll
+            for (int r = 0; r < NST; ++r) {
+                const int e = (int)threadIdx.x + r * NT;
+                nxt[r] = (e < TAB) ? src[e] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        prefetch_tab(s_begin);
+
+        // The U stream is ONE flat software pipeline over (slice, iteration), DEPTH items in flight per
+        // wave (3 at 1024 threads: the most that fits 128 VGPRs without spills, 1 % faster than 2; 4..8 at 512 threads: slower at m = 8): the loads of the first iterations of slice s+1 are in flight
+        // while slice s finishes.  The two item buffers have STATIC roles (loop unrolled by two, the
+        // roles swap when a slice has an odd iteration count) so no register copies are issued: the
+        // kernel is instruction-issue bound (ablations in DESIGN.md), every slot counts.
+        const int ipw = (wave * VPW < nact) ? (nact - wave * VPW + step - 1) / step : 0;   // iterations per slice, this wave
+        int ls = s_begin, lit = 0;                             // (slice, iteration) of the next load to issue
+        auto load_next = [&](Item &it) {
+            // always in bounds (indices clamped): no exec-mask juggling; results of clamped lanes are discarded
+            int ci = wave * VPW + lit * step + v;
+            ci = ci < nact ? ci : nact - 1;
+            const int lsc = ls < s_end ? ls : s_end - 1;
+            // wave-uniform 64-bit bases (SGPRs) + 32-bit lane offsets: one VALU instruction per address instead of a 64-bit chain
+            uint32_t li = (uint32_t)ci;                        // dense block (every vector active): the list is the identity,
+            if (!dense) li = list[ci];                         // skip the LDS round trip in front of the load addresses
+            const char *ub = reinterpret_cast<const char *>(Usj + ((int64_t)lsc * n + lo) * SL);
+            const char *rb = reinterpret_cast<const char *>(rec + lo * CS);
+            const uint32_t uo = li * (uint32_t)(SL * 4) + (uint32_t)q * 16u;
+            if (ABL == 1) it.u = (f32x4){(float)li, 1.f, 2.f, 3.f};
+            else it.u = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(ub + uo));      // streamed once per node update: non-temporal measured 3 % faster than a cached load
+            const uint32_t *rp = reinterpret_cast<const uint32_t *>(rb + li * (uint32_t)CS);
+#pragma unroll
+            for (int w = 0; w < RW; ++w) it.r[w] = rp[w];
+            if (++lit >= ipw) { lit = 0; ++ls; }
+        };
+        auto gather = [&](const Item &cur) -> f32x4 {
+            f32x4 s = cur.u;
+#pragma unroll
+            for (int w = 0; w < CW; ++w) {
+                const uint32_t hiw = (w + 1 < RW) ? cur.r[w + 1] : 0u;
+                const uint32_t cw = __builtin_amdgcn_perm(hiw, cur.r[w], sel[w]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int kk = 4 * w + t;
+                    if (kk < M - 1) {
+                        uint32_t code;
+                        // low byte through an opaque v_and so that the address is and + lshl_add (the optimiser's own form,
+                        // (cw << 6) & 0x3fc0 then + base, is one VALU instruction longer); the others are bfe/lshr + lshl_add
+                        if (t == 0) asm("v_and_b32 %0, 0xff, %1" : "=v"(code) : "v"(cw));
+                        else code = (cw >> (8 * t)) & 0xffu;
+                        if (ABL != 2 && ABL != 4) s = s + tab[(kk * LSQ_H + code) * LPV + q];      // ascending k, plain f32 add
+                        else s.x += (float)code;
+                    }
+                }
+            }
+            return s;
+        };
+        auto finish = [&](f32x4 s, int slice, int c0) {
+            // first-argmin: in-lane over 4 candidates, then one packed LDS atomic min per lane
+            float lm = fminf(fminf(s.x, s.y), fminf(s.z, s.w));
+            uint32_t li = (s.z == lm) ? 2u : 3u;                               // three selects, no divergent control flow
+            li = (s.y == lm) ? 1u : li;
+            li = (s.x == lm) ? 0u : li;
+            li += 4u * q + (uint32_t)(SL * slice);
+            const uint32_t bits = __float_as_uint(lm + 0.0f);                  // -0 -> +0: they compare equal in the reference
+            uint32_t ord = bits ^ ((uint32_t)((int32_t)bits >> 31) | 0x80000000u);   // monotone float -> uint
+            // only the lane(s) holding the minimum of the vector's LPV lanes post it (DPP mins within the quad): 4x fewer LDS
+            // atomics and no same-address serialisation (15 % of the LDS cycles); equal minima all post, the packed key orders them
+            float vm = lm;
+            if (LPV >= 2) vm = fminf(vm, dpp_self<DPP_XOR1, 0xf>(vm));
+            if (LPV >= 4) vm = fminf(vm, dpp_self<DPP_XOR2, 0xf>(vm));
+            bool post = (lm == vm);                                            // false for a NaN lane: NaN never wins ...
+            if (__builtin_expect(__ballot((lm != lm) | (s.x != s.x)) != 0ull, 0)) {       // wave-uniform, rare: a NaN is present
+                if ((slice == 0) & (q == 0) & (s.x != s.x)) { ord = 0u; li = 0u; post = true; }   // ... except s[0]: the strict-< scan keeps index 0
+            }
+            if ((c0 + v < nact) & post) atomicMin(&best64[c0 + v], ((unsigned long long)ord << 32) | li);
+        };
+        auto compute = [&](const Item &cur, int slice, int c0) { finish(gather(cur), slice, c0); };
+        Item buf[DEPTH];
+#pragma unroll
+        for (int e = 0; e < DEPTH; ++e) load_next(buf[e]);
+        int phase = 0;                                         // index of the buffer holding the next item to consume
+
+        for (int slice = s_begin; slice < s_end; ++slice) {
+            if (ABL < 3) __syncthreads();                      // everyone is done with the previous slice table
+#pragma unroll
+            for (int r = 0; r < NST; ++r) {                    // commit the table prefetched one slice ago
+                const int e = (int)threadIdx.x + r * NT;
+                if (e < TAB && ABL != 4) tab[e] = nxt[r];
+            }
+            if (ABL < 3) __syncthreads();
+            if (slice + 1 < s_end && ABL != 4) prefetch_tab(slice + 1);       // next slice's table travels L2 -> VGPRs under this slice's work
+            int c0 = wave * VPW, t = 0;
+            auto run = [&](auto P_) {                          // P = buffer consumed first; all buffer indices are compile-time
+                constexpr int P = decltype(P_)::value;
+                for (; t + DEPTH <= ipw; t += DEPTH) {
+#pragma unroll
+                    for (int e = 0; e < DEPTH; ++e) {
+                        compute(buf[(P + e) % DEPTH], slice, c0); load_next(buf[(P + e) % DEPTH]); c0 += step;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < DEPTH - 1; ++e)
+                    if (t < ipw) {
+                        compute(buf[(P + e) % DEPTH], slice, c0); load_next(buf[(P + e) % DEPTH]); c0 += step;
+                        ++t; phase = (P + e + 1) % DEPTH;
+                    }
+            };
+            bool ran = false;                                  // run() changes `phase`: exactly one instantiation per slice
+            auto try_phase = [&](auto P_) {
+                if constexpr (decltype(P_)::value < DEPTH) {
+                    if (!ran && phase == decltype(P_)::value) { run(P_); ran = true; }
+                }
+            };
+            try_phase(std::integral_constant<int, 0>{}); try_phase(std::integral_constant<int, 1>{});
+            try_phase(std::integral_constant<int, 2>{}); try_phase(std::integral_constant<int, 3>{});
+            try_phase(std::integral_constant<int, 4>{}); try_phase(std::integral_constant<int, 5>{});
+            try_phase(std::integral_constant<int, 6>{}); try_phase(std::integral_constant<int, 7>{});
+        }
+        __syncthreads();
+    };
+
+    if constexpr (ADAPT) {
+        // ---- team size of this node update, from the per-segment active counts (identical in every block and in icm_apply_scan_kernel)
+        __shared__ unsigned segoff_s[LSQ_TEAM_MAX + 1];
+        unsigned mine = 0;
+        for (int b = threadIdx.x; b < team.npass; b += NT) mine += team.segcount[b];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
+        if (lane == 0) wave_tot[wave] = (int)mine;
+        __syncthreads();
+        unsigned long long active = 0;
+        for (int w2 = 0; w2 < NW; ++w2) active += (unsigned)wave_tot[w2];
+        __syncthreads();                                          // wave_tot is reused by the compaction below
+        if (active == 0) return;
+        const int S = lsq_team_size(active, team.npass, (int)gridDim.x, team.smax, team.cap);
+        if (S > 1) {
+            const int j = nodes.j[0];
+            const int g = (int)blockIdx.x % S;                    // member: blocks b, b + 8, ... share an XCD, so each XCD's L2 holds 1/S of the node's table
+            const int nteams = (int)gridDim.x / S;
+            const int nranges = (team.npass + S - 1) / S;
+            const int s_begin = g * NS / S, s_end = (g + 1) * NS / S;
+            for (int r = (int)blockIdx.x / S; r < nranges; r += nteams) {
+                const int seg0 = r * S;
+                const int nseg = (team.npass - seg0 < S) ? team.npass - seg0 : S;
+                if (threadIdx.x == 0) {                           // offsets of the team's segments in its concatenated active list
+                    unsigned o = 0;
+                    for (int sg = 0; sg <= LSQ_TEAM_MAX; ++sg) { segoff_s[sg] = o; if (sg < nseg) o += team.segcount[seg0 + sg]; }
+                }
+                __syncthreads();
+                const int total = (int)segoff_s[LSQ_TEAM_MAX];
+                const int64_t lo = (int64_t)seg0 * per_pass;
+                for (int c0 = 0; c0 < total; c0 += PP) {            // one chunk unless the range's active list overflows the LDS bookkeeping
+                    const int nact = (total - c0 < PP) ? total - c0 : PP;
+                    for (int ci = threadIdx.x; ci < nact; ci += NT) {
+                        const unsigned pos = (unsigned)(c0 + ci);
+                        int sg = 0;
+#pragma unroll
+                        for (int t = 1; t < LSQ_TEAM_MAX; ++t) sg += (t < nseg && segoff_s[t] <= pos) ? 1 : 0;      // segoff_s is non-decreasing
+                        list[ci] = (unsigned short)(sg * per_pass + team.seglist[(size_t)(seg0 + sg) * LSQ_SEG_STRIDE + (pos - segoff_s[sg])]);
+                        best64[ci] = ~0ull;
+                    }
+                    if (threadIdx.x == 0 && active_total) {       // [0] node updates recomputed (counted once per team), [3] team block-node-updates
+                        if (g == 0) {
+                            atomicAdd(active_total, (unsigned long long)nact);
+                            atomicAdd(active_total + 4 + (nodes.pos0 & (LSQ_WALK_TRACE - 1)), (unsigned long long)nact);
+                        }
+                        atomicAdd(active_total + 3, 1ull);
+                    }
+                    __syncthreads();
+                    walk_slices(j, lo, nact, false, s_begin, s_end);
+                    for (int ci = threadIdx.x; ci < nact; ci += NT) team.part[(size_t)g * (size_t)n + (size_t)(lo + list[ci])] = best64[ci];
+                    __syncthreads();
+                }
+            }
+            return;
+        }
+    }
+
     const int64_t npass = (n + per_pass - 1) / per_pass;
     for (int64_t pass = blockIdx.x; pass < npass; pass += gridDim.x) {
         const int64_t lo = pass * per_pass;
@@ -109,20 +347,6 @@ __global__ __launch_bounds__(NT) void icm_walk_kernel(const float *__restrict__ 
         for (int nu = 0; nu < nodes.count; ++nu) {
         const int j = nodes.j[nu];
         const float *__restrict__ Usj = U + (int64_t)j * n * LSQ_H;
-        const float *__restrict__ Tsj = Ts + (int64_t)j * NS * TAB * 4;
-        uint32_t sel[CW > 0 ? CW : 1];
-    #pragma unroll
-        for (int w = 0; w < CW; ++w) {
-            uint32_t sv = 0;
-    #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int kk = 4 * w + t;
-                const int k = kk + (kk >= j ? 1 : 0);
-                sv |= (uint32_t)((kk < M - 1 ? k - 4 * w : 0) & 7) << (8 * t);
-            }
-            sel[w] = sv;
-        }
-
         // ---- compact list of the vectors whose node j must be recomputed (exact skip: a node whose
         // conditioning codes did not change since it was last minimised keeps the same argmin)
         {
@@ -194,148 +418,78 @@ __global__ __launch_bounds__(NT) void icm_walk_kernel(const float *__restrict__ 
         }
         for (int ci = threadIdx.x; ci < nact; ci += NT) best64[ci] = ~0ull;      // ordered before the first atomics by the slice-0 barriers
 
-        constexpr int NST = (TAB + NT - 1) / NT;               // float4 table entries staged per thread
-        f32x4 nxt[NST > 0 ? NST : 1];
-        auto prefetch_tab = [&](int sl) {
-            const f32x4 *src = reinterpret_cast<const f32x4 *>(Tsj) + (int64_t)sl * TAB;
-#pragma unroll
-            for (int r = 0; r < NST; ++r) {
-                const int e = (int)threadIdx.x + r * NT;
-                nxt[r] = (e < TAB) ? src[e] : (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-        };
-        prefetch_tab(0);
-
-        // The U stream is ONE flat software pipeline over (slice, iteration), DEPTH items in flight per
-        // wave (3 at 1024 threads: the most that fits 128 VGPRs without spills, 1 % faster than 2; 4..8 at 512 threads: slower at m = 8): the loads of the first iterations of slice s+1 are in flight
-        // while slice s finishes.  The two item buffers have STATIC roles (loop unrolled by two, the
-        // roles swap when a slice has an odd iteration count) so no register copies are issued: the
-        // kernel is instruction-issue bound (ablations in DESIGN.md), every slot counts.
-        const int ipw = (wave * VPW < nact) ? (nact - wave * VPW + step - 1) / step : 0;   // iterations per slice, this wave
-        int ls = 0, lit = 0;                                   // (slice, iteration) of the next load to issue
-        const bool dense = (nact == cnt);                      // block-uniform
-        auto load_next = [&](Item &it) {
-            // always in bounds (indices clamped): no exec-mask juggling; results of clamped lanes are discarded
-            int ci = wave * VPW + lit * step + v;
-            ci = ci < nact ? ci : nact - 1;
-            const int lsc = ls < NS ? ls : NS - 1;
-            // wave-uniform 64-bit bases (SGPRs) + 32-bit lane offsets: one VALU instruction per address instead of a 64-bit chain
-            uint32_t li = (uint32_t)ci;                        // dense block (every vector active): the list is the identity,
-            if (!dense) li = list[ci];                         // skip the LDS round trip in front of the load addresses
-            const char *ub = reinterpret_cast<const char *>(Usj + ((int64_t)lsc * n + lo) * SL);
-            const char *rb = reinterpret_cast<const char *>(rec + lo * CS);
-            const uint32_t uo = li * (uint32_t)(SL * 4) + (uint32_t)q * 16u;
-            if (ABL == 1) it.u = (f32x4){(float)li, 1.f, 2.f, 3.f};
-            else it.u = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(ub + uo));      // streamed once per node update: non-temporal measured 3 % faster than a cached load
-            const uint32_t *rp = reinterpret_cast<const uint32_t *>(rb + li * (uint32_t)CS);
-#pragma unroll
-            for (int w = 0; w < RW; ++w) it.r[w] = rp[w];
-            if (++lit >= ipw) { lit = 0; ++ls; }
-        };
-        auto gather = [&](const Item &cur) -> f32x4 {
-            f32x4 s = cur.u;
-#pragma unroll
-            for (int w = 0; w < CW; ++w) {
-                const uint32_t hiw = (w + 1 < RW) ? cur.r[w + 1] : 0u;
-                const uint32_t cw = __builtin_amdgcn_perm(hiw, cur.r[w], sel[w]);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int kk = 4 * w + t;
-                    if (kk < M - 1) {
-                        uint32_t code;
-                        // low byte through an opaque v_and so that the address is and + lshl_add (the optimiser's own form,
-                        // (cw << 6) & 0x3fc0 then + base, is one VALU instruction longer); the others are bfe/lshr + lshl_add
-                        if (t == 0) asm("v_and_b32 %0, 0xff, %1" : "=v"(code) : "v"(cw));
-                        else code = (cw >> (8 * t)) & 0xffu;
-                        if (ABL != 2 && ABL != 4) s = s + tab[(kk * LSQ_H + code) * LPV + q];      // ascending k, plain f32 add
-                        else s.x += (float)code;
-                    }
-                }
-            }
-            return s;
-        };
-        auto finish = [&](f32x4 s, int slice, int c0) {
-            // first-argmin: in-lane over 4 candidates, then one packed LDS atomic min per lane
-            float lm = fminf(fminf(s.x, s.y), fminf(s.z, s.w));
-            uint32_t li = (s.z == lm) ? 2u : 3u;                               // three selects, no divergent control flow
-            li = (s.y == lm) ? 1u : li;
-            li = (s.x == lm) ? 0u : li;
-            li += 4u * q + (uint32_t)(SL * slice);
-            const uint32_t bits = __float_as_uint(lm + 0.0f);                  // -0 -> +0: they compare equal in the reference
-            uint32_t ord = bits ^ ((uint32_t)((int32_t)bits >> 31) | 0x80000000u);   // monotone float -> uint
-            // only the lane(s) holding the minimum of the vector's LPV lanes post it (DPP mins within the quad): 4x fewer LDS
-            // atomics and no same-address serialisation (15 % of the LDS cycles); equal minima all post, the packed key orders them
-            float vm = lm;
-            if (LPV >= 2) vm = fminf(vm, dpp_self<DPP_XOR1, 0xf>(vm));
-            if (LPV >= 4) vm = fminf(vm, dpp_self<DPP_XOR2, 0xf>(vm));
-            bool post = (lm == vm);                                            // false for a NaN lane: NaN never wins ...
-            if (__builtin_expect(__ballot((lm != lm) | (s.x != s.x)) != 0ull, 0)) {       // wave-uniform, rare: a NaN is present
-                if ((slice == 0) & (q == 0) & (s.x != s.x)) { ord = 0u; li = 0u; post = true; }   // ... except s[0]: the strict-< scan keeps index 0
-            }
-            if ((c0 + v < nact) & post) atomicMin(&best64[c0 + v], ((unsigned long long)ord << 32) | li);
-        };
-        auto compute = [&](const Item &cur, int slice, int c0) { finish(gather(cur), slice, c0); };
-        Item buf[DEPTH];
-#pragma unroll
-        for (int e = 0; e < DEPTH; ++e) load_next(buf[e]);
-        int phase = 0;                                         // index of the buffer holding the next item to consume
-
-        for (int slice = 0; slice < NS; ++slice) {
-            if (ABL < 3) __syncthreads();                      // everyone is done with the previous slice table
-#pragma unroll
-            for (int r = 0; r < NST; ++r) {                    // commit the table prefetched one slice ago
-                const int e = (int)threadIdx.x + r * NT;
-                if (e < TAB && ABL != 4) tab[e] = nxt[r];
-            }
-            if (ABL < 3) __syncthreads();
-            if (slice + 1 < NS && ABL != 4) prefetch_tab(slice + 1);       // next slice's table travels L2 -> VGPRs under this slice's work
-            int c0 = wave * VPW, t = 0;
-            auto run = [&](auto P_) {                          // P = buffer consumed first; all buffer indices are compile-time
-                constexpr int P = decltype(P_)::value;
-                for (; t + DEPTH <= ipw; t += DEPTH) {
-#pragma unroll
-                    for (int e = 0; e < DEPTH; ++e) {
-                        compute(buf[(P + e) % DEPTH], slice, c0); load_next(buf[(P + e) % DEPTH]); c0 += step;
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < DEPTH - 1; ++e)
-                    if (t < ipw) {
-                        compute(buf[(P + e) % DEPTH], slice, c0); load_next(buf[(P + e) % DEPTH]); c0 += step;
-                        ++t; phase = (P + e + 1) % DEPTH;
-                    }
-            };
-            bool ran = false;                                  // run() changes `phase`: exactly one instantiation per slice
-            auto try_phase = [&](auto P_) {
-                if constexpr (decltype(P_)::value < DEPTH) {
-                    if (!ran && phase == decltype(P_)::value) { run(P_); ran = true; }
-                }
-            };
-            try_phase(std::integral_constant<int, 0>{}); try_phase(std::integral_constant<int, 1>{});
-            try_phase(std::integral_constant<int, 2>{}); try_phase(std::integral_constant<int, 3>{});
-            try_phase(std::integral_constant<int, 4>{}); try_phase(std::integral_constant<int, 5>{});
-            try_phase(std::integral_constant<int, 6>{}); try_phase(std::integral_constant<int, 7>{});
-        }
-        __syncthreads();
-        for (int ci = threadIdx.x; ci < nact; ci += NT) {
-            const int64_t i = lo + list[ci];
-            const unsigned bi = (unsigned)(best64[ci] & 0xffffffffull);
-            const uint8_t code = (uint8_t)(bi > 255 ? 0 : bi);
-            // the record with byte j replaced (one aligned load instead of a byte load)
-            uint32_t rw[RW];
-#pragma unroll
-            for (int w2 = 0; w2 < RW; ++w2) rw[w2] = reinterpret_cast<const uint32_t *>(rec + i * CS)[w2];
-            const uint8_t old = (uint8_t)(rw[j >> 2] >> (8 * (j & 3)));
-            rec[i * CS + j] = code;
-            if (valid) {
-                unsigned short vm = (code != old) ? (unsigned short)(1u << j) : (unsigned short)(valid[i] | (1u << j));
-                vm = (unsigned short)(vm | known_valid<RW>(rw, j, code, ref_rec ? ref_rec + i * CS : nullptr, ref_valid ? ref_valid + i : nullptr));
-                valid[i] = vm;
-            }
-        }
+        walk_slices(j, lo, nact, nact == cnt, 0, NS);
+        for (int ci = threadIdx.x; ci < nact; ci += NT) apply_node_result<CS>(rec, valid, lo + list[ci], j, best64[ci], ref_rec, ref_valid);
         __syncthreads();
         }   // node updates
     }
+}
+
+// ---- bookkeeping between two adaptive one-node launches (one 1024-thread block per segment) -------------------------------
+// (a) team mode only (S > 1, same S as the walk kernel computed): the lowest-index minimum over the S members' partial keys of
+//     every vector that was active at node j -> its new code and validity mask (apply_node_result, the block-local rules);
+// (b) the active list of the NEXT node jnext: the segment's vectors whose node jnext must be recomputed (ascending) + their count.
+// j < 0: nothing to fold (first launch of a sequence); jnext < 0: no list wanted (last).
+template <int CS>
+__global__ __launch_bounds__(1024) void icm_apply_scan_kernel(uint8_t *__restrict__ rec, unsigned short *__restrict__ valid, int64_t n, int per_pass,
+                                                              int j, int jnext, int use_skip, const unsigned *__restrict__ segcount_cur,
+                                                              unsigned *__restrict__ segcount_next, unsigned short *__restrict__ seglist,
+                                                              const unsigned long long *__restrict__ part, int npass, int smax, int cap, int walk_grid,
+                                                              const uint8_t *__restrict__ ref_rec, const unsigned short *__restrict__ ref_valid) {
+    constexpr int EPT = 4;
+    __shared__ int wave_tot[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int S = 1;
+    if (j >= 0) {
+        unsigned mine = 0;
+        for (int b = threadIdx.x; b < npass; b += 1024) mine += segcount_cur[b];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
+        if (lane == 0) wave_tot[wave] = (int)mine;
+        __syncthreads();
+        unsigned long long active = 0;
+        for (int w2 = 0; w2 < 16; ++w2) active += (unsigned)wave_tot[w2];
+        __syncthreads();
+        S = lsq_team_size(active, npass, walk_grid, smax, cap);
+    }
+    const int64_t lo = (int64_t)blockIdx.x * per_pass;
+    const int cnt = (int)((lo + per_pass < n ? lo + per_pass : n) - lo);
+    const int base = (int)threadIdx.x * EPT;
+    int f[EPT], c = 0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int idx = base + e;
+        f[e] = 0;
+        if (idx < cnt) {
+            const int64_t i = lo + idx;
+            unsigned short vm = valid[i];
+            if (S > 1 && (!use_skip || !((vm >> j) & 1))) {       // was active at node j: its partial keys are there
+                unsigned long long key = part[i];
+                for (int g = 1; g < S; ++g) { const unsigned long long k2 = part[(size_t)g * (size_t)n + (size_t)i]; key = k2 < key ? k2 : key; }
+                apply_node_result<CS>(rec, valid, i, j, key, ref_rec, ref_valid);
+                vm = valid[i];
+            }
+            f[e] = (jnext >= 0) && (!use_skip || !((vm >> jnext) & 1));
+        }
+        c += f[e];
+    }
+    if (jnext < 0) return;
+    int inc = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    int wbase = 0;
+    for (int w2 = 0; w2 < wave; ++w2) wbase += wave_tot[w2];
+    int pos = wbase + inc - c;
+    unsigned short *out = seglist + (size_t)blockIdx.x * LSQ_SEG_STRIDE;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e)
+        if (f[e]) out[pos++] = (unsigned short)(base + e);
+    if (threadIdx.x == 1023) segcount_next[blockIdx.x] = (unsigned)(wbase + inc);
 }
 
 // Ts[j][slice][kk][b][SL] <- T[j][k(kk)][b][slice*SL ..]   (one thread per float4)
@@ -723,27 +877,54 @@ int optin_lds(LdsOptIn &st, Kern kernel, int bytes) {
         default: lsq_set_error("m = %d out of range 1..16", m); return LSQ_EINVAL;          \
     }
 
+// geometry of a walk launch over n vectors: vectors per pass (<= the LDS budget PP), number of passes (= segments), grid
+void lsq_walk_geometry(int64_t n, int m, int *per_pass, int *npass, int *pp_cap) {
+    const int PP = lsq_walk_pp(m, lsq_walk_slice_width(m));
+    const int64_t rounds = (n + 256 * (int64_t)PP - 1) / (256 * (int64_t)PP);          // passes per CU
+    int64_t per = rounds > 0 ? (n + 256 * rounds - 1) / (256 * rounds) : 1;
+    if (per > PP) per = PP;
+    if (per < 1) per = 1;
+    *per_pass = (int)per;
+    *npass = (int)((n + per - 1) / per);
+    if (pp_cap) *pp_cap = PP;
+}
+
 template <int M, int SL, int ABL = 0, int DEPTH = 2, int NT = 1024>
 static int launch_walk_t(hipStream_t s, const float *U, const float *Ts, const float *T, uint8_t *rec, unsigned short *valid, int64_t n,
                          const WalkNodes &nodes, int use_skip, unsigned long long *active_total, int light,
-                         const uint8_t *ref_rec, const unsigned short *ref_valid) {
+                         const uint8_t *ref_rec, const unsigned short *ref_valid, const lsq_team_bufs *tb) {
     constexpr int TAB = (M - 1) * LSQ_H * (SL / 4);
     constexpr int PP = LSQ_WALK_PP(M, SL);
     constexpr int LDS_BYTES = TAB * 16 + PP * 8 + PP * 2;                // slice table + packed running best + active list
-    static_assert(LDS_BYTES + 256 <= 160 * 1024, "slice table + running best must fit the 160 KiB LDS");
-    static LdsOptIn optin;
-    LSQ_TRY(optin_lds(optin, &icm_walk_kernel<M, SL, ABL, DEPTH, NT>, LDS_BYTES));
-    const int64_t rounds = (n + 256 * (int64_t)PP - 1) / (256 * (int64_t)PP);          // passes per CU
-    int64_t per_pass = (n + 256 * rounds - 1) / (256 * rounds);
-    if (per_pass > PP) per_pass = PP;
-    if (per_pass < 1) per_pass = 1;
-    const int64_t npass = (n + per_pass - 1) / per_pass;
-    const unsigned grid = (unsigned)(npass < 256 ? npass : 256);
+    static_assert(LDS_BYTES + 512 <= 160 * 1024, "slice table + running best must fit the 160 KiB LDS");
+    int per_pass = 1, npass = 1;
+    lsq_walk_geometry(n, M, &per_pass, &npass, nullptr);
     // blocks with at most this many active vectors gather from L2 instead of staging (option "light"; thresholds 96..1024 measured)
     const int direct_max = light >= 0 ? light : LSQ_KNOB("LSQ_WALK_DIRECT", 256);
-    hipLaunchKernelGGL((icm_walk_kernel<M, SL, ABL, DEPTH, NT>), dim3(grid), dim3(NT), LDS_BYTES, s, U, Ts, T, rec, valid, n, nodes, (int)per_pass,
-                       (use_skip && valid) ? 1 : 0, (T && ABL == 0) ? direct_max : 0, active_total, (use_skip && valid) ? ref_rec : nullptr,
-                       (use_skip && valid) ? ref_valid : nullptr);
+    const int skip = (use_skip && valid) ? 1 : 0;
+    TeamArgs ta{nullptr, nullptr, nullptr, 0, 1, 0};
+    if (tb) {
+        if constexpr (ABL == 0) {                                        // adaptive one-node launch: team size chosen on the device
+            if (!valid || nodes.count != 1) { lsq_set_error("adaptive walk launch needs validity masks and exactly one node"); return LSQ_EINVAL; }
+            static LdsOptIn optin_a;
+            LSQ_TRY(optin_lds(optin_a, &icm_walk_kernel<M, SL, 0, DEPTH, NT, true>, LDS_BYTES));
+            ta = TeamArgs{tb->segcount, tb->seglist, tb->part, npass, tb->smax, tb->cap > 0 && tb->cap < PP ? tb->cap : PP * 15 / 16};
+            const int g16 = (npass + LSQ_TEAM_MAX - 1) / LSQ_TEAM_MAX * LSQ_TEAM_MAX;      // every team size divides the grid
+            const unsigned grid = (unsigned)(g16 < 256 ? g16 : 256);
+            hipLaunchKernelGGL((icm_walk_kernel<M, SL, 0, DEPTH, NT, true>), dim3(grid), dim3(NT), LDS_BYTES, s, U, Ts, T, rec, valid, n, nodes, per_pass,
+                               skip, T ? direct_max : 0, active_total, skip ? ref_rec : nullptr, skip ? ref_valid : nullptr, ta);
+            LSQ_HIP(hipGetLastError());
+            return LSQ_OK;
+        } else {
+            lsq_set_error("ablation variants have no adaptive mode");
+            return LSQ_EINVAL;
+        }
+    }
+    static LdsOptIn optin;
+    LSQ_TRY(optin_lds(optin, &icm_walk_kernel<M, SL, ABL, DEPTH, NT, false>, LDS_BYTES));
+    const unsigned grid = (unsigned)(npass < 256 ? npass : 256);
+    hipLaunchKernelGGL((icm_walk_kernel<M, SL, ABL, DEPTH, NT, false>), dim3(grid), dim3(NT), LDS_BYTES, s, U, Ts, T, rec, valid, n, nodes, per_pass,
+                       skip, (T && ABL == 0) ? direct_max : 0, active_total, skip ? ref_rec : nullptr, skip ? ref_valid : nullptr, ta);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }
@@ -755,7 +936,7 @@ int lsq_walk_slice_width(int m) {
 // `order[nnodes]`: the node updates to run back to back inside the launch (1 = one node; icmiter*m = a whole ILS iteration)
 int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const float *T, uint8_t *rec, unsigned short *valid, int64_t n, int m,
                         const int32_t *order, int nnodes, int pos0, int use_skip, unsigned long long *active_total, int ablation, int light,
-                        const uint8_t *ref_rec, const unsigned short *ref_valid) {
+                        const uint8_t *ref_rec, const unsigned short *ref_valid, const lsq_team_bufs *tb) {
     if (n <= 0 || nnodes <= 0) return LSQ_OK;
     if (m < 1 || m > LSQ_MAX_M) { lsq_set_error("m = %d out of range 1..16", m); return LSQ_EINVAL; }
     for (int done = 0; done < nnodes; done += LSQ_WALK_MAX_NODES) {
@@ -770,13 +951,14 @@ int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const fl
         // m >= 14: up to 15 table reads in flight + 8 staged table registers per thread do not fit 128 VGPRs (measured at
         // m = 16: 67..100 spilled registers, 1.5..2.5x slower) -> 512-thread blocks (256 VGPRs per wave), more U items in
         // flight instead.  m = 9..13 fit (<= 4 spills) and are 3-5 % faster with 1024 threads (measured for every m).
-#define LSQ_WALK_ARGS s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light, ref_rec, ref_valid
+#define LSQ_WALK_ARGS s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light, ref_rec, ref_valid, tb
 #define LSQ_WALK_CASE_MID(MM) case MM: LSQ_TRY((launch_walk_t<MM, 8, 0, 2>(LSQ_WALK_ARGS))); break;
 #define LSQ_WALK_CASE_BIG(MM) case MM: LSQ_TRY((launch_walk_t<MM, 8, 0, 4, 512>(LSQ_WALK_ARGS))); break;
 #define LSQ_WALK_CASE(MM, SLL) case MM: LSQ_TRY((launch_walk_t<MM, SLL, 0, 3>(LSQ_WALK_ARGS))); break;
 #ifdef LSQ_TUNING      // timing-only variants and alternative shapes: profiling library only (results of the ablations are garbage)
         bool handled = true;
-        if (m <= 8 && lsq_walk_slice_width(m) == 8) {
+        if (tb) handled = false;                                       // adaptive launches use the shipped shapes only
+        else if (m <= 8 && lsq_walk_slice_width(m) == 8) {
             switch (m) {
                 LSQ_WALK_CASE(1, 8) LSQ_WALK_CASE(2, 8) LSQ_WALK_CASE(3, 8) LSQ_WALK_CASE(4, 8)
                 LSQ_WALK_CASE(5, 8) LSQ_WALK_CASE(6, 8) LSQ_WALK_CASE(7, 8) LSQ_WALK_CASE(8, 8)
@@ -804,6 +986,28 @@ int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const fl
 #undef LSQ_WALK_CASE_BIG
 #undef LSQ_WALK_CASE_MID
     }
+    return LSQ_OK;
+}
+
+// bookkeeping launch between two adaptive node updates (see icm_apply_scan_kernel): fold node j's team partials (j >= 0, only
+// when the device chose a team size > 1), then build the active lists of node jnext (jnext >= 0) into seglist / segcount_next
+int lsq_launch_icm_apply_scan(hipStream_t s, uint8_t *rec, unsigned short *valid, int64_t n, int m, int j, int jnext, int use_skip,
+                              const lsq_team_bufs *tb, unsigned *segcount_next, const uint8_t *ref_rec, const unsigned short *ref_valid) {
+    if (n <= 0) return LSQ_OK;
+    if (!valid || !tb) { lsq_set_error("lsq_launch_icm_apply_scan: validity masks and team buffers required"); return LSQ_EINVAL; }
+    int per_pass = 1, npass = 1, PP = 4096;
+    lsq_walk_geometry(n, m, &per_pass, &npass, &PP);
+    const int cap = tb->cap > 0 && tb->cap < PP ? tb->cap : PP * 15 / 16;
+    const int g16 = (npass + LSQ_TEAM_MAX - 1) / LSQ_TEAM_MAX * LSQ_TEAM_MAX;
+    const int walk_grid = g16 < 256 ? g16 : 256;
+    const int skip = use_skip ? 1 : 0;
+    if (lsq_code_stride(m) == 8)
+        hipLaunchKernelGGL(icm_apply_scan_kernel<8>, dim3((unsigned)npass), dim3(1024), 0, s, rec, valid, n, per_pass, j, jnext, skip, tb->segcount, segcount_next,
+                           const_cast<unsigned short *>(tb->seglist), tb->part, npass, tb->smax, cap, walk_grid, skip ? ref_rec : nullptr, skip ? ref_valid : nullptr);
+    else
+        hipLaunchKernelGGL(icm_apply_scan_kernel<16>, dim3((unsigned)npass), dim3(1024), 0, s, rec, valid, n, per_pass, j, jnext, skip, tb->segcount, segcount_next,
+                           const_cast<unsigned short *>(tb->seglist), tb->part, npass, tb->smax, cap, walk_grid, skip ? ref_rec : nullptr, skip ? ref_valid : nullptr);
+    LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }
 
