@@ -346,7 +346,7 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t c
     if (c->schedule == 5 && valid && m > 1 && c->team > 1 && cn >= c->team_min && nsweeps > 0) {
         int per_pass = 1, npass = 1, PP = 4096;
         lsq_walk_geometry(cn, m, &per_pass, &npass, &PP);
-        const int cap = c->team_cap > 0 && c->team_cap < PP ? c->team_cap : PP * 15 / 16;
+        const int cap = c->team_cap > 0 ? c->team_cap : PP * 15 / 16;
         const int g16 = (npass + 15) / 16 * 16, grid = g16 < 256 ? g16 : 256;
         int smax = c->team;
         while (smax > 1 && smax > LSQ_H / lsq_walk_slice_width(m)) smax >>= 1;

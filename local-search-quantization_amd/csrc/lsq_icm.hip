@@ -908,7 +908,7 @@ static int launch_walk_t(hipStream_t s, const float *U, const float *Ts, const f
             if (!valid || nodes.count != 1) { lsq_set_error("adaptive walk launch needs validity masks and exactly one node"); return LSQ_EINVAL; }
             static LdsOptIn optin_a;
             LSQ_TRY(optin_lds(optin_a, &icm_walk_kernel<M, SL, 0, DEPTH, NT, true>, LDS_BYTES));
-            ta = TeamArgs{tb->segcount, tb->seglist, tb->part, npass, tb->smax, tb->cap > 0 && tb->cap < PP ? tb->cap : PP * 15 / 16};
+            ta = TeamArgs{tb->segcount, tb->seglist, tb->part, npass, tb->smax, tb->cap > 0 ? tb->cap : PP * 15 / 16};
             const int g16 = (npass + LSQ_TEAM_MAX - 1) / LSQ_TEAM_MAX * LSQ_TEAM_MAX;      // every team size divides the grid
             const unsigned grid = (unsigned)(g16 < 256 ? g16 : 256);
             hipLaunchKernelGGL((icm_walk_kernel<M, SL, 0, DEPTH, NT, true>), dim3(grid), dim3(NT), LDS_BYTES, s, U, Ts, T, rec, valid, n, nodes, per_pass,
@@ -997,7 +997,7 @@ int lsq_launch_icm_apply_scan(hipStream_t s, uint8_t *rec, unsigned short *valid
     if (!valid || !tb) { lsq_set_error("lsq_launch_icm_apply_scan: validity masks and team buffers required"); return LSQ_EINVAL; }
     int per_pass = 1, npass = 1, PP = 4096;
     lsq_walk_geometry(n, m, &per_pass, &npass, &PP);
-    const int cap = tb->cap > 0 && tb->cap < PP ? tb->cap : PP * 15 / 16;
+    const int cap = tb->cap > 0 ? tb->cap : PP * 15 / 16;
     const int g16 = (npass + LSQ_TEAM_MAX - 1) / LSQ_TEAM_MAX * LSQ_TEAM_MAX;
     const int walk_grid = g16 < 256 ? g16 : 256;
     const int skip = use_skip ? 1 : 0;

@@ -219,8 +219,9 @@ def test_teams_overflowing_ranges_run_in_chunks(lsq, oracle):
     d, n, m, ils, J, npert, seed = 16, 120_000, 8, [2], 3, 4, 77
     X, K, B0 = make_problem(d, n, m, seed=seed, kind="gauss")
     Bs_ref, objs_ref = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, True, seed)
-    # cap is only the AIM of the size choice: with team = 16 forced from sweep 0 and cap 4000, 120 000 active / 16 ranges = 7500 per team > 4096
-    Bs, objs, t = _run_sched5(lsq, X, B0, K, m, ils, J, npert, seed, team_from=0, team=16, team_cap=4000)
+    # cap is only the AIM of the device-side size choice: with cap = 8000 the first sweep picks S = 16, i.e. 120 000 / 16 = 7500 active
+    # vectors per team > the 4096 one block can book-keep -> two chunks per team
+    Bs, objs, t = _run_sched5(lsq, X, B0, K, m, ils, J, npert, seed, team_from=0, team=16, team_cap=8000)
     assert np.array_equal(Bs, Bs_ref), "%d of %d codes differ" % ((Bs != Bs_ref).sum(), Bs.size)
     assert t["team_blocks"] > 0
 
