@@ -311,7 +311,7 @@ def main():
             "bytes_per_node_update": 4 * h + cs + 1,
             "node_updates_recomputed_per_launch": nu_per_launch,
             "recomputed_fraction": tm["icm_node_updates"] / max(total_nu * args.steps, 1),
-            "blocks": {"staged": int(tm["staged_blocks"]), "light": int(tm["light_blocks"]), "team": int(tm["team_blocks"])},
+            "blocks": {"staged": int(tm["staged_blocks"]), "light": int(tm["light_blocks"]), "filtered": int(tm["filtered_blocks"])},
             "data_flow": "M2 (SURVEY 8(d)): the unary row of a node is re-read from HBM at every recomputed node update; `achieved` counts only "
                          "node updates that were actually recomputed (memoised ones move no bytes).  It is a fraction of the traffic this "
                          "design chose to create, not of the compulsory bytes -- see m1_compulsory.",

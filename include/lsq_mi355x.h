@@ -73,7 +73,7 @@ typedef struct lsq_timings {
     /* which path the ICM blocks took (counted per block and node update, on the device; since v200): */
     int64_t staged_blocks;   /* table slices staged through LDS, the block walked all of them (team size 1)  */
     int64_t light_blocks;    /* few active vectors: table columns gathered from L2, one wave per vector       */
-    int64_t team_blocks;     /* table slices staged through LDS, the block walked its share (team size > 1)   */
+    int64_t filtered_blocks; /* 16-bit filtered walk (exact refinement of ambiguous vectors), LDS-staged slices       */
 } lsq_timings;
 
 LSQ_API const char *lsq_last_error(void);

@@ -65,19 +65,14 @@ struct lsq_ctx {
     int light = -1;          // schedules 3/4: light-block threshold (-1 = default)
     int fallback = 1;        // schedules 3/4: a candidate equal to its current record inherits that record's validity bits (exact)
     int skip = 1;            // schedule 3: skip node updates whose inputs did not change (exact memoisation)
-    int team = LSQ_TEAM_DEFAULT;   // schedule 5: largest team size of an adaptive node update (1 = teams off)
-    int team_from = -1;      // schedule 5: first sweep (0-based) run as adaptive one-node launches; earlier sweeps share one launch (-1 = auto)
-    int team_cap = 0;        // schedule 5: active vectors per team the device-side size choice aims at (0 = default, 15/16 of the LDS budget)
-    int64_t team_min = 32768;// schedule 5: chunks with fewer vectors keep the one-launch schedule (every block is light there; launches would dominate)
     // workspace
     DevBuf sci, T, Ts, U, part, vCur, vNew, active, recCur, recNew, prev, counters, obj, bad;
-    DevBuf segcount, seglist, tpart;                   // adaptive (team) node updates: per-segment active lists + the members' partial keys
     DevBuf sX, sX2, sK, sB16, sOut16, sTight, sF32;    // staging for the host-buffer entry points (sX/sX2: double-buffered X chunks)
     hipStream_t copy_stream = nullptr;               // H2D of X runs here, under the compute of the previous panel / chunk
     hipEvent_t copy_done = nullptr;
     // timings
     double cat_ms[CAT_COUNT] = {0, 0, 0, 0, 0, 0};
-    int64_t icm_launches = 0, icm_node_updates = 0, staged_blocks = 0, light_blocks = 0, team_blocks = 0;
+    int64_t icm_launches = 0, icm_node_updates = 0, staged_blocks = 0, light_blocks = 0, filtered_blocks = 0;
     int64_t trace[LSQ_WALK_TRACE] = {0};
     struct Pending { hipEvent_t a, b; int cat; };
     std::vector<Pending> pending;
@@ -153,7 +148,7 @@ extern "C" int lsq_destroy(lsq_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : c->pool) (void)hipEventDestroy(e);
-    DevBuf *bufs[] = {&c->segcount, &c->seglist, &c->tpart, &c->sci, &c->T, &c->Ts, &c->U, &c->part, &c->vCur, &c->vNew, &c->active, &c->recCur, &c->recNew, &c->prev, &c->counters, &c->obj, &c->bad,
+    DevBuf *bufs[] = {&c->sci, &c->T, &c->Ts, &c->U, &c->part, &c->vCur, &c->vNew, &c->active, &c->recCur, &c->recNew, &c->prev, &c->counters, &c->obj, &c->bad,
                       &c->sX, &c->sX2, &c->sK, &c->sB16, &c->sOut16, &c->sTight, &c->sF32};
     for (DevBuf *b : bufs) b->release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -182,17 +177,11 @@ extern "C" int lsq_set_option(lsq_ctx *c, const char *key, int64_t value) {
 #endif
     else if (!strcmp(key, "light")) c->light = (int)value;
     else if (!strcmp(key, "fallback")) c->fallback = (int)value;
-    else if (!strcmp(key, "team")) {
-        if (value != 1 && value != 2 && value != 4 && value != 8 && value != 16) { lsq_set_error("team must be 1, 2, 4, 8 or 16"); return LSQ_EINVAL; }
-        c->team = (int)value;
-    } else if (!strcmp(key, "team_from")) c->team_from = (int)value;
-    else if (!strcmp(key, "team_cap")) c->team_cap = (int)value;
-    else if (!strcmp(key, "team_min")) c->team_min = value;
     else if (!strcmp(key, "schedule")) {
 #ifdef LSQ_TUNING
-        if (value < 0 || value > 5) { lsq_set_error("schedule must be 0..5"); return LSQ_EINVAL; }
+        if (value < 0 || value > 4) { lsq_set_error("schedule must be 0..4"); return LSQ_EINVAL; }
 #else
-        if (value < 3 || value > 5) { lsq_set_error("schedule must be 3, 4 or 5 (schedules 0..2 exist in the tuning build only)"); return LSQ_EINVAL; }
+        if (value < 3 || value > 4) { lsq_set_error("schedule must be 3 or 4 (schedules 0..2 exist in the tuning build only)"); return LSQ_EINVAL; }
 #endif
         c->schedule = (int)value;
     } else { lsq_set_error("unknown option '%s'", key); return LSQ_EINVAL; }
@@ -213,7 +202,7 @@ extern "C" int lsq_get_timings(lsq_ctx *c, lsq_timings *out) {
     out->icm_node_updates = c->icm_node_updates;
     out->staged_blocks = c->staged_blocks;
     out->light_blocks = c->light_blocks;
-    out->team_blocks = c->team_blocks;
+    out->filtered_blocks = c->filtered_blocks;
     return LSQ_OK;
 }
 
@@ -227,7 +216,7 @@ extern "C" int lsq_reset_timings(lsq_ctx *c) {
     LSQ_TRY(use_device(c));
     LSQ_TRY(resolve_timings(c));
     for (double &v : c->cat_ms) v = 0.0;
-    c->icm_launches = c->icm_node_updates = c->staged_blocks = c->light_blocks = c->team_blocks = 0;
+    c->icm_launches = c->icm_node_updates = c->staged_blocks = c->light_blocks = c->filtered_blocks = 0;
     for (int64_t &v : c->trace) v = 0;
     return LSQ_OK;
 }
@@ -340,61 +329,19 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t c
         return LSQ_OK;
     }
 #endif
-    // Schedule 5 (adaptive): the first sweeps -- every vector active after a perturbation -- share ONE launch as in schedule 4; from sweep
-    // `from` on every node update is its own launch whose team size the DEVICE picks from the node's active count (icm_walk_kernel
-    // ADAPT, lsq_team_size), followed by the bookkeeping launch that folds the team partials and lists the next node's active vectors.
-    if (c->schedule == 5 && valid && m > 1 && c->team > 1 && cn >= c->team_min && nsweeps > 0) {
-        int per_pass = 1, npass = 1, PP = 4096;
-        lsq_walk_geometry(cn, m, &per_pass, &npass, &PP);
-        const int cap = c->team_cap > 0 ? c->team_cap : PP * 15 / 16;
-        const int g16 = (npass + 15) / 16 * 16, grid = g16 < 256 ? g16 : 256;
-        int smax = c->team;
-        while (smax > 1 && smax > LSQ_H / lsq_walk_slice_width(m)) smax >>= 1;
-        // auto: teams already form with every vector active (mid-size chunks) -> all sweeps adaptive; else the first sweep is dense
-        int from = c->team_from >= 0 ? c->team_from : (lsq_team_size((unsigned long long)cn, npass, grid, smax, cap) > 1 ? 0 : 1);
-        if (from > nsweeps) from = nsweeps;
-        LSQ_TRY(c->segcount.ensure(sizeof(unsigned) * 2 * (size_t)npass));
-        LSQ_TRY(c->seglist.ensure(sizeof(unsigned short) * 4096 * (size_t)npass));
-        LSQ_TRY(c->tpart.ensure(sizeof(unsigned long long) * (size_t)smax * (size_t)cn));
-        unsigned *sc[2] = {c->segcount.as<unsigned>(), c->segcount.as<unsigned>() + npass};
-        const uint8_t *rr = c->fallback ? ref_rec : nullptr;
-        const unsigned short *rv = c->fallback ? ref_valid : nullptr;
-        std::vector<int32_t> seq((size_t)nsweeps * m);
-        for (int sw = 0; sw < nsweeps; ++sw)
-            for (int q = 0; q < m; ++q) seq[(size_t)sw * m + q] = order[q];
-        if (from > 0) {
-            LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>(), c->Ts.as<float>(), c->T.as<float>(), rec, valid, cn, m, seq.data(), from * m, 0, c->skip,
-                                        c->active.as<unsigned long long>(), 0, c->light, rr, rv, nullptr));
-            c->icm_launches += ((int64_t)from * m + 63) / 64;
-        }
-        const int first = from * m, total = nsweeps * m;
-        if (first < total) {
-            lsq_team_bufs tb{sc[0], c->seglist.as<unsigned short>(), c->tpart.as<unsigned long long>(), smax, cap};
-            LSQ_TRY(lsq_launch_icm_apply_scan(c->stream, rec, valid, cn, m, -1, seq[(size_t)first], c->skip, &tb, sc[0], rr, rv));
-            for (int t = first; t < total; ++t) {
-                const int cur = (t - first) & 1;
-                tb.segcount = sc[cur];
-                LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>(), c->Ts.as<float>(), c->T.as<float>(), rec, valid, cn, m, &seq[(size_t)t], 1, t, c->skip,
-                                            c->active.as<unsigned long long>(), 0, c->light, rr, rv, &tb));
-                LSQ_TRY(lsq_launch_icm_apply_scan(c->stream, rec, valid, cn, m, seq[(size_t)t], t + 1 < total ? seq[(size_t)t + 1] : -1, c->skip, &tb, sc[cur ^ 1], rr, rv));
-            }
-            c->icm_launches += total - first;
-        }
-        return LSQ_OK;
-    }
     if (c->schedule >= 4) {
         // the whole ILS iteration (nsweeps x m node updates) in ONE launch: a block owns its vectors throughout
         std::vector<int32_t> seq((size_t)nsweeps * m);
         for (int sw = 0; sw < nsweeps; ++sw)
             for (int q = 0; q < m; ++q) seq[(size_t)sw * m + q] = order[q];
         LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>(), c->Ts.as<float>(), c->T.as<float>(), rec, valid, cn, m, seq.data(), (int)seq.size(), 0, c->skip,
-                                    c->active.as<unsigned long long>(), c->ablation, c->light, c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr, nullptr));
+                                    c->active.as<unsigned long long>(), c->ablation, c->light, c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr));
         c->icm_launches += ((int64_t)seq.size() + 63) / 64;
     } else {
         for (int sw = 0; sw < nsweeps; ++sw)
             for (int q = 0; q < m; ++q)
                 LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>(), c->Ts.as<float>(), c->T.as<float>(), rec, valid, cn, m, &order[q], 1, sw * m + q, c->skip,
-                                            c->active.as<unsigned long long>(), c->ablation, c->light, c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr, nullptr));
+                                            c->active.as<unsigned long long>(), c->ablation, c->light, c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr));
         c->icm_launches += (int64_t)nsweeps * m;
     }
     return LSQ_OK;
@@ -483,7 +430,7 @@ static int finish_call(lsq_ctx *c, int64_t I, int nr, double *obj_sums, int64_t 
         c->icm_node_updates += (int64_t)act[0];
         c->staged_blocks += (int64_t)act[1];
         c->light_blocks += (int64_t)act[2];
-        c->team_blocks += (int64_t)act[3];
+        c->filtered_blocks += (int64_t)act[3];
         for (int q = 0; q < LSQ_WALK_TRACE; ++q) c->trace[q] += (int64_t)act[4 + q];
     }
     if (stats) for (int64_t q = 0; q < 2 * I; ++q) stats[q] = (int64_t)cnt[(size_t)q];

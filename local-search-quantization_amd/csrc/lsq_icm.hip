@@ -78,38 +78,18 @@ __device__ inline void apply_node_result(uint8_t *__restrict__ rec, unsigned sho
 #define LSQ_WALK_MAX_NODES 64
 struct WalkNodes { int count; int pos0; uint8_t j[LSQ_WALK_MAX_NODES]; };      // kernel argument: the node updates of one launch, in order; pos0 = position of j[0] in the ILS iteration's node sequence (trace counters)
 
-// ---- adaptive ("team") mode of a ONE-node launch ---------------------------------------------------------------------------
-// Why: a block that walks all 256/SL slices pulls the node's whole (m-1) x 256 KiB table L2 -> LDS whatever its number of active
-// vectors: 448 MiB per node update over 256 CUs = 34-41 us at the ~13 TB/s the L2s deliver when every CU reads the same lines
-// (profiles/r02a_sweep_breakdown.json: sweep 4 with 6 % of the vectors active still takes 51 us; n = 10^5 runs at 0.4x the rate of
-// n = 10^6).  A TEAM of S blocks shares a vector range S times longer instead: member g stages only slices [g NS/S, (g+1) NS/S) and
-// posts one packed partial key per active vector; icm_apply_scan_kernel (next launch) takes the lowest-index minimum over the S
-// partials and builds the next node's active lists.  S is chosen ON THE DEVICE from the node's active count, identically by every
-// block of both kernels: S = 1 (this kernel's ordinary path, block-local apply) while the active vectors fill the blocks.
-// Segment b = vectors [b per_pass, (b+1) per_pass) -- the range a block owns when S = 1; team r owns segments [r S, (r+1) S).
-#define LSQ_SEG_STRIDE 4096          // entries per segment list (>= per_pass)
-#define LSQ_TEAM_MAX 16
-struct TeamArgs {
-    const unsigned *segcount;        // [npass] active vectors of this node per segment       (written by icm_apply_scan_kernel)
-    const unsigned short *seglist;   // [npass][LSQ_SEG_STRIDE] their indices within the segment, ascending
-    unsigned long long *part;        // [smax][n] packed partial keys, member-major
-    int npass;                       // number of segments
-    int smax;                        // largest team size allowed: 1, 2, 4, 8 or 16 (option "team")
-    int cap;                         // active vectors per team the size choice aims at (< PP: room for imbalance; an overflowing team runs in chunks)
-};
 // ---- LDS-walk kernel -------------------------------------------------------------------------------------------------------
 // ONE block walks the 256/SL slices of a node for its own range of <= 4096 vectors, keeping the running (min value, index) of
 // every vector in LDS as a packed 64-bit key.  Ts is the slice-major copy of the pair tables, Ts[j][slice][kk][b][SL]
 // (kk = rank of k among k != j), so that staging one slice is one contiguous, fully coalesced copy of (m-1) x 256 x SL x 4 B.
 // NT: threads per block (1024 or 512); DEPTH: U items in flight per wave (<= 8); ABL (tuning build only): timing-only ablations
-// (1: no U stream, 2: no table adds, 3: no slice barriers, 4: U stream only); ADAPT: one-node launch with device-chosen team size.
-template <int M, int SL, int ABL = 0, int DEPTH = 2, int NT = 1024, bool ADAPT = false>
+// (1: no U stream, 2: no table adds, 3: no slice barriers, 4: U stream only).
+template <int M, int SL, int ABL = 0, int DEPTH = 2, int NT = 1024>
 __global__ __launch_bounds__(NT) void icm_walk_kernel(const float *__restrict__ U, const float *__restrict__ Ts, const float *__restrict__ T,
                                                         uint8_t *__restrict__ rec, unsigned short *__restrict__ valid,
                                                         int64_t n, const WalkNodes nodes, int per_pass, int use_skip, int direct_max,
                                                         unsigned long long *__restrict__ active_total,
-                                                        const uint8_t *__restrict__ ref_rec, const unsigned short *__restrict__ ref_valid,
-                                                        const TeamArgs team) {
+                                                        const uint8_t *__restrict__ ref_rec, const unsigned short *__restrict__ ref_valid) {
     constexpr int CS = (M <= 8) ? 8 : 16;
     constexpr int NS = LSQ_H / SL;
     constexpr int LPV = SL / 4;
@@ -278,63 +258,6 @@ __global__ __launch_bounds__(NT) void icm_walk_kernel(const float *__restrict__ 
         __syncthreads();
     };
 
-    if constexpr (ADAPT) {
-        // ---- team size of this node update, from the per-segment active counts (identical in every block and in icm_apply_scan_kernel)
-        __shared__ unsigned segoff_s[LSQ_TEAM_MAX + 1];
-        unsigned mine = 0;
-        for (int b = threadIdx.x; b < team.npass; b += NT) mine += team.segcount[b];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
-        if (lane == 0) wave_tot[wave] = (int)mine;
-        __syncthreads();
-        unsigned long long active = 0;
-        for (int w2 = 0; w2 < NW; ++w2) active += (unsigned)wave_tot[w2];
-        __syncthreads();                                          // wave_tot is reused by the compaction below
-        if (active == 0) return;
-        const int S = lsq_team_size(active, team.npass, (int)gridDim.x, team.smax, team.cap);
-        if (S > 1) {
-            const int j = nodes.j[0];
-            const int g = (int)blockIdx.x % S;                    // member: blocks b, b + 8, ... share an XCD, so each XCD's L2 holds 1/S of the node's table
-            const int nteams = (int)gridDim.x / S;
-            const int nranges = (team.npass + S - 1) / S;
-            const int s_begin = g * NS / S, s_end = (g + 1) * NS / S;
-            for (int r = (int)blockIdx.x / S; r < nranges; r += nteams) {
-                const int seg0 = r * S;
-                const int nseg = (team.npass - seg0 < S) ? team.npass - seg0 : S;
-                if (threadIdx.x == 0) {                           // offsets of the team's segments in its concatenated active list
-                    unsigned o = 0;
-                    for (int sg = 0; sg <= LSQ_TEAM_MAX; ++sg) { segoff_s[sg] = o; if (sg < nseg) o += team.segcount[seg0 + sg]; }
-                }
-                __syncthreads();
-                const int total = (int)segoff_s[LSQ_TEAM_MAX];
-                const int64_t lo = (int64_t)seg0 * per_pass;
-                for (int c0 = 0; c0 < total; c0 += PP) {            // one chunk unless the range's active list overflows the LDS bookkeeping
-                    const int nact = (total - c0 < PP) ? total - c0 : PP;
-                    for (int ci = threadIdx.x; ci < nact; ci += NT) {
-                        const unsigned pos = (unsigned)(c0 + ci);
-                        int sg = 0;
-#pragma unroll
-                        for (int t = 1; t < LSQ_TEAM_MAX; ++t) sg += (t < nseg && segoff_s[t] <= pos) ? 1 : 0;      // segoff_s is non-decreasing
-                        list[ci] = (unsigned short)(sg * per_pass + team.seglist[(size_t)(seg0 + sg) * LSQ_SEG_STRIDE + (pos - segoff_s[sg])]);
-                        best64[ci] = ~0ull;
-                    }
-                    if (threadIdx.x == 0 && active_total) {       // [0] node updates recomputed (counted once per team), [3] team block-node-updates
-                        if (g == 0) {
-                            atomicAdd(active_total, (unsigned long long)nact);
-                            atomicAdd(active_total + 4 + (nodes.pos0 & (LSQ_WALK_TRACE - 1)), (unsigned long long)nact);
-                        }
-                        atomicAdd(active_total + 3, 1ull);
-                    }
-                    __syncthreads();
-                    walk_slices(j, lo, nact, false, s_begin, s_end);
-                    for (int ci = threadIdx.x; ci < nact; ci += NT) team.part[(size_t)g * (size_t)n + (size_t)(lo + list[ci])] = best64[ci];
-                    __syncthreads();
-                }
-            }
-            return;
-        }
-    }
-
     const int64_t npass = (n + per_pass - 1) / per_pass;
     for (int64_t pass = blockIdx.x; pass < npass; pass += gridDim.x) {
         const int64_t lo = pass * per_pass;
@@ -378,7 +301,7 @@ __global__ __launch_bounds__(NT) void icm_walk_kernel(const float *__restrict__ 
         }
         const int nact = nact_s;
         if (nact == 0) { __syncthreads(); continue; }          // block-uniform (the barrier protects nact_s / wave_tot reuse)
-        if (threadIdx.x == 0 && active_total) {            // [0] node updates recomputed, [1] staged / [2] light block-node-updates
+        if (threadIdx.x == 0 && active_total) {            // [0] node updates recomputed, [1] staged / [2] light block-node-updates ([3]: filtered walk)
             atomicAdd(active_total, (unsigned long long)nact);
             atomicAdd(active_total + (nact <= direct_max ? 2 : 1), 1ull);
             atomicAdd(active_total + 4 + ((nodes.pos0 + nu) & (LSQ_WALK_TRACE - 1)), (unsigned long long)nact);
@@ -423,73 +346,6 @@ __global__ __launch_bounds__(NT) void icm_walk_kernel(const float *__restrict__ 
         __syncthreads();
         }   // node updates
     }
-}
-
-// ---- bookkeeping between two adaptive one-node launches (one 1024-thread block per segment) -------------------------------
-// (a) team mode only (S > 1, same S as the walk kernel computed): the lowest-index minimum over the S members' partial keys of
-//     every vector that was active at node j -> its new code and validity mask (apply_node_result, the block-local rules);
-// (b) the active list of the NEXT node jnext: the segment's vectors whose node jnext must be recomputed (ascending) + their count.
-// j < 0: nothing to fold (first launch of a sequence); jnext < 0: no list wanted (last).
-template <int CS>
-__global__ __launch_bounds__(1024) void icm_apply_scan_kernel(uint8_t *__restrict__ rec, unsigned short *__restrict__ valid, int64_t n, int per_pass,
-                                                              int j, int jnext, int use_skip, const unsigned *__restrict__ segcount_cur,
-                                                              unsigned *__restrict__ segcount_next, unsigned short *__restrict__ seglist,
-                                                              const unsigned long long *__restrict__ part, int npass, int smax, int cap, int walk_grid,
-                                                              const uint8_t *__restrict__ ref_rec, const unsigned short *__restrict__ ref_valid) {
-    constexpr int EPT = 4;
-    __shared__ int wave_tot[16];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int S = 1;
-    if (j >= 0) {
-        unsigned mine = 0;
-        for (int b = threadIdx.x; b < npass; b += 1024) mine += segcount_cur[b];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
-        if (lane == 0) wave_tot[wave] = (int)mine;
-        __syncthreads();
-        unsigned long long active = 0;
-        for (int w2 = 0; w2 < 16; ++w2) active += (unsigned)wave_tot[w2];
-        __syncthreads();
-        S = lsq_team_size(active, npass, walk_grid, smax, cap);
-    }
-    const int64_t lo = (int64_t)blockIdx.x * per_pass;
-    const int cnt = (int)((lo + per_pass < n ? lo + per_pass : n) - lo);
-    const int base = (int)threadIdx.x * EPT;
-    int f[EPT], c = 0;
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int idx = base + e;
-        f[e] = 0;
-        if (idx < cnt) {
-            const int64_t i = lo + idx;
-            unsigned short vm = valid[i];
-            if (S > 1 && (!use_skip || !((vm >> j) & 1))) {       // was active at node j: its partial keys are there
-                unsigned long long key = part[i];
-                for (int g = 1; g < S; ++g) { const unsigned long long k2 = part[(size_t)g * (size_t)n + (size_t)i]; key = k2 < key ? k2 : key; }
-                apply_node_result<CS>(rec, valid, i, j, key, ref_rec, ref_valid);
-                vm = valid[i];
-            }
-            f[e] = (jnext >= 0) && (!use_skip || !((vm >> jnext) & 1));
-        }
-        c += f[e];
-    }
-    if (jnext < 0) return;
-    int inc = c;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(inc, off, 64);
-        if (lane >= off) inc += t;
-    }
-    if (lane == 63) wave_tot[wave] = inc;
-    __syncthreads();
-    int wbase = 0;
-    for (int w2 = 0; w2 < wave; ++w2) wbase += wave_tot[w2];
-    int pos = wbase + inc - c;
-    unsigned short *out = seglist + (size_t)blockIdx.x * LSQ_SEG_STRIDE;
-#pragma unroll
-    for (int e = 0; e < EPT; ++e)
-        if (f[e]) out[pos++] = (unsigned short)(base + e);
-    if (threadIdx.x == 1023) segcount_next[blockIdx.x] = (unsigned)(wbase + inc);
 }
 
 // Ts[j][slice][kk][b][SL] <- T[j][k(kk)][b][slice*SL ..]   (one thread per float4)
@@ -892,39 +748,21 @@ void lsq_walk_geometry(int64_t n, int m, int *per_pass, int *npass, int *pp_cap)
 template <int M, int SL, int ABL = 0, int DEPTH = 2, int NT = 1024>
 static int launch_walk_t(hipStream_t s, const float *U, const float *Ts, const float *T, uint8_t *rec, unsigned short *valid, int64_t n,
                          const WalkNodes &nodes, int use_skip, unsigned long long *active_total, int light,
-                         const uint8_t *ref_rec, const unsigned short *ref_valid, const lsq_team_bufs *tb) {
+                         const uint8_t *ref_rec, const unsigned short *ref_valid) {
     constexpr int TAB = (M - 1) * LSQ_H * (SL / 4);
     constexpr int PP = LSQ_WALK_PP(M, SL);
     constexpr int LDS_BYTES = TAB * 16 + PP * 8 + PP * 2;                // slice table + packed running best + active list
-    static_assert(LDS_BYTES + 512 <= 160 * 1024, "slice table + running best must fit the 160 KiB LDS");
+    static_assert(LDS_BYTES + 256 <= 160 * 1024, "slice table + running best must fit the 160 KiB LDS");
     int per_pass = 1, npass = 1;
     lsq_walk_geometry(n, M, &per_pass, &npass, nullptr);
     // blocks with at most this many active vectors gather from L2 instead of staging (option "light"; thresholds 96..1024 measured)
     const int direct_max = light >= 0 ? light : LSQ_KNOB("LSQ_WALK_DIRECT", 256);
     const int skip = (use_skip && valid) ? 1 : 0;
-    TeamArgs ta{nullptr, nullptr, nullptr, 0, 1, 0};
-    if (tb) {
-        if constexpr (ABL == 0) {                                        // adaptive one-node launch: team size chosen on the device
-            if (!valid || nodes.count != 1) { lsq_set_error("adaptive walk launch needs validity masks and exactly one node"); return LSQ_EINVAL; }
-            static LdsOptIn optin_a;
-            LSQ_TRY(optin_lds(optin_a, &icm_walk_kernel<M, SL, 0, DEPTH, NT, true>, LDS_BYTES));
-            ta = TeamArgs{tb->segcount, tb->seglist, tb->part, npass, tb->smax, tb->cap > 0 ? tb->cap : PP * 15 / 16};
-            const int g16 = (npass + LSQ_TEAM_MAX - 1) / LSQ_TEAM_MAX * LSQ_TEAM_MAX;      // every team size divides the grid
-            const unsigned grid = (unsigned)(g16 < 256 ? g16 : 256);
-            hipLaunchKernelGGL((icm_walk_kernel<M, SL, 0, DEPTH, NT, true>), dim3(grid), dim3(NT), LDS_BYTES, s, U, Ts, T, rec, valid, n, nodes, per_pass,
-                               skip, T ? direct_max : 0, active_total, skip ? ref_rec : nullptr, skip ? ref_valid : nullptr, ta);
-            LSQ_HIP(hipGetLastError());
-            return LSQ_OK;
-        } else {
-            lsq_set_error("ablation variants have no adaptive mode");
-            return LSQ_EINVAL;
-        }
-    }
     static LdsOptIn optin;
-    LSQ_TRY(optin_lds(optin, &icm_walk_kernel<M, SL, ABL, DEPTH, NT, false>, LDS_BYTES));
+    LSQ_TRY(optin_lds(optin, &icm_walk_kernel<M, SL, ABL, DEPTH, NT>, LDS_BYTES));
     const unsigned grid = (unsigned)(npass < 256 ? npass : 256);
-    hipLaunchKernelGGL((icm_walk_kernel<M, SL, ABL, DEPTH, NT, false>), dim3(grid), dim3(NT), LDS_BYTES, s, U, Ts, T, rec, valid, n, nodes, per_pass,
-                       skip, (T && ABL == 0) ? direct_max : 0, active_total, skip ? ref_rec : nullptr, skip ? ref_valid : nullptr, ta);
+    hipLaunchKernelGGL((icm_walk_kernel<M, SL, ABL, DEPTH, NT>), dim3(grid), dim3(NT), LDS_BYTES, s, U, Ts, T, rec, valid, n, nodes, per_pass,
+                       skip, (T && ABL == 0) ? direct_max : 0, active_total, skip ? ref_rec : nullptr, skip ? ref_valid : nullptr);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }
@@ -936,7 +774,7 @@ int lsq_walk_slice_width(int m) {
 // `order[nnodes]`: the node updates to run back to back inside the launch (1 = one node; icmiter*m = a whole ILS iteration)
 int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const float *T, uint8_t *rec, unsigned short *valid, int64_t n, int m,
                         const int32_t *order, int nnodes, int pos0, int use_skip, unsigned long long *active_total, int ablation, int light,
-                        const uint8_t *ref_rec, const unsigned short *ref_valid, const lsq_team_bufs *tb) {
+                        const uint8_t *ref_rec, const unsigned short *ref_valid) {
     if (n <= 0 || nnodes <= 0) return LSQ_OK;
     if (m < 1 || m > LSQ_MAX_M) { lsq_set_error("m = %d out of range 1..16", m); return LSQ_EINVAL; }
     for (int done = 0; done < nnodes; done += LSQ_WALK_MAX_NODES) {
@@ -951,14 +789,13 @@ int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const fl
         // m >= 14: up to 15 table reads in flight + 8 staged table registers per thread do not fit 128 VGPRs (measured at
         // m = 16: 67..100 spilled registers, 1.5..2.5x slower) -> 512-thread blocks (256 VGPRs per wave), more U items in
         // flight instead.  m = 9..13 fit (<= 4 spills) and are 3-5 % faster with 1024 threads (measured for every m).
-#define LSQ_WALK_ARGS s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light, ref_rec, ref_valid, tb
+#define LSQ_WALK_ARGS s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light, ref_rec, ref_valid
 #define LSQ_WALK_CASE_MID(MM) case MM: LSQ_TRY((launch_walk_t<MM, 8, 0, 2>(LSQ_WALK_ARGS))); break;
 #define LSQ_WALK_CASE_BIG(MM) case MM: LSQ_TRY((launch_walk_t<MM, 8, 0, 4, 512>(LSQ_WALK_ARGS))); break;
 #define LSQ_WALK_CASE(MM, SLL) case MM: LSQ_TRY((launch_walk_t<MM, SLL, 0, 3>(LSQ_WALK_ARGS))); break;
 #ifdef LSQ_TUNING      // timing-only variants and alternative shapes: profiling library only (results of the ablations are garbage)
         bool handled = true;
-        if (tb) handled = false;                                       // adaptive launches use the shipped shapes only
-        else if (m <= 8 && lsq_walk_slice_width(m) == 8) {
+        if (m <= 8 && lsq_walk_slice_width(m) == 8) {
             switch (m) {
                 LSQ_WALK_CASE(1, 8) LSQ_WALK_CASE(2, 8) LSQ_WALK_CASE(3, 8) LSQ_WALK_CASE(4, 8)
                 LSQ_WALK_CASE(5, 8) LSQ_WALK_CASE(6, 8) LSQ_WALK_CASE(7, 8) LSQ_WALK_CASE(8, 8)
@@ -986,28 +823,6 @@ int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const fl
 #undef LSQ_WALK_CASE_BIG
 #undef LSQ_WALK_CASE_MID
     }
-    return LSQ_OK;
-}
-
-// bookkeeping launch between two adaptive node updates (see icm_apply_scan_kernel): fold node j's team partials (j >= 0, only
-// when the device chose a team size > 1), then build the active lists of node jnext (jnext >= 0) into seglist / segcount_next
-int lsq_launch_icm_apply_scan(hipStream_t s, uint8_t *rec, unsigned short *valid, int64_t n, int m, int j, int jnext, int use_skip,
-                              const lsq_team_bufs *tb, unsigned *segcount_next, const uint8_t *ref_rec, const unsigned short *ref_valid) {
-    if (n <= 0) return LSQ_OK;
-    if (!valid || !tb) { lsq_set_error("lsq_launch_icm_apply_scan: validity masks and team buffers required"); return LSQ_EINVAL; }
-    int per_pass = 1, npass = 1, PP = 4096;
-    lsq_walk_geometry(n, m, &per_pass, &npass, &PP);
-    const int cap = tb->cap > 0 ? tb->cap : PP * 15 / 16;
-    const int g16 = (npass + LSQ_TEAM_MAX - 1) / LSQ_TEAM_MAX * LSQ_TEAM_MAX;
-    const int walk_grid = g16 < 256 ? g16 : 256;
-    const int skip = use_skip ? 1 : 0;
-    if (lsq_code_stride(m) == 8)
-        hipLaunchKernelGGL(icm_apply_scan_kernel<8>, dim3((unsigned)npass), dim3(1024), 0, s, rec, valid, n, per_pass, j, jnext, skip, tb->segcount, segcount_next,
-                           const_cast<unsigned short *>(tb->seglist), tb->part, npass, tb->smax, cap, walk_grid, skip ? ref_rec : nullptr, skip ? ref_valid : nullptr);
-    else
-        hipLaunchKernelGGL(icm_apply_scan_kernel<16>, dim3((unsigned)npass), dim3(1024), 0, s, rec, valid, n, per_pass, j, jnext, skip, tb->segcount, segcount_next,
-                           const_cast<unsigned short *>(tb->seglist), tb->part, npass, tb->smax, cap, walk_grid, skip ? ref_rec : nullptr, skip ? ref_valid : nullptr);
-    LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }
 

@@ -10,7 +10,6 @@
 
 #define LSQ_H 256          // candidates per codebook: one wave x float4 per lane
 #define LSQ_MAX_M 16
-#define LSQ_TEAM_DEFAULT 16      // largest team size of an adaptive node update (option "team")
 #define LSQ_WALK_TRACE 64        // per-position (sweep * m + rank in the node order, mod 64) recomputed node updates
 #define LSQ_WALK_COUNTERS (4 + LSQ_WALK_TRACE)      // device counters of the walk kernel: [0] node updates recomputed, [1..3] staged / light / team block-node-updates, [4..] trace
 
@@ -120,22 +119,10 @@ int lsq_launch_tables_to_slices(hipStream_t s, const float *T, float *Ts, int m,
 // active_total (optional): += number of vectors actually recomputed; ablation != 0: timing-only variants (m = 8), garbage results.
 // U is the slice-major unary buffer of ALL nodes; T (optional) the row-major tables for light blocks' L2 gathers; order[nnodes] = node updates run back to back inside the launch
 // (a block owns its vectors for the whole launch): 1 entry = one node update, icmiter*m entries = a whole ILS iteration.
-// Adaptive (team) launches: device buffers written by lsq_launch_icm_apply_scan and read by the next one-node walk launch.
-//   segcount [npass] u32, seglist [npass][4096] u16, part [smax][n] u64; smax = largest team size (1, 2, 4, 8, 16); cap = 0 -> default
-struct lsq_team_bufs { const unsigned *segcount; const unsigned short *seglist; unsigned long long *part; int smax; int cap; };
-// largest power of two S <= smax such that the active vectors, spread over npass/S ranges, still fit one block's bookkeeping
-__host__ __device__ inline int lsq_team_size(unsigned long long active, int npass, int grid, int smax, int cap) {
-    int S = 1;
-    while (2 * S <= smax && grid % (2 * S) == 0 && active * (unsigned long long)(2 * S) <= (unsigned long long)cap * (unsigned long long)npass) S *= 2;
-    return S;
-}
 void lsq_walk_geometry(int64_t n, int m, int *per_pass, int *npass, int *pp_cap);      // segments of the walk kernel over n vectors
-// tb != nullptr: ONE node (nnodes == 1), the team size is chosen on the device from tb->segcount; a lsq_launch_icm_apply_scan must follow
 int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const float *T, uint8_t *rec, unsigned short *valid, int64_t n, int m,
                         const int32_t *order, int nnodes, int pos0, int use_skip, unsigned long long *active_total, int ablation, int light,
-                        const uint8_t *ref_rec, const unsigned short *ref_valid, const lsq_team_bufs *tb);
-int lsq_launch_icm_apply_scan(hipStream_t s, uint8_t *rec, unsigned short *valid, int64_t n, int m, int j, int jnext, int use_skip,
-                              const lsq_team_bufs *tb, unsigned *segcount_next, const uint8_t *ref_rec, const unsigned short *ref_valid);
+                        const uint8_t *ref_rec, const unsigned short *ref_valid);
 // ref_rec / ref_valid (optional, read-only): the vectors' current records and their validity masks; a candidate that becomes
 // equal to its current record inherits those bits (exact: validity depends on the code tuple only)
 // light: blocks with <= light active vectors gather table columns from L2 instead of staging slices (-1 = default 256)

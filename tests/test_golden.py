@@ -38,13 +38,11 @@ def test_oracle_reproduces_golden(oracle, path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("schedule", [5, 4, 3, 2, 0, 1])
+@pytest.mark.parametrize("schedule", [4, 3, 2, 0, 1])
 @pytest.mark.parametrize("path", FIXTURES, ids=lambda p: os.path.basename(p)[:-4])
 def test_hip_reproduces_golden(lsq, path, schedule):
     z, X, K, d, n, m, J, npert, randord, seed = _load(path)
     with lsq.Engine(0, schedule=schedule, tuning=schedule < 3) as eng:
-        if schedule == 5:
-            eng.set_option("team_min", 0)
         Bs, objs = eng.encode_icm(X, z["B0"], K, m, z["ilsiters"], J, npert, randord, seed=seed)
         assert np.array_equal(Bs, z["Bs"]), "%d codes differ" % (Bs != z["Bs"]).sum()
         assert np.allclose(objs, z["objs"], rtol=1e-5, atol=0)            # north_star tolerance for the MSE

@@ -74,15 +74,13 @@ CONFIGS = [
 ]
 
 
-@pytest.mark.parametrize("schedule", [5, 4, 3, 2, 0, 1])
+@pytest.mark.parametrize("schedule", [4, 3, 2, 0, 1])
 @pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: "d%d_n%d_m%d" % (c[0], c[1], c[2]))
 def test_encode_icm_matches_oracle(lsq, oracle, cfg, schedule):
     d, n, m, ils, J, npert, randord, seed, kind = cfg
     X, K, B0 = make_problem(d, n, m, seed=seed, kind=kind)
     Bs_ref, objs_ref, st_ref = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, randord, seed, want_stats=True)
     with lsq.Engine(0, schedule=schedule, tuning=schedule < 3) as eng:
-        if schedule == 5:
-            eng.set_option("team_min", 0)            # adaptive one-node launches even at these tiny sizes
         Bs, objs = eng.encode_icm(X, B0, K, m, ils, J, npert, randord, seed=seed)
     assert np.array_equal(Bs, Bs_ref), "%d of %d codes differ" % ((Bs != Bs_ref).sum(), Bs.size)
     assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0)

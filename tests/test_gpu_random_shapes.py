@@ -54,7 +54,7 @@ def test_random_shape_matches_oracle(lsq, oracle, case):
         tm = eng.timings()
     assert np.array_equal(Bs, Bs_ref), "%d of %d codes differ" % ((Bs != Bs_ref).sum(), Bs.size)
     assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0)
-    staged, light = tm["staged_blocks"] + tm["team_blocks"], tm["light_blocks"]
+    staged, light = tm["staged_blocks"] + tm["filtered_blocks"], tm["light_blocks"]
     if J == 0:
         assert staged == 0 and light == 0                  # no sweeps: perturbation + accept only
     elif mode == "forced":

@@ -4,7 +4,7 @@ because a block with <= 256 active vectors -- any n <= 65 536 -- takes the L2-ga
 
 Two ways to make blocks stage:  option "light" = 0 (always stage, any n)  and  natural staging (n large enough that every
 block holds more than 256 active vectors).  Each test asserts WHICH path ran through the device counters exported in
-`lsq_timings` (staged_blocks / light_blocks / team_blocks).
+`lsq_timings` (staged_blocks / light_blocks / filtered_blocks).
 
 Instantiation families (csrc/lsq_icm.hip, lsq_launch_icm_walk): m = 1..8 -> <M,16,DEPTH 3,1024 threads>;
 m = 9..13 -> <M,8,DEPTH 2,1024>; m = 14..16 -> <M,8,DEPTH 4,512>.  The reference demos use m = 7 (demo_lsq_gpu.jl:15);
@@ -21,7 +21,7 @@ H = 256
 
 def _paths(eng):
     t = eng.timings()
-    return t["staged_blocks"], t["light_blocks"], t["team_blocks"]
+    return t["staged_blocks"], t["light_blocks"], t["filtered_blocks"]
 
 
 @pytest.mark.parametrize("m", list(range(1, 17)))
@@ -169,84 +169,3 @@ def test_cfg5_chunk_walk(lsq, oracle):
         assert torch.equal(dq[0], dBs[0][:q])
         assert abs(sq[0] / q - c.astype(np.float64).mean()) <= 1e-6 * sq[0] / q
 
-
-# ---- adaptive team-tiled node updates (schedule 5) ---------------------------------------------------------------------------
-def _run_sched5(lsq, X, B0, K, m, ils, J, npert, seed, **opts):
-    with lsq.Engine(0, schedule=5) as eng:
-        for k, v in opts.items():
-            eng.set_option(k, v)
-        Bs, objs = eng.encode_icm(X, B0, K, m, ils, J, npert, True, seed=seed)
-        t = eng.timings()
-        stats = None
-    return Bs, objs, t
-
-
-@pytest.mark.parametrize("m", list(range(2, 17)))
-def test_teams_every_m(lsq, oracle, m):
-    """Schedule 5, every codebook count: n = 6000 (forced adaptive with team_min = 0) so that teams of every size form as the
-    sweeps thin out; compared with the oracle on all vectors; the team path must actually have run."""
-    d, n, ils, J, npert, seed = 16, 6000 + 11 * m, [1, 3], 3, min(4, m), 700 + m
-    X, K, B0 = make_problem(d, n, m, seed=seed, kind="gauss")
-    Bs_ref, objs_ref = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, True, seed)
-    for opts in ({"team_min": 0}, {"team_min": 0, "team_from": 0, "team": 4}, {"team_min": 0, "skip": 0}, {"team_min": 0, "fallback": 0, "team": 2}):
-        Bs, objs, t = _run_sched5(lsq, X, B0, K, m, ils, J, npert, seed, **opts)
-        assert np.array_equal(Bs, Bs_ref), "m=%d %r: %d of %d codes differ" % (m, opts, (Bs != Bs_ref).sum(), Bs.size)
-        assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0)
-        assert t["team_blocks"] > 0, "m=%d %r: the team path did not run (%r)" % (m, opts, t)
-
-
-@pytest.mark.parametrize("m,n,d", [(8, 125_000, 32), (7, 100_000, 16), (16, 70_000, 16), (12, 200_000, 16), (8, 300_000, 16)])
-def test_teams_mid_size_natural(lsq, oracle, m, n, d):
-    """Mid-size chunks (cfg4's per-GPU share is 125 000 vectors): teams form from the first sweep on without any forcing.
-    Codes, objective and the recomputed-node-update count must equal schedule 4's (the memoisation rule is the same), and the oracle's."""
-    ils, J, npert, seed = [2], 3 if m <= 8 else 2, min(4, m), 40 + m
-    X, K, B0 = make_problem(d, n, m, seed=seed, kind="gauss")
-    Bs_ref, objs_ref = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, True, seed)
-    Bs, objs, t5 = _run_sched5(lsq, X, B0, K, m, ils, J, npert, seed)
-    assert np.array_equal(Bs, Bs_ref), "%d of %d codes differ" % ((Bs != Bs_ref).sum(), Bs.size)
-    assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0)
-    assert t5["team_blocks"] > 0
-    with lsq.Engine(0, schedule=4) as eng:
-        Bs4, _ = eng.encode_icm(X, B0, K, m, ils, J, npert, True, seed=seed)
-        t4 = eng.timings()
-    assert np.array_equal(Bs4, Bs_ref)
-    assert t5["icm_node_updates"] == t4["icm_node_updates"]
-
-
-def test_teams_overflowing_ranges_run_in_chunks(lsq, oracle):
-    """team_cap far below what a team's range holds: every team's active list overflows the LDS bookkeeping of one block and is
-    processed in several chunks (re-staging its slices) -- the robustness path for data whose active vectors cluster."""
-    d, n, m, ils, J, npert, seed = 16, 120_000, 8, [2], 3, 4, 77
-    X, K, B0 = make_problem(d, n, m, seed=seed, kind="gauss")
-    Bs_ref, objs_ref = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, True, seed)
-    # cap is only the AIM of the device-side size choice: with cap = 8000 the first sweep picks S = 16, i.e. 120 000 / 16 = 7500 active
-    # vectors per team > the 4096 one block can book-keep -> two chunks per team
-    Bs, objs, t = _run_sched5(lsq, X, B0, K, m, ils, J, npert, seed, team_from=0, team=16, team_cap=8000)
-    assert np.array_equal(Bs, Bs_ref), "%d of %d codes differ" % ((Bs != Bs_ref).sum(), Bs.size)
-    assert t["team_blocks"] > 0
-
-
-def test_teams_device_api_chunks_and_full_size(lsq, oracle):
-    """Schedule 5 on BASELINE configs[1] at full size: identical codes / sums / counters to schedule 4 (10^6 vectors, two ILS
-    snapshots), with both paths of the hybrid in use (dense first sweep staged by whole blocks, later sweeps by teams); plus
-    resident chunks of ragged sizes."""
-    import torch
-    n, d, m, ils, J, npert, seed = 1_000_000, 128, 8, [1, 3], 4, 4, 42
-    with lsq.Engine(0, schedule=4) as e4, lsq.Engine(0, schedule=5) as e5, lsq.Engine(0, schedule=5, chunk=270_001) as e5c:
-        dX = e4.synth_data_u8_dev(1234, n, d)
-        dB0 = e4.randinit_dev(7, n, m)
-        dK = e4.synth_codebooks_dev(4321, m, d)
-        ref, sums, stats = e4.encode_icm_dev(dX, dB0, dK, m, ils, J, npert, True, seed=seed)
-        nu4 = e4.timings()["icm_node_updates"]
-        for e in (e5, e5c):
-            got, s5, st5 = e.encode_icm_dev(dX, dB0, dK, m, ils, J, npert, True, seed=seed)
-            t5 = e.timings()
-            assert torch.equal(got, ref)
-            assert np.allclose(s5, sums, rtol=1e-12) and np.array_equal(st5, stats)
-            assert t5["icm_node_updates"] == nu4
-            assert t5["team_blocks"] > 0 and t5["staged_blocks"] > 0
-        # a sample against the oracle
-        X, K = dX[:512].cpu().numpy(), dK.cpu().numpy()
-        B0 = dB0[:512].cpu().numpy().astype(np.int16) + 1
-        r, _ = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, True, seed)
-        assert np.array_equal(r[1], ref[1][:512].cpu().numpy().astype(np.int16) + 1)

@@ -14,7 +14,7 @@ def run(n, d, m, sched, opts, ils=16, J=4, steps=3):
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
         tm = eng.timings()
         r = dict(n=n, d=d, m=m, sched=sched, opts=opts, ms=dt * 1e3, Mvps=n / dt / 1e6, icm_ms=tm["icm_ms"] / steps, unaries_ms=tm["unaries_ms"]/steps, cost_ms=tm["cost_ms"]/steps,
-                 staged=tm["staged_blocks"] // steps, light=tm["light_blocks"] // steps, team=tm["team_blocks"] // steps, obj=float(sums[0] / n))
+                 staged=tm["staged_blocks"] // steps, light=tm["light_blocks"] // steps, team=tm["filtered_blocks"] // steps, obj=float(sums[0] / n))
         print(json.dumps(r), flush=True); res.append(r)
 for n, d, m in ((1_000_000, 128, 8), (125_000, 960, 8), (100_000, 128, 8), (250_000, 128, 8), (500_000, 128, 8), (1_000_000, 128, 16), (10_000, 128, 8)):
     run(n, d, m, 4, {})
