@@ -74,6 +74,9 @@ typedef struct lsq_timings {
     int64_t staged_blocks;   /* table slices staged through LDS, the block walked all of them (team size 1)  */
     int64_t light_blocks;    /* few active vectors: table columns gathered from L2, one wave per vector       */
     int64_t filtered_blocks; /* 16-bit filtered walk (exact refinement of ambiguous vectors), LDS-staged slices       */
+    int64_t filter_refined;  /* node updates the 16-bit filter could not decide: every candidate within the window evaluated exactly */
+    int64_t filter_exact;    /* ... number of exact f32 candidate evaluations that took                               */
+    int64_t filter_f32;      /* node updates sent to the f32 path because a unary fell outside the sampled level range  */
 } lsq_timings;
 
 LSQ_API const char *lsq_last_error(void);

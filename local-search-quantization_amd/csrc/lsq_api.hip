@@ -59,20 +59,25 @@ struct lsq_ctx {
     hipStream_t stream = nullptr;
     int64_t chunk = 1 << 20;
     int profile = 0;
-    int schedule = 4;        // 0: per-node L2-gather kernel, 1: fused sweeps, 2: LDS-slice + combine, 3: LDS-walk, one launch per node,
-                             // 4: LDS-walk, one launch per ILS iteration (default)
+    int schedule = 6;        // 3: LDS-walk (f32), one launch per node; 4: the same, one launch per ILS iteration; 6 (default): 16-bit filtered walk
+                             // with exact refinement, one launch per ILS iteration (chunks below q16_min vectors / non-finite data: schedule 4);
+                             // tuning build only: 0 per-node L2 gathers, 1 fused sweeps, 2 LDS slices + combine
+    int64_t q16_min = 65536; // schedule 6: smaller chunks take schedule 4 (every block is light there: nothing to filter)
+    int tables_changed = 1;  // schedule 6: the pair tables were rebuilt since the last lsq_launch_q16_prepare
+    int per_node = 0;        // schedule 6: one launch per node update instead of 64 per launch (profiling: per-sweep timings / counters)
     int ablation = 0;        // timing-only kernel ablations (results are garbage when != 0)
     int light = -1;          // schedules 3/4: light-block threshold (-1 = default)
     int fallback = 1;        // schedules 3/4: a candidate equal to its current record inherits that record's validity bits (exact)
     int skip = 1;            // schedule 3: skip node updates whose inputs did not change (exact memoisation)
     // workspace
     DevBuf sci, T, Ts, U, part, vCur, vNew, active, recCur, recNew, prev, counters, obj, bad;
+    DevBuf Uq, Tq, qp, qscratch, qflag;                // 16-bit filtered walk: u16 unary planes, u16 slice tables, lsq_q16_params, bound scratch, per-vector out-of-range flags
     DevBuf sX, sX2, sK, sB16, sOut16, sTight, sF32;    // staging for the host-buffer entry points (sX/sX2: double-buffered X chunks)
     hipStream_t copy_stream = nullptr;               // H2D of X runs here, under the compute of the previous panel / chunk
     hipEvent_t copy_done = nullptr;
     // timings
     double cat_ms[CAT_COUNT] = {0, 0, 0, 0, 0, 0};
-    int64_t icm_launches = 0, icm_node_updates = 0, staged_blocks = 0, light_blocks = 0, filtered_blocks = 0;
+    int64_t icm_launches = 0, icm_node_updates = 0, staged_blocks = 0, light_blocks = 0, filtered_blocks = 0, filter_refined = 0, filter_exact = 0, filter_f32 = 0;
     int64_t trace[LSQ_WALK_TRACE] = {0};
     struct Pending { hipEvent_t a, b; int cat; };
     std::vector<Pending> pending;
@@ -148,7 +153,7 @@ extern "C" int lsq_destroy(lsq_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : c->pool) (void)hipEventDestroy(e);
-    DevBuf *bufs[] = {&c->sci, &c->T, &c->Ts, &c->U, &c->part, &c->vCur, &c->vNew, &c->active, &c->recCur, &c->recNew, &c->prev, &c->counters, &c->obj, &c->bad,
+    DevBuf *bufs[] = {&c->Uq, &c->Tq, &c->qp, &c->qscratch, &c->qflag, &c->sci, &c->T, &c->Ts, &c->U, &c->part, &c->vCur, &c->vNew, &c->active, &c->recCur, &c->recNew, &c->prev, &c->counters, &c->obj, &c->bad,
                       &c->sX, &c->sX2, &c->sK, &c->sB16, &c->sOut16, &c->sTight, &c->sF32};
     for (DevBuf *b : bufs) b->release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -177,11 +182,13 @@ extern "C" int lsq_set_option(lsq_ctx *c, const char *key, int64_t value) {
 #endif
     else if (!strcmp(key, "light")) c->light = (int)value;
     else if (!strcmp(key, "fallback")) c->fallback = (int)value;
+    else if (!strcmp(key, "q16_min")) c->q16_min = value;
+    else if (!strcmp(key, "per_node")) c->per_node = value != 0;
     else if (!strcmp(key, "schedule")) {
 #ifdef LSQ_TUNING
-        if (value < 0 || value > 4) { lsq_set_error("schedule must be 0..4"); return LSQ_EINVAL; }
+        if (value < 0 || value > 6 || value == 5) { lsq_set_error("schedule must be 0..4 or 6"); return LSQ_EINVAL; }
 #else
-        if (value < 3 || value > 4) { lsq_set_error("schedule must be 3 or 4 (schedules 0..2 exist in the tuning build only)"); return LSQ_EINVAL; }
+        if (value != 3 && value != 4 && value != 6) { lsq_set_error("schedule must be 3, 4 or 6 (schedules 0..2 exist in the tuning build only)"); return LSQ_EINVAL; }
 #endif
         c->schedule = (int)value;
     } else { lsq_set_error("unknown option '%s'", key); return LSQ_EINVAL; }
@@ -203,6 +210,9 @@ extern "C" int lsq_get_timings(lsq_ctx *c, lsq_timings *out) {
     out->staged_blocks = c->staged_blocks;
     out->light_blocks = c->light_blocks;
     out->filtered_blocks = c->filtered_blocks;
+    out->filter_refined = c->filter_refined;
+    out->filter_exact = c->filter_exact;
+    out->filter_f32 = c->filter_f32;
     return LSQ_OK;
 }
 
@@ -216,7 +226,7 @@ extern "C" int lsq_reset_timings(lsq_ctx *c) {
     LSQ_TRY(use_device(c));
     LSQ_TRY(resolve_timings(c));
     for (double &v : c->cat_ms) v = 0.0;
-    c->icm_launches = c->icm_node_updates = c->staged_blocks = c->light_blocks = c->filtered_blocks = 0;
+    c->icm_launches = c->icm_node_updates = c->staged_blocks = c->light_blocks = c->filtered_blocks = c->filter_refined = c->filter_exact = c->filter_f32 = 0;
     for (int64_t &v : c->trace) v = 0;
     return LSQ_OK;
 }
@@ -282,6 +292,7 @@ static int u_slice_width(const lsq_ctx *c, int m) {      // layout of the unary 
 
 static int prepare_tables(lsq_ctx *c, const float *dK, int d, int m) {
     Timer t(c, CAT_TABLES);
+    c->tables_changed = 1;
     const int mh = m * LSQ_H;
     LSQ_TRY(c->sci.ensure(sizeof(float) * (size_t)mh));
     LSQ_TRY(c->T.ensure(sizeof(float) * (size_t)mh * mh));
@@ -296,13 +307,33 @@ static int prepare_tables(lsq_ctx *c, const float *dK, int d, int m) {
 }
 
 // unaries of rows [r0, r0 + rows) of a cn-vector chunk (dX points at the chunk's first vector)
+static bool use_q16(const lsq_ctx *c, int64_t cn) { return c->schedule == 6 && cn >= c->q16_min; }
+
 static int build_unaries(lsq_ctx *c, const float *dX, const float *dK, int d, int64_t cn, int m, int slice, int64_t r0, int64_t rows) {
+    uint16_t *dq = nullptr;
+    if (slice > 0 && r0 == 0 && rows == cn && use_q16(c, cn)) {
+        // 16-bit filtered walk: rigorous value bounds of this chunk -> parameters -> 16-bit slice tables; the GEMM below then also emits the u16 planes
+        Timer t(c, CAT_TABLES);
+        LSQ_TRY(c->Uq.ensure(sizeof(uint16_t) * (size_t)m * (size_t)cn * LSQ_H));
+        LSQ_TRY(c->Tq.ensure(sizeof(uint16_t) * (size_t)m * (size_t)(m > 1 ? m - 1 : 1) * LSQ_H * LSQ_H));
+        LSQ_TRY(c->qscratch.ensure(256 + sizeof(float) * 2 * (size_t)m * m));
+        LSQ_TRY(c->qflag.ensure(sizeof(unsigned short) * (size_t)(cn + 2)));
+        LSQ_TRY(c->qp.ensure(sizeof(lsq_q16_params)));
+        if (c->tables_changed) LSQ_HIP(hipMemsetAsync(c->qp.p, 0, sizeof(lsq_q16_params), c->stream));      // first chunk of a call: ok = 0, oor = 0
+        char *sc = c->qscratch.as<char>();
+        LSQ_TRY(lsq_launch_q16_prepare(c->stream, dX, cn, d, dK, c->sci.as<float>(), c->T.as<float>(), m, c->Tq.as<uint16_t>(),
+                                       reinterpret_cast<int *>(sc + 16), reinterpret_cast<float *>(sc + 256), reinterpret_cast<unsigned *>(sc + 64),
+                                       c->qflag.as<unsigned short>(), c->qp.as<lsq_q16_params>(), c->tables_changed));
+        c->tables_changed = 0;
+        dq = c->Uq.as<uint16_t>();
+    }
     Timer t(c, CAT_UNARIES);
     LSQ_TRY(c->U.ensure(sizeof(float) * (size_t)m * (size_t)cn * LSQ_H));
     // row-major  (slice == 0): U[(j*cn + i)*h + a]                      = chain(x_i[t] * -2 K[j,a][t]) + sci[j,a]
     // slice-major (slice = SL): U[j*cn*h + ((a/SL)*cn + i)*SL + a%SL]   (same values, LDS-slice schedule)
     return lsq_launch_chain_gemm(c->stream, dX + r0 * d, dK, c->sci.as<float>(), -2.0f, rows, m * LSQ_H, d, LSQ_H, cn * (int64_t)LSQ_H, LSQ_H,
-                                 c->U.as<float>(), slice, cn, r0);
+                                 c->U.as<float>(), slice, cn, r0, dq, dq ? lsq_q16_slice_width(m) : 0, dq ? c->qp.as<lsq_q16_params>() : nullptr, 0,
+                                 dq ? c->qflag.as<unsigned short>() : nullptr, nullptr);
 }
 
 // ref_rec / ref_valid: the vectors' current records and validity masks (read-only during the sweeps), or nullptr
@@ -334,6 +365,25 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t c
         std::vector<int32_t> seq((size_t)nsweeps * m);
         for (int sw = 0; sw < nsweeps; ++sw)
             for (int q = 0; q < m; ++q) seq[(size_t)sw * m + q] = order[q];
+        const int *idle = nullptr;
+        if (use_q16(c, cn) && valid) {
+            // 16-bit filtered walk; when the chunk's bounds were not usable (params.ok == 0: non-finite data) it idles and the f32 walk
+            // below -- which idles when params.ok == 1 -- does the work.  64 node updates per launch, as below.
+            const lsq_q16_params *P = c->qp.as<lsq_q16_params>();
+            const size_t per_launch = c->per_node ? 1 : 64;
+            for (size_t done = 0; done < seq.size(); done += per_launch) {
+                const int cntn = (int)std::min<size_t>(per_launch, seq.size() - done);
+                LSQ_TRY(lsq_launch_icm_walkq(c->stream, c->U.as<float>(), c->Uq.as<uint16_t>(), c->Tq.as<uint16_t>(), c->T.as<float>(), rec, valid, cn, m,
+                                             seq.data() + done, cntn, (int)done, c->skip, c->active.as<unsigned long long>(), c->light,
+                                             c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr, P, c->qflag.as<unsigned short>()));
+                LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>(), c->Ts.as<float>(), c->T.as<float>(), rec, valid, cn, m, seq.data() + done, cntn, (int)done, c->skip,
+                                            c->active.as<unsigned long long>(), 0, c->light, c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr,
+                                            reinterpret_cast<const int *>(P)));
+            }
+            c->icm_launches += ((int64_t)seq.size() + (int64_t)per_launch - 1) / (int64_t)per_launch;
+            return LSQ_OK;
+        }
+        (void)idle;
         LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>(), c->Ts.as<float>(), c->T.as<float>(), rec, valid, cn, m, seq.data(), (int)seq.size(), 0, c->skip,
                                     c->active.as<unsigned long long>(), c->ablation, c->light, c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr));
         c->icm_launches += ((int64_t)seq.size() + 63) / 64;
@@ -431,6 +481,9 @@ static int finish_call(lsq_ctx *c, int64_t I, int nr, double *obj_sums, int64_t 
         c->staged_blocks += (int64_t)act[1];
         c->light_blocks += (int64_t)act[2];
         c->filtered_blocks += (int64_t)act[3];
+        c->filter_refined += (int64_t)act[4 + LSQ_WALK_TRACE];
+        c->filter_exact += (int64_t)act[4 + LSQ_WALK_TRACE + 1];
+        c->filter_f32 += (int64_t)act[4 + LSQ_WALK_TRACE + 2];
         for (int q = 0; q < LSQ_WALK_TRACE; ++q) c->trace[q] += (int64_t)act[4 + q];
     }
     if (stats) for (int64_t q = 0; q < 2 * I; ++q) stats[q] = (int64_t)cnt[(size_t)q];

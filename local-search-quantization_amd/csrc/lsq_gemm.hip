@@ -42,7 +42,7 @@ struct TileRegs { float4 v[BM * BK / 4 / 256]; };
 
 template <bool VEC4, int BK>
 __device__ inline void tile_load(const float *__restrict__ src, int64_t rows_total, int64_t row0, int Kd, int k0,
-                                 TileRegs<VEC4, BK> &t, int tid) {
+                                 TileRegs<VEC4, BK> &t, int tid, int64_t ld) {
     constexpr int Q4 = BK / 4, NE = BM * BK / 4 / 256;
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
@@ -52,7 +52,7 @@ __device__ inline void tile_load(const float *__restrict__ src, int64_t rows_tot
         const int kk = k0 + 4 * q;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gr < rows_total) {
-            const float *p = src + gr * (int64_t)Kd + kk;
+            const float *p = src + gr * ld + kk;
             if (VEC4 && kk + 3 < Kd) {
                 v = *reinterpret_cast<const float4 *>(p);
             } else {
@@ -78,12 +78,20 @@ __device__ inline void tile_store(const TileRegs<VEC4, BK> &t, float scale, floa
     }
 }
 
-template <bool VEC4, int BK>
+// Q16 = 1: the epilogue ALSO emits every value as a 16-bit fixed-point level q = rint((v - loU_j) * invD_j) of its column plane j = c / h
+// (lsq_q16_params) into the slice-major u16 planes Dq -- the filter input of icm_walkq_kernel.  The range [loU, loU + 65535 D) comes from a
+// SAMPLE of the rows (below), so a value may fall outside it: its level is clamped (meaningless), bit j of qflag[row] is raised and
+// icm_walkq_kernel sends that vector's node j through the f32 path -- exactness never depends on the sample.
+// Q16 = 2: range-only pass over a sample of the rows (every rts-th 128-row panel, contiguous reads): nothing is stored, the minimum / maximum of every column plane are
+// accumulated in qrange[2 j], qrange[2 j + 1] as order-preserving uint keys.
+template <bool VEC4, int BK, int Q16 = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void chain_gemm_kernel(const float *__restrict__ A, const float *__restrict__ Bm,
                                                          const float *__restrict__ addv, float alpha, int64_t M, int N,
                                                          int Kd, int h, int64_t plane_stride, int64_t row_stride,
                                                          float *__restrict__ D, int64_t row_tiles, int col_tiles, int slice,
-                                                         int64_t Mtot, int64_t rbase) {
+                                                         int64_t Mtot, int64_t rbase, uint16_t *__restrict__ Dq, int slice_q,
+                                                         lsq_q16_params *__restrict__ qp, int64_t lda, unsigned short *__restrict__ qflag,
+                                                         unsigned *__restrict__ qrange, int rts) {
     constexpr int LD = BK + 1;
     __shared__ float As[2][BM * LD];
     __shared__ float Bs[2][BN * LD];
@@ -94,7 +102,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int64_t rt = (s / col_tiles) * 8 + xcd;
     const int ct = (int)(s % col_tiles);
     if (rt >= row_tiles) return;
-    const int64_t row0 = rt * BM;
+    const int64_t row0 = rt * BM * rts;                  // rts > 1 (range-only pass): every rts-th 128-row panel
     const int col0 = ct * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -110,8 +118,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     TileRegs<VEC4, BK> ra, rb;
-    tile_load<VEC4, BK>(A, M, row0, Kd, 0, ra, tid);
-    tile_load<VEC4, BK>(Bm, N, col0, Kd, 0, rb, tid);
+    tile_load<VEC4, BK>(A, M, row0, Kd, 0, ra, tid, lda);
+    tile_load<VEC4, BK>(Bm, N, col0, Kd, 0, rb, tid, (int64_t)Kd);
     tile_store<VEC4, BK>(ra, 1.0f, As[0], tid);
     tile_store<VEC4, BK>(rb, alpha, Bs[0], tid);
     __syncthreads();
@@ -119,8 +127,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int k0 = 0; k0 < Kd; k0 += BK) {
         const bool more = k0 + BK < Kd;
         if (more) {                                              // next chunk travels HBM/L2 -> registers under this chunk's MFMAs
-            tile_load<VEC4, BK>(A, M, row0, Kd, k0 + BK, ra, tid);
-            tile_load<VEC4, BK>(Bm, N, col0, Kd, k0 + BK, rb, tid);
+            tile_load<VEC4, BK>(A, M, row0, Kd, k0 + BK, ra, tid, lda);
+            tile_load<VEC4, BK>(Bm, N, col0, Kd, k0 + BK, rb, tid, (int64_t)Kd);
         }
         const int kend = (Kd - k0 < BK) ? ((Kd - k0 + 1) & ~1) : BK;   // odd tail: one zero product appended
         const float *ap = As[cur] + (wy * 64 + l31) * LD + lhi;
@@ -141,6 +149,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         cur ^= 1;
     }
 
+    float bmin = __builtin_inff(), bmax = -__builtin_inff();      // range-only pass: the block tile lies in ONE column plane (h is a multiple of 128)
+    bool bnan = false;
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj) {
         const int c = col0 + wx * 64 + tj * 32 + l31;
@@ -153,6 +163,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const int64_t coff = slice ? (int64_t)(c / h) * plane_stride + (int64_t)(a / slice) * (Mtot * slice) + (a % slice)
                                    : (int64_t)(c / h) * plane_stride + a;
         const int64_t rstride = slice ? (int64_t)slice : row_stride;
+        float qlo = 0.f, qinv = 0.f;
+        int64_t qoff = 0;
+        int noor = 0;
+        const bool q16 = Q16 == 1 && qp->ok != 0;          // unusable bounds (non-finite data): the f32 walk handles the chunk, nothing to emit
+        if (q16) {
+            qlo = qp->node[c / h].loU;
+            qinv = qp->node[c / h].invD;
+            qoff = (int64_t)(c / h) * (Mtot * (int64_t)h) + (int64_t)(a / slice_q) * (Mtot * slice_q) + (a % slice_q);
+        }
+        float vmin = __builtin_inff(), vmax = -__builtin_inff();
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
 #pragma unroll
@@ -161,8 +181,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 if (row < M) {
                     float v = acc[ti][tj][r];
                     if (addv) v = v + add;           // one rounded add (utils.jl:112-118)
+                    if (Q16 == 2) { vmin = fminf(vmin, v); vmax = fmaxf(vmax, v); continue; }
                     D[coff + (rbase + row) * rstride] = v;
+                    if (q16) {
+                        const float qf = rintf((v - qlo) * qinv);
+                        if (!(qf >= 0.0f && qf <= 65535.0f)) { atomicOr(reinterpret_cast<unsigned *>(qflag + ((rbase + row) & ~(int64_t)1)), (1u << (c / h)) << (16 * (int)((rbase + row) & 1))); ++noor; }
+                        const uint32_t q16v = (uint32_t)fminf(fmaxf(qf, 0.0f), 65535.0f);
+                        const uint32_t nb = (uint32_t)__shfl_down((int)q16v, 1, 64);          // the next candidate of the same row (same lhi half)
+                        if (!(l31 & 1)) *reinterpret_cast<uint32_t *>(Dq + qoff + (rbase + row) * slice_q) = q16v | (nb << 16);
+                    }
                 }
+            }
+        }
+        if (q16 && noor) atomicAdd(&qp->oor, noor);
+        if (Q16 == 2) { bmin = fminf(bmin, vmin); bmax = fmaxf(bmax, vmax); bnan = bnan || !(vmin == vmin && vmax == vmax); }
+    }
+    if (Q16 == 2) {                                        // one pair of atomics per block (not per wave: they all hit the plane's two words)
+        __shared__ float rmin[4], rmax[4];
+        __shared__ int rnan[4];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { bmin = fminf(bmin, __shfl_xor(bmin, off, 64)); bmax = fmaxf(bmax, __shfl_xor(bmax, off, 64)); }
+        const bool wnan = __ballot(bnan) != 0ull;
+        if (lane == 0) { rmin[wave] = bmin; rmax[wave] = bmax; rnan[wave] = wnan ? 1 : 0; }
+        __syncthreads();
+        if (tid == 0) {
+            const float lo4 = fminf(fminf(rmin[0], rmin[1]), fminf(rmin[2], rmin[3])), hi4 = fmaxf(fmaxf(rmax[0], rmax[1]), fmaxf(rmax[2], rmax[3]));
+            const int plane = col0 / h;
+            if (rnan[0] | rnan[1] | rnan[2] | rnan[3]) atomicOr(&qrange[2 * LSQ_MAX_M], 1u);      // a non-finite value in the sample
+            else if (lo4 <= hi4) {
+                const unsigned bl = __float_as_uint(lo4), bh = __float_as_uint(hi4);
+                atomicMin(&qrange[2 * plane], bl ^ ((unsigned)((int)bl >> 31) | 0x80000000u));
+                atomicMax(&qrange[2 * plane + 1], bh ^ ((unsigned)((int)bh >> 31) | 0x80000000u));
             }
         }
     }
@@ -180,24 +229,48 @@ __global__ __launch_bounds__(256) void sqnorms_kernel(const float *__restrict__ 
 }  // namespace
 
 int lsq_launch_chain_gemm(hipStream_t s, const float *A, const float *Bm, const float *addv, float alpha, int64_t M,
-                          int N, int Kd, int h, int64_t plane_stride, int64_t row_stride, float *D, int slice, int64_t Mtot, int64_t rbase) {
+                          int N, int Kd, int h, int64_t plane_stride, int64_t row_stride, float *D, int slice, int64_t Mtot, int64_t rbase,
+                          uint16_t *Dq, int slice_q, lsq_q16_params *qp, int64_t lda, unsigned short *qflag, unsigned *qrange, int rts) {
+    if (lda <= 0) lda = Kd;
+    if (rts < 1) rts = 1;
     if (M <= 0 || N <= 0) return LSQ_OK;
-    const int64_t row_tiles = (M + BM - 1) / BM;
+    const int64_t row_tiles = (M + (int64_t)BM * rts - 1) / ((int64_t)BM * rts);
     const int col_tiles = (N + BN - 1) / BN;
     const int64_t blocks = ((row_tiles + 7) / 8) * 8 * col_tiles;
     if (blocks > 0x7fffffffLL) { lsq_set_error("chain_gemm: grid too large"); return LSQ_EINVAL; }
     const bool vec4 = (Kd % 4 == 0) && (((uintptr_t)A | (uintptr_t)Bm) % 16 == 0);
     const int bk = LSQ_KNOB("LSQ_GEMM_BK", 16);
     // K chunks of 8 or 16 only: both fit four resident blocks per CU (the kernel is compiled for 4 waves per SIMD)
+    if (qrange) {          // range-only pass
+        if (vec4 && lda % 4 == 0)
+            hipLaunchKernelGGL((chain_gemm_kernel<true, 16, 2>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
+                               plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, qrange, rts);
+        else
+            hipLaunchKernelGGL((chain_gemm_kernel<false, 16, 2>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
+                               plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, qrange, rts);
+        LSQ_HIP(hipGetLastError());
+        return LSQ_OK;
+    }
+    if (Dq) {
+        if (!qp || !qflag || slice_q < 1) { lsq_set_error("chain_gemm: quantised output needs parameters"); return LSQ_EINVAL; }
+        if (vec4)
+            hipLaunchKernelGGL((chain_gemm_kernel<true, 16, 1>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
+                               plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, Dq, slice_q, qp, lda, qflag, nullptr, 1);
+        else
+            hipLaunchKernelGGL((chain_gemm_kernel<false, 16, 1>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
+                               plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, Dq, slice_q, qp, lda, qflag, nullptr, 1);
+        LSQ_HIP(hipGetLastError());
+        return LSQ_OK;
+    }
     if (vec4 && bk == 8)
         hipLaunchKernelGGL((chain_gemm_kernel<true, 8>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase);
+                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, nullptr, 1);
     else if (vec4)
         hipLaunchKernelGGL((chain_gemm_kernel<true, 16>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase);
+                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, nullptr, 1);
     else
         hipLaunchKernelGGL((chain_gemm_kernel<false, 16>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase);
+                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, nullptr, 1);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }

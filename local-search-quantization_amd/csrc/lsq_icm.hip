@@ -28,56 +28,6 @@
 
 namespace {
 
-// vectors per block pass of the LDS-walk kernel: table + 10 B per vector must fit the 160 KiB LDS
-constexpr int lsq_walk_pp(int M, int SL) {
-    const int avail = 160 * 1024 - 256 - (M - 1) * LSQ_H * (SL / 4) * 16;      // bytes left beside the slice table
-    const int pp = avail / 10 / 64 * 64;
-    return pp > 4096 ? 4096 : pp;                                             // 4096 up to m = 14 (SL = 8), 4032 at m = 16
-}
-#define LSQ_WALK_PP(M, SL) lsq_walk_pp(M, SL)
-
-// Validity is a property of the code tuple alone ("code j is the first argmin of node j given the other codes").  When the
-// candidate tuple, after node j took `code`, equals the vector's CURRENT tuple (the state the ILS iteration started from, whose
-// validity bits were established earlier and are read-only during the sweeps), everything known about that tuple holds for
-// the candidate too: its bits are OR-ed in.  A vector that has fallen back to a known fixed point stops being recomputed at
-// once instead of being re-verified for another sweep.  Exact: only true statements about the same tuple are imported.
-template <int RW>
-__device__ inline unsigned short known_valid(const uint32_t (&rw)[RW], int j, uint8_t code, const uint8_t *ref, const unsigned short *refv) {
-    if (!ref || !refv) return 0;
-    bool same = true;
-#pragma unroll
-    for (int w = 0; w < RW; ++w) {
-        uint32_t mine = rw[w];
-        if (w == (j >> 2)) mine = (mine & ~(0xffu << (8 * (j & 3)))) | ((uint32_t)code << (8 * (j & 3)));
-        same = same && (mine == reinterpret_cast<const uint32_t *>(ref)[w]);
-    }
-    return same ? *refv : (unsigned short)0;
-}
-
-// Result of a node update for vector i: code j <- the index part of the packed minimum key; validity bookkeeping (exact skip):
-// a changed code invalidates every other node, an unchanged one confirms node j; what is known about the vector's current
-// state is imported when the candidate tuple equals it (known_valid).
-template <int CS>
-__device__ inline void apply_node_result(uint8_t *__restrict__ rec, unsigned short *__restrict__ valid, int64_t i, int j, unsigned long long key,
-                                         const uint8_t *__restrict__ ref_rec, const unsigned short *__restrict__ ref_valid) {
-    constexpr int RW = CS / 4;
-    const unsigned bi = (unsigned)(key & 0xffffffffull);
-    const uint8_t code = (uint8_t)(bi > 255 ? 0 : bi);
-    uint32_t rw[RW];                                     // the record before the update (one aligned load instead of a byte load)
-#pragma unroll
-    for (int w2 = 0; w2 < RW; ++w2) rw[w2] = reinterpret_cast<const uint32_t *>(rec + i * CS)[w2];
-    const uint8_t old = (uint8_t)(rw[j >> 2] >> (8 * (j & 3)));
-    rec[i * CS + j] = code;
-    if (valid) {
-        unsigned short vm = (code != old) ? (unsigned short)(1u << j) : (unsigned short)(valid[i] | (1u << j));
-        vm = (unsigned short)(vm | known_valid<RW>(rw, j, code, ref_rec ? ref_rec + i * CS : nullptr, ref_valid ? ref_valid + i : nullptr));
-        valid[i] = vm;
-    }
-}
-
-#define LSQ_WALK_MAX_NODES 64
-struct WalkNodes { int count; int pos0; uint8_t j[LSQ_WALK_MAX_NODES]; };      // kernel argument: the node updates of one launch, in order; pos0 = position of j[0] in the ILS iteration's node sequence (trace counters)
-
 // ---- LDS-walk kernel -------------------------------------------------------------------------------------------------------
 // ONE block walks the 256/SL slices of a node for its own range of <= 4096 vectors, keeping the running (min value, index) of
 // every vector in LDS as a packed 64-bit key.  Ts is the slice-major copy of the pair tables, Ts[j][slice][kk][b][SL]
@@ -89,9 +39,11 @@ __global__ __launch_bounds__(NT) void icm_walk_kernel(const float *__restrict__ 
                                                         uint8_t *__restrict__ rec, unsigned short *__restrict__ valid,
                                                         int64_t n, const WalkNodes nodes, int per_pass, int use_skip, int direct_max,
                                                         unsigned long long *__restrict__ active_total,
-                                                        const uint8_t *__restrict__ ref_rec, const unsigned short *__restrict__ ref_valid) {
+                                                        const uint8_t *__restrict__ ref_rec, const unsigned short *__restrict__ ref_valid,
+                                                        const int *__restrict__ idle_if_set) {
     constexpr int CS = (M <= 8) ? 8 : 16;
     constexpr int NS = LSQ_H / SL;
+    if (idle_if_set && *idle_if_set) return;            // the filtered walk (icm_walkq_kernel) did this launch's work
     constexpr int LPV = SL / 4;
     constexpr int VPW = 64 / LPV;
     constexpr int CW = (M - 1 + 3) / 4;
@@ -342,7 +294,20 @@ __global__ __launch_bounds__(NT) void icm_walk_kernel(const float *__restrict__ 
         for (int ci = threadIdx.x; ci < nact; ci += NT) best64[ci] = ~0ull;      // ordered before the first atomics by the slice-0 barriers
 
         walk_slices(j, lo, nact, nact == cnt, 0, NS);
-        for (int ci = threadIdx.x; ci < nact; ci += NT) apply_node_result<CS>(rec, valid, lo + list[ci], j, best64[ci], ref_rec, ref_valid);
+        {   // all of a thread's loads before its first store: one global round trip for its PP / NT vectors
+            constexpr int EPD = (PP + NT - 1) / NT;
+            int64_t vi[EPD];
+            uint32_t vcode[EPD];
+            bool von[EPD];
+#pragma unroll
+            for (int e = 0; e < EPD; ++e) {
+                const int ci = (int)threadIdx.x + e * NT;
+                von[e] = ci < nact;
+                vi[e] = lo + (von[e] ? list[ci] : 0);
+                vcode[e] = von[e] ? (uint32_t)(best64[ci] & 0xffffffffull) : 0u;
+            }
+            apply_node_results<CS, EPD>(rec, valid, vi, vcode, von, j, ref_rec, ref_valid);
+        }
         __syncthreads();
         }   // node updates
     }
@@ -699,24 +664,6 @@ inline unsigned wave_grid(int64_t n) {      // persistent grid: 4 waves per bloc
 }
 inline unsigned thread_grid(int64_t n) { return (unsigned)((n + 255) / 256); }
 
-// One-time, per-device opt-in to > 64 KiB of dynamic LDS for one kernel instantiation.  lsq_multi_* runs one host thread
-// per device through the launchers, so the "done" flags are guarded (unsynchronised function-local statics).
-struct LdsOptIn {
-    std::mutex mu;
-    bool done[64] = {};
-};
-template <class Kern>
-int optin_lds(LdsOptIn &st, Kern kernel, int bytes) {
-    int dev = 0;
-    LSQ_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lock(st.mu);
-    if (dev < 0 || dev >= 64 || !st.done[dev]) {
-        LSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        if (dev >= 0 && dev < 64) st.done[dev] = true;
-    }
-    return LSQ_OK;
-}
-
 }  // namespace
 
 
@@ -748,7 +695,7 @@ void lsq_walk_geometry(int64_t n, int m, int *per_pass, int *npass, int *pp_cap)
 template <int M, int SL, int ABL = 0, int DEPTH = 2, int NT = 1024>
 static int launch_walk_t(hipStream_t s, const float *U, const float *Ts, const float *T, uint8_t *rec, unsigned short *valid, int64_t n,
                          const WalkNodes &nodes, int use_skip, unsigned long long *active_total, int light,
-                         const uint8_t *ref_rec, const unsigned short *ref_valid) {
+                         const uint8_t *ref_rec, const unsigned short *ref_valid, const int *idle_if_set) {
     constexpr int TAB = (M - 1) * LSQ_H * (SL / 4);
     constexpr int PP = LSQ_WALK_PP(M, SL);
     constexpr int LDS_BYTES = TAB * 16 + PP * 8 + PP * 2;                // slice table + packed running best + active list
@@ -762,7 +709,7 @@ static int launch_walk_t(hipStream_t s, const float *U, const float *Ts, const f
     LSQ_TRY(optin_lds(optin, &icm_walk_kernel<M, SL, ABL, DEPTH, NT>, LDS_BYTES));
     const unsigned grid = (unsigned)(npass < 256 ? npass : 256);
     hipLaunchKernelGGL((icm_walk_kernel<M, SL, ABL, DEPTH, NT>), dim3(grid), dim3(NT), LDS_BYTES, s, U, Ts, T, rec, valid, n, nodes, per_pass,
-                       skip, (T && ABL == 0) ? direct_max : 0, active_total, skip ? ref_rec : nullptr, skip ? ref_valid : nullptr);
+                       skip, (T && ABL == 0) ? direct_max : 0, active_total, skip ? ref_rec : nullptr, skip ? ref_valid : nullptr, idle_if_set);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }
@@ -774,7 +721,7 @@ int lsq_walk_slice_width(int m) {
 // `order[nnodes]`: the node updates to run back to back inside the launch (1 = one node; icmiter*m = a whole ILS iteration)
 int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const float *T, uint8_t *rec, unsigned short *valid, int64_t n, int m,
                         const int32_t *order, int nnodes, int pos0, int use_skip, unsigned long long *active_total, int ablation, int light,
-                        const uint8_t *ref_rec, const unsigned short *ref_valid) {
+                        const uint8_t *ref_rec, const unsigned short *ref_valid, const int *idle_if_set) {
     if (n <= 0 || nnodes <= 0) return LSQ_OK;
     if (m < 1 || m > LSQ_MAX_M) { lsq_set_error("m = %d out of range 1..16", m); return LSQ_EINVAL; }
     for (int done = 0; done < nnodes; done += LSQ_WALK_MAX_NODES) {
@@ -789,7 +736,7 @@ int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const fl
         // m >= 14: up to 15 table reads in flight + 8 staged table registers per thread do not fit 128 VGPRs (measured at
         // m = 16: 67..100 spilled registers, 1.5..2.5x slower) -> 512-thread blocks (256 VGPRs per wave), more U items in
         // flight instead.  m = 9..13 fit (<= 4 spills) and are 3-5 % faster with 1024 threads (measured for every m).
-#define LSQ_WALK_ARGS s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light, ref_rec, ref_valid
+#define LSQ_WALK_ARGS s, U, Ts, T, rec, valid, n, nodes, use_skip, active_total, light, ref_rec, ref_valid, idle_if_set
 #define LSQ_WALK_CASE_MID(MM) case MM: LSQ_TRY((launch_walk_t<MM, 8, 0, 2>(LSQ_WALK_ARGS))); break;
 #define LSQ_WALK_CASE_BIG(MM) case MM: LSQ_TRY((launch_walk_t<MM, 8, 0, 4, 512>(LSQ_WALK_ARGS))); break;
 #define LSQ_WALK_CASE(MM, SLL) case MM: LSQ_TRY((launch_walk_t<MM, SLL, 0, 3>(LSQ_WALK_ARGS))); break;

@@ -1,0 +1,756 @@
+// lsq_icmq.hip -- the 16-bit FILTERED ICM node update (gfx950): same codes as icm_walk_kernel, half the bytes.
+//
+// A node update needs argmin_a s[a],  s[a] = ((U_j[a] + T_jk1[b_k1][a]) + T_jk2[b_k2][a]) + ...  (plain f32 adds, ascending k,
+// lowest index on ties: reference src/encodings/encode_icm.jl:84-119).  icm_walk_kernel evaluates all 256 candidates in f32: 1 KiB
+// of unaries from HBM and (m-1) KiB of table rows from LDS per vector and node -- both at their practical limits
+// (profiles/r02a_*: 5.7 TB/s of HBM, LDS 52 % busy).  Almost all of that precision is wasted: on SIFT-like data the best and the
+// second-best candidate differ by ~6000 while the values span ~10^6.  So:
+//
+//   FILTER   every term is also stored as a 16-bit level on ONE common step D_j per node (lsq_q16_params): U by the GEMM epilogue
+//            (Uq, slice-major u16), the pair tables by tables_to_q16_slices_kernel (Tq).  The levels of a candidate are summed with
+//            packed 16-bit adds, Q[a] = qU[a] + SUM_k qT_k[a] <= 65535 by construction, two candidates per VALU lane-op, 512 B of
+//            unaries and (m-1) x 512 B of table rows per vector and node.  A wave tracks the two smallest keys (Q << 16 | a).
+//   BOUND    |lo_sum + D Q[a] - s_f32[a]| <= slack := m (0.5 + 2^-5) D + eps_f32  for every candidate (rounding of each level,
+//            rounding of the f32 chain).  Hence the exact argmin a* obeys  Q[a*] <= Qmin + window,  window = floor(2 slack / D) + 1.
+//   REFINE   second - best > window: the best key IS the exact argmin (>= 98 % of the node updates).  Otherwise both candidates are
+//            evaluated EXACTLY (the f32 unaries the GEMM also wrote, the f32 tables, canonical order), and every other candidate c
+//            has s_f32[c] >= lo_sum + D (Q_second - m (0.5 + 2^-5)) - eps =: L3; if L3 > min(e1, e2) the lexicographic
+//            (value, index) minimum of the two is the answer, else (third candidate in reach, < 0.1 %) the vector is redone by
+//            one wave in full f32 (the light-block routine).
+// Non-finite inputs / degenerate ranges set params.ok = 0 and the launch leaves the chunk to icm_walk_kernel (both are enqueued;
+// exactly one of them works).  Parity: every test that compares icm_walk_kernel with the oracle also runs this kernel.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "lsq_wave.h"
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#ifdef LSQ_TUNING
+__device__ unsigned long long *g_walkq_dbg = nullptr;      // [launch slot][block][16] timestamps (tools only)
+__device__ unsigned int g_walkq_dbg_slot = 0;
+__device__ unsigned long long *g_walkq_dbg_cur = nullptr;   // block 0's record of the running launch (for q16_refine's stamps)
+#define DBG_STAMP(k) do { if (dbgp && threadIdx.x == 0) dbgp[k] = wall_clock64(); } while (0)
+#else
+#define DBG_STAMP(k) do {} while (0)
+#endif
+
+namespace {
+
+__device__ inline uint32_t pk_add_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b));      // v_pk_add_u16
+}
+__device__ inline uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ inline uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+// two smallest of the union of two (lo <= hi) pairs
+__device__ inline void top2_merge(uint32_t &lo, uint32_t &hi, uint32_t olo, uint32_t ohi) {
+    const uint32_t nhi = umin(umin(umax(lo, olo), hi), ohi);
+    lo = umin(lo, olo);
+    hi = nhi;
+}
+template <int CTRL>
+__device__ inline uint32_t dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+
+// ---- parameters -----------------------------------------------------------------------------------------------------------------
+// exact min / max of every off-diagonal pair table T[j][k] (65536 floats): range[(j*m + k)*2 + {0,1}]
+__global__ __launch_bounds__(256) void table_range_kernel(const float *__restrict__ T, int m, float *__restrict__ range, int *__restrict__ bad) {
+    const int jk = blockIdx.x, j = jk / m, k = jk % m;
+    if (j == k) return;
+    const float *p = T + (int64_t)jk * LSQ_H * LSQ_H;
+    float lo = __builtin_inff(), hi = -__builtin_inff();
+    bool nonfinite = false;
+    for (int e = threadIdx.x; e < LSQ_H * LSQ_H; e += 256) {
+        const float v = p[e];
+        nonfinite = nonfinite || !(fabsf(v) <= 3.0e38f);
+        lo = fminf(lo, v);
+        hi = fmaxf(hi, v);
+    }
+    __shared__ float slo[4], shi[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off, 64)); hi = fmaxf(hi, __shfl_xor(hi, off, 64)); }
+    if (__ballot(nonfinite) != 0ull && (threadIdx.x & 63) == 0) atomicExch(bad, 1);
+    if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        range[jk * 2 + 0] = fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3]));
+        range[jk * 2 + 1] = fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3]));
+    }
+}
+
+// One block: value ranges -> lsq_q16_params (in double).
+//   U_j: the minimum / maximum over a SAMPLE of the chunk's vectors (range-only GEMM pass, qrange = order-preserving keys), widened by 1/8 of
+//        the width on both sides.  Vectors the sample did not predict are flagged by the GEMM epilogue (non-finite values included) and
+//        take the f32 path, so the range only has to be good, not guaranteed.
+//   T_jk: exact range (table_range_kernel).
+// ok = 0 -- the whole chunk goes to the f32 walk -- when a pair table or the sample holds a non-finite value, or a range degenerates.
+__global__ __launch_bounds__(64) void q16_params_kernel(const float *__restrict__ trange, const int *__restrict__ bad, const unsigned *__restrict__ qrange,
+                                                        int m, lsq_q16_params *__restrict__ P) {
+    if (threadIdx.x != 0) return;
+    bool ok = (bad[0] == 0) && (qrange[2 * LSQ_MAX_M] == 0);
+    for (int j = 0; j < m; ++j) {
+        const unsigned kl = qrange[2 * j], kh = qrange[2 * j + 1];
+        lsq_q16_node nd;
+        for (int k = 0; k < LSQ_MAX_M; ++k) nd.loT[k] = 0.0f;
+        nd.loU = 0.0f; nd.invD = 0.0f; nd.D = 0.0f; nd.window = 65535; nd.lo_sum = 0.0; nd.slack = 0.0;
+        if (kl > kh) { ok = false; P->node[j] = nd; continue; }      // empty sample
+        const double sl = (double)__uint_as_float((kl & 0x80000000u) ? (kl ^ 0x80000000u) : ~kl);
+        const double sh = (double)__uint_as_float((kh & 0x80000000u) ? (kh ^ 0x80000000u) : ~kh);
+        const double mg = 0.125 * (sh - sl) + 1e-30 + fmax(fabs(sl), fabs(sh)) / 1048576.0;
+        double loU = sl - mg;
+        const double hiU = sh + mg;
+        nd.loU = (float)loU;
+        if ((double)nd.loU > loU) nd.loU = nextafterf(nd.loU, -__builtin_inff());
+        loU = (double)nd.loU;
+        double rsum = hiU - loU, smax = fmax(fabs(loU), fabs(hiU)), lo_sum = loU;
+        for (int k = 0; k < m; ++k) {
+            if (k == j) continue;
+            const double tl = (double)trange[(j * m + k) * 2], th = (double)trange[(j * m + k) * 2 + 1];
+            nd.loT[k] = (float)tl;
+            rsum += th - tl;
+            smax += fmax(fabs(tl), fabs(th));
+            lo_sum += tl;
+        }
+        const double D = rsum / 65500.0;
+        const double eps = (double)(m + 1) * smax * 5.9604644775390625e-8 * 2.0;      // f32 chain vs real sum: <= m roundings of <= 2^-24 smax (x2 margin)
+        const double slack = (double)m * (0.5 + 1.0 / 32.0) * D + eps + 65535.0 * D * 2.384185791015625e-7;      // + the f32 rounding of D and 1/D over 65535 levels
+        nd.D = (float)D;
+        nd.invD = (float)(1.0 / D);
+        nd.lo_sum = lo_sum;
+        nd.slack = slack;
+        const double w = 2.0 * slack / D;
+        nd.window = (w < 30000.0) ? (int)w + 1 : 65535;
+        if (!(D > 1e-30 && D < 1e30 && rsum == rsum && smax < 1e30)) ok = false;
+        if (!(nd.invD > 1e-30f && nd.invD < 1e30f)) ok = false;
+        P->node[j] = nd;
+    }
+    P->ok = ok ? 1 : 0;          // P->oor accumulates over the chunks of a call (zeroed by the host at its start)
+}
+
+// Tq[j][slice][kk][b][SLQ] (u16)  <-  rint((T[j][k(kk)][b][slice*SLQ ..] - loT[j][k]) * invD_j)      (one thread per 8 levels = 16 B)
+template <int SLQ>
+__global__ __launch_bounds__(256) void tables_to_q16_slices_kernel(const float *__restrict__ T, uint16_t *__restrict__ Tq, int m,
+                                                                   const lsq_q16_params *__restrict__ P) {
+    constexpr int NS = LSQ_H / SLQ, LPV = SLQ / 8;
+    const int64_t total = (int64_t)m * NS * (m - 1) * LSQ_H * LPV;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int qq = (int)(e % LPV);
+    int64_t r = e / LPV;
+    const int b = (int)(r % LSQ_H); r /= LSQ_H;
+    const int kk = (int)(r % (m - 1)); r /= (m - 1);
+    const int slice = (int)(r % NS);
+    const int j = (int)(r / NS);
+    const int k = kk + (kk >= j ? 1 : 0);
+    const float lo = P->node[j].loT[k], inv = P->node[j].invD;
+    const float *src = T + (((int64_t)j * m + k) * LSQ_H + b) * LSQ_H + slice * SLQ + qq * 8;
+    uint32_t w[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float q0 = fminf(fmaxf(rintf((src[2 * t] - lo) * inv), 0.0f), 65535.0f);
+        const float q1 = fminf(fmaxf(rintf((src[2 * t + 1] - lo) * inv), 0.0f), 65535.0f);
+        w[t] = (uint32_t)q0 | ((uint32_t)q1 << 16);
+    }
+    reinterpret_cast<u32x4 *>(Tq)[e] = (u32x4){w[0], w[1], w[2], w[3]};
+}
+
+// exact f32 conditioned value of candidate a of node j for vector i (canonical order, encode_icm.jl:84-101), from the f32 unaries
+template <int M, int RW>
+__device__ inline float q16_exact_value(const float *__restrict__ U, const float *__restrict__ T, int64_t n, int SLF, int j, int64_t i,
+                            const uint32_t (&rw)[RW], int a) {
+    float s = U[(int64_t)j * n * LSQ_H + ((int64_t)(a / SLF) * n + i) * SLF + (a % SLF)];
+    const float *Tj = T + (int64_t)j * M * LSQ_H * LSQ_H;
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+        if (k == j) continue;
+        const uint32_t bk = (rw[k >> 2] >> (8 * (k & 3))) & 0xffu;
+        s = s + Tj[((int64_t)(k * LSQ_H) + bk) * LSQ_H + a];
+    }
+    return s;
+}
+
+// Exact refinement of the block's ambiguous vectors (records arec[0 .. namb): {ci | a1 << 16 | a2 << 24, limit, record words}, written by
+// the decide phase): 16 lanes per vector, 4 vectors per wave at a time.  ONE dependent global round trip in the common case:
+//   * lane t recomputes the level sums of candidates [16 t, 16 t + 16) from the u16 planes and the u16 slice tables (the codes come from
+//     the LDS record, so the table loads do not wait for anything) and keeps the survivors: those within the window of the best key,
+//     which provably include the exact argmin and all its exact ties;
+//   * IN PARALLEL the exact f32 terms of the two best candidates a1, a2 (known from the keys) are loaded speculatively, one term per lane
+//     (lanes 0..7: a1, 8..15: a2; term 0 = unary, 1.. = table entries in ascending k) and summed in canonical order through shuffles;
+//   * survivors other than a1 / a2 (rare) take a second trip: q16_exact_value per survivor.
+// The lexicographic (value, index) minimum over everything evaluated is the argmin.  Kept lean: it shares the slice walk's 128 VGPRs.
+template <int M, int SLQ, int NT>
+__device__ inline int q16_refine(const float *__restrict__ U, const uint16_t *__restrict__ Uq, const uint16_t *__restrict__ Tq,
+                                 const float *__restrict__ T, uint8_t *__restrict__ rec, unsigned short *__restrict__ valid,
+                                 const uint8_t *__restrict__ ref_rec, const unsigned short *__restrict__ ref_valid, int64_t n, int j,
+                                 int64_t lo, const unsigned short *list, const uint32_t *arec, int namb, int SLF, int abl) {
+    constexpr int CS = (M <= 8) ? 8 : 16;
+    constexpr int RW = CS / 4;
+    constexpr int AREC = 2 + RW;
+    if (abl & 4) return 0;
+    constexpr int NS = LSQ_H / SLQ;
+    constexpr int TAB = (M - 1) * LSQ_H * (SLQ / 8);
+    constexpr int NW = NT / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane >> 4, t16 = lane & 15;
+    const int sl = (16 * t16) / SLQ, off = (16 * t16) % SLQ;              // slice / offset (in candidates) of this lane's 16 candidates
+    const uint16_t *__restrict__ Uqj = Uq + (int64_t)j * n * LSQ_H;
+    const uint16_t *__restrict__ Tqj = Tq + ((int64_t)j * NS + sl) * TAB * 8 + off;
+    const float *__restrict__ Tj = T + (int64_t)j * M * LSQ_H * LSQ_H;
+    const bool have_ref = ref_rec && ref_valid;
+    int nexact = 0;
+    for (int r0 = wave * 4; r0 < namb; r0 += NW * 4) {
+        const int r = r0 + grp;
+        const bool act = r < namb;
+        const uint32_t *ar = arec + (act ? r : r0) * AREC;
+        const uint32_t key = ar[0], limit = ar[1];
+        uint32_t rw[RW];
+#pragma unroll
+        for (int w2 = 0; w2 < RW; ++w2) rw[w2] = ar[2 + w2];
+        const int ci = (int)(key & 0xffffu), a1 = (int)((key >> 16) & 0xffu), a2 = (int)(key >> 24);
+        const int64_t i = lo + list[ci];
+        // ---- the one round trip: unary levels, table levels, bookkeeping (lane 0), speculative exact terms (one per lane)
+        const u32x4 *up = reinterpret_cast<const u32x4 *>(Uqj + ((int64_t)sl * n + ((abl & 2) ? (int64_t)0 : i)) * SLQ + off);
+        u32x4 s0 = (u32x4){0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, s1 = s0;
+        if (!(abl & 8)) { s0 = up[0]; s1 = up[1]; }
+        unsigned short vo = 0, rv = 0;
+        uint32_t rr[RW];
+#pragma unroll
+        for (int w2 = 0; w2 < RW; ++w2) rr[w2] = 0;
+        if (t16 == 0) {
+            if (valid) vo = valid[i];
+            if (have_ref) {
+#pragma unroll
+                for (int w2 = 0; w2 < RW; ++w2) rr[w2] = reinterpret_cast<const uint32_t *>(ref_rec + i * CS)[w2];
+                rv = ref_valid[i];
+            }
+        }
+        float term = 0.0f;                                                // lanes 0..M-1: terms of a1, lanes 8..8+M-1: terms of a2 (M <= 8); M > 8: slow path only
+        if (M <= 8) {
+            const int cand = (t16 < 8) ? a1 : a2, tt = t16 & 7;           // term tt: 0 = unary, q >= 1 = table of the q-th conditioning codebook
+            if (abl & 1) term = 1.0f;
+            else if (tt == 0) term = U[(int64_t)j * n * LSQ_H + ((int64_t)(cand / SLF) * n + ((abl & 16) ? lo : i)) * SLF + (cand % SLF)];
+            else if (tt < M) {
+                const int k = (tt - 1) + ((tt - 1) >= j ? 1 : 0);
+                const uint32_t bk = (rw[k >> 2] >> (8 * (k & 3))) & 0xffu;
+                term = Tj[((int64_t)(k * LSQ_H) + bk) * LSQ_H + cand];
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < M - 1; ++kk) {
+            if (abl & 8) break;
+            const int k = kk + (kk >= j ? 1 : 0);
+            const uint32_t bk = (rw[k >> 2] >> (8 * (k & 3))) & 0xffu;
+            const u32x4 *tp = reinterpret_cast<const u32x4 *>(Tqj + ((int64_t)kk * LSQ_H + bk) * SLQ);
+            const u32x4 b0 = tp[0], b1 = tp[1];
+            s0.x = pk_add_u16(s0.x, b0.x); s0.y = pk_add_u16(s0.y, b0.y); s0.z = pk_add_u16(s0.z, b0.z); s0.w = pk_add_u16(s0.w, b0.w);
+            s1.x = pk_add_u16(s1.x, b1.x); s1.y = pk_add_u16(s1.y, b1.y); s1.z = pk_add_u16(s1.z, b1.z); s1.w = pk_add_u16(s1.w, b1.w);
+        }
+        uint32_t mask = 0;                                                // bit p: candidate 16 t16 + p survives
+#define LSQ_SURV(W, B) mask |= (((W) & 0xffffu) <= limit ? 1u : 0u) << (B); mask |= (((W) >> 16) <= limit ? 1u : 0u) << ((B) + 1);
+        LSQ_SURV(s0.x, 0) LSQ_SURV(s0.y, 2) LSQ_SURV(s0.z, 4) LSQ_SURV(s0.w, 6) LSQ_SURV(s1.x, 8) LSQ_SURV(s1.y, 10) LSQ_SURV(s1.z, 12) LSQ_SURV(s1.w, 14)
+#undef LSQ_SURV
+        if (!act) mask = 0;
+        float bv = __builtin_inff();
+        int bi = 0x7fffffff;
+        if (M <= 8) {
+            // canonical sums of a1 (lanes 0..7 of the group) and a2 (lanes 8..15): ((u + t1) + t2) + ...  in ascending k
+            float e = __shfl(term, (lane & ~7), 64);
+#pragma unroll
+            for (int q = 1; q < M; ++q) e = e + __shfl(term, (lane & ~7) + q, 64);
+            const float e1 = __shfl(e, lane & ~15, 64), e2 = __shfl(e, (lane & ~15) + 8, 64);
+            // a1 and a2 are survivors by construction; drop them from the masks and rank them here
+            if (a1 / 16 == t16) mask &= ~(1u << (a1 % 16));
+            if (a2 / 16 == t16) mask &= ~(1u << (a2 % 16));
+            bv = e1; bi = a1;
+            if (e2 < bv || (e2 == bv && a2 < bi)) { bv = e2; bi = a2; }
+            if (act && t16 == 0) nexact += 2;
+        }
+        while (mask) {                                                    // third survivors (or every survivor when M > 8): one more trip
+            const int a = 16 * t16 + __builtin_ctz(mask);
+            mask &= mask - 1;
+            const float ev = q16_exact_value<M, RW>(U, T, n, SLF, j, i, rw, a);
+            ++nexact;
+            if (ev < bv || (ev == bv && a < bi)) { bv = ev; bi = a; }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 16);
+            const int oi = __shfl_xor(bi, o, 16);
+            if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (act && t16 == 0) {                                            // apply_node_result, its loads done above
+            const uint8_t c8 = (uint8_t)bi;
+            const uint8_t old = (uint8_t)(rw[j >> 2] >> (8 * (j & 3)));
+            rec[i * CS + j] = c8;
+            if (valid) {
+                unsigned short vm = (c8 != old) ? (unsigned short)(1u << j) : (unsigned short)(vo | (1u << j));
+                if (have_ref) {
+                    bool same = true;
+#pragma unroll
+                    for (int w2 = 0; w2 < RW; ++w2) {
+                        uint32_t mine = rw[w2];
+                        if (w2 == (j >> 2)) mine = (mine & ~(0xffu << (8 * (j & 3)))) | ((uint32_t)c8 << (8 * (j & 3)));
+                        same = same && (mine == rr[w2]);
+                    }
+                    if (same) vm = (unsigned short)(vm | rv);
+                }
+                valid[i] = vm;
+            }
+        }
+    }
+    return nexact;
+}
+
+// ---- the filtered walk ----------------------------------------------------------------------------------------------------------
+// Block / pass / node structure, compaction of the active vectors, light blocks and the validity bookkeeping are those of
+// icm_walk_kernel; the slice walk runs on 16-bit levels (slices of SLQ = 32 candidates for m <= 8, 16 above: the same 64 / 32-byte
+// pieces and the same LDS table footprint as the f32 walk, half as many slices).
+template <int M, int SLQ, int DEPTH, int NT>
+__global__ __launch_bounds__(NT) void icm_walkq_kernel(const float *__restrict__ U, const uint16_t *__restrict__ Uq, const uint16_t *__restrict__ Tq,
+                                                       const float *__restrict__ T, uint8_t *__restrict__ rec, unsigned short *__restrict__ valid,
+                                                       int64_t n, const WalkNodes nodes, int per_pass, int use_skip, int direct_max,
+                                                       unsigned long long *__restrict__ active_total,
+                                                       const uint8_t *__restrict__ ref_rec, const unsigned short *__restrict__ ref_valid,
+                                                       const lsq_q16_params *__restrict__ P, int SLF, const unsigned short *__restrict__ qflag, int abl) {
+    constexpr int CS = (M <= 8) ? 8 : 16;
+    constexpr int NS = LSQ_H / SLQ;
+    constexpr int LPV = SLQ / 8;                         // lanes per vector: 8 levels (16 B) per lane
+    constexpr int VPW = 64 / LPV;
+    constexpr int CW = (M - 1 + 3) / 4;
+    constexpr int RW = CS / 4;
+    constexpr int TAB = (M - 1) * LSQ_H * LPV;           // 16-byte entries of one slice table
+    constexpr int PP = LSQ_WALK_PP(M, SLQ / 2);          // same LDS budget as the f32 walk with slices of SLQ / 2 floats
+    if (P->ok == 0) return;                              // non-finite / degenerate bounds: icm_walk_kernel (enqueued next) does this launch's work
+#ifdef LSQ_TUNING
+    unsigned long long *dbgp = nullptr;
+    if (g_walkq_dbg) {
+        __shared__ unsigned dbg_slot_s;
+        if (threadIdx.x == 0) dbg_slot_s = (blockIdx.x == 0) ? atomicAdd(&g_walkq_dbg_slot, 1u) : 0u;
+        __syncthreads();
+        // only block 0 knows the slot; other blocks use the launch's slot through a second counter-free trick: they record nothing
+        if (blockIdx.x == 0 && dbg_slot_s < 4096) dbgp = g_walkq_dbg + (size_t)dbg_slot_s * 24;
+    }
+    DBG_STAMP(0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_walkq_dbg_cur = dbgp;
+#endif
+    extern __shared__ u32x4 lds_walkq[];
+    u32x4 *tab = lds_walkq;
+    uint32_t *bestA = reinterpret_cast<uint32_t *>(lds_walkq + TAB);                           // [PP] smallest key (Q << 16 | candidate)
+    uint32_t *bestB = bestA + PP;                                                              // [PP] second smallest key
+    unsigned short *list = reinterpret_cast<unsigned short *>(bestB + PP);                     // [PP] active local indices
+    __shared__ int wave_tot[16];
+    __shared__ int nact_s;
+    __shared__ int redo_s;
+    __shared__ int f32_s;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int v = lane / LPV, q = lane % LPV;
+    constexpr int NW = NT / 64;
+    constexpr int EPT = 4096 / NT;
+    constexpr int step = NW * VPW;
+    const int LPF = SLF / 4;                             // f32 unary planes (light blocks, exact refinement): slices of SLF floats
+
+    struct Item { u32x4 u; uint32_t r[RW]; };
+
+    auto walk_slices = [&](const int j, const int64_t lo, const int nact, const bool dense) {
+#ifndef LSQ_TUNING
+        unsigned long long *dbgp = nullptr; (void)dbgp;
+#endif
+        const uint16_t *__restrict__ Uqj = Uq + (int64_t)j * n * LSQ_H;
+        const uint16_t *__restrict__ Tqj = Tq + (int64_t)j * NS * TAB * 8;
+        uint32_t sel[CW > 0 ? CW : 1];
+#pragma unroll
+        for (int w = 0; w < CW; ++w) {
+            uint32_t sv = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int kk = 4 * w + t;
+                const int k = kk + (kk >= j ? 1 : 0);
+                sv |= (uint32_t)((kk < M - 1 ? k - 4 * w : 0) & 7) << (8 * t);
+            }
+            sel[w] = sv;
+        }
+        constexpr int NST = (TAB + NT - 1) / NT;
+        u32x4 nxt[NST > 0 ? NST : 1];
+        auto prefetch_tab = [&](int sl) {
+            const u32x4 *src = reinterpret_cast<const u32x4 *>(Tqj) + (int64_t)sl * TAB;
+#pragma unroll
+            for (int r = 0; r < NST; ++r) {
+                const int e = (int)threadIdx.x + r * NT;
+                nxt[r] = (e < TAB) ? src[e] : (u32x4){0u, 0u, 0u, 0u};
+            }
+        };
+        prefetch_tab(0);
+        const int ipw = (wave * VPW < nact) ? (nact - wave * VPW + step - 1) / step : 0;
+        int ls = 0, lit = 0;
+        auto load_next = [&](Item &it) {
+            int ci = wave * VPW + lit * step + v;
+            ci = ci < nact ? ci : nact - 1;
+            const int lsc = ls < NS ? ls : NS - 1;
+            uint32_t li = (uint32_t)ci;
+            if (!dense) li = list[ci];
+            const char *ub = reinterpret_cast<const char *>(Uqj + ((int64_t)lsc * n + lo) * SLQ);
+            const char *rb = reinterpret_cast<const char *>(rec + lo * CS);
+            const uint32_t uo = li * (uint32_t)(SLQ * 2) + (uint32_t)q * 16u;
+            it.u = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(ub + uo));
+            const uint32_t *rp = reinterpret_cast<const uint32_t *>(rb + li * (uint32_t)CS);
+#pragma unroll
+            for (int w = 0; w < RW; ++w) it.r[w] = rp[w];
+            if (++lit >= ipw) { lit = 0; ++ls; }
+        };
+        auto compute = [&](const Item &cur, int slice, int c0) {
+            u32x4 s = cur.u;
+#pragma unroll
+            for (int w = 0; w < CW; ++w) {
+                const uint32_t hiw = (w + 1 < RW) ? cur.r[w + 1] : 0u;
+                const uint32_t cw = __builtin_amdgcn_perm(hiw, cur.r[w], sel[w]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int kk = 4 * w + t;
+                    if (kk < M - 1) {
+                        uint32_t code;
+                        if (t == 0) asm("v_and_b32 %0, 0xff, %1" : "=v"(code) : "v"(cw));
+                        else code = (cw >> (8 * t)) & 0xffu;
+                        const u32x4 row = tab[(kk * LSQ_H + code) * LPV + q];
+                        s.x = pk_add_u16(s.x, row.x); s.y = pk_add_u16(s.y, row.y);      // levels add exactly: the sum of the m levels fits 16 bits
+                        s.z = pk_add_u16(s.z, row.z); s.w = pk_add_u16(s.w, row.w);
+                    }
+                }
+            }
+            // keys (Q << 16 | candidate): two smallest of the lane's 8, then of the vector's LPV lanes
+            const uint32_t base = (uint32_t)(SLQ * slice) + 8u * (uint32_t)q;
+            uint32_t k0 = (s.x << 16) | base, k1 = (s.x & 0xffff0000u) | (base + 1u);
+            uint32_t k2 = (s.y << 16) | (base + 2u), k3 = (s.y & 0xffff0000u) | (base + 3u);
+            uint32_t k4 = (s.z << 16) | (base + 4u), k5 = (s.z & 0xffff0000u) | (base + 5u);
+            uint32_t k6 = (s.w << 16) | (base + 6u), k7 = (s.w & 0xffff0000u) | (base + 7u);
+            uint32_t l0 = umin(k0, k1), h0 = umax(k0, k1), l1 = umin(k2, k3), h1 = umax(k2, k3);
+            uint32_t l2 = umin(k4, k5), h2 = umax(k4, k5), l3 = umin(k6, k7), h3 = umax(k6, k7);
+            top2_merge(l0, h0, l1, h1);
+            top2_merge(l2, h2, l3, h3);
+            top2_merge(l0, h0, l2, h2);
+            if (LPV >= 2) top2_merge(l0, h0, dpp_u32<DPP_XOR1>(l0), dpp_u32<DPP_XOR1>(h0));
+            if (LPV >= 4) top2_merge(l0, h0, dpp_u32<DPP_XOR2>(l0), dpp_u32<DPP_XOR2>(h0));
+            if ((q == 0) & (c0 + v < nact)) {
+                const uint32_t old = atomicMin(&bestA[c0 + v], l0);      // returns the previous minimum: the larger of the two is a runner-up
+                atomicMin(&bestB[c0 + v], umin(umax(old, l0), h0));
+            }
+        };
+        Item buf[DEPTH];
+#pragma unroll
+        for (int e = 0; e < DEPTH; ++e) load_next(buf[e]);
+        int phase = 0;
+        for (int slice = 0; slice < NS; ++slice) {
+            __syncthreads();
+#ifdef LSQ_TUNING
+            if (slice < 8) DBG_STAMP(3 + slice);
+#endif
+#pragma unroll
+            for (int r = 0; r < NST; ++r) {
+                const int e = (int)threadIdx.x + r * NT;
+                if (e < TAB) tab[e] = nxt[r];
+            }
+            __syncthreads();
+            if (slice + 1 < NS) prefetch_tab(slice + 1);
+            int c0 = wave * VPW, t = 0;
+            auto run = [&](auto P_) {
+                constexpr int PH = decltype(P_)::value;
+                for (; t + DEPTH <= ipw; t += DEPTH) {
+#pragma unroll
+                    for (int e = 0; e < DEPTH; ++e) {
+                        compute(buf[(PH + e) % DEPTH], slice, c0); load_next(buf[(PH + e) % DEPTH]); c0 += step;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < DEPTH - 1; ++e)
+                    if (t < ipw) {
+                        compute(buf[(PH + e) % DEPTH], slice, c0); load_next(buf[(PH + e) % DEPTH]); c0 += step;
+                        ++t; phase = (PH + e + 1) % DEPTH;
+                    }
+            };
+            bool ran = false;
+            auto try_phase = [&](auto P_) {
+                if constexpr (decltype(P_)::value < DEPTH) {
+                    if (!ran && phase == decltype(P_)::value) { run(P_); ran = true; }
+                }
+            };
+            try_phase(std::integral_constant<int, 0>{}); try_phase(std::integral_constant<int, 1>{});
+            try_phase(std::integral_constant<int, 2>{}); try_phase(std::integral_constant<int, 3>{});
+        }
+        __syncthreads();
+    };
+
+    // one wave per vector, everything in f32: the light-block routine of icm_walk_kernel (also the last resort of the filter)
+    auto full_f32 = [&](const int j, const int64_t i) {
+        const float *__restrict__ Usj = U + (int64_t)j * n * LSQ_H;
+        const float *__restrict__ Tj = T + (int64_t)j * M * LSQ_H * LSQ_H;
+        const CodeRec cr = load_rec<CS>(rec, i);
+        f32x4 s = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(Usj + ((int64_t)(lane / LPF) * n + i) * SLF) + (lane % LPF));
+        f32x4 c[M > 1 ? M - 1 : 1];
+#pragma unroll
+        for (int kk = 0; kk < M - 1; ++kk) {
+            const int k = kk + (kk >= j ? 1 : 0);
+            c[kk] = reinterpret_cast<const f32x4 *>(Tj + ((int64_t)(k * LSQ_H) + cr.get(k)) * LSQ_H)[lane];
+        }
+#pragma unroll
+        for (int kk = 0; kk < M - 1; ++kk) s = s + c[kk];
+        const uint32_t code = (uint32_t)wave_first_argmin(s, lane);
+        if (lane == 0) apply_node_result<CS>(rec, valid, i, j, (unsigned long long)code, ref_rec, ref_valid);
+    };
+
+    const int64_t npass = (n + per_pass - 1) / per_pass;
+    for (int64_t pass = blockIdx.x; pass < npass; pass += gridDim.x) {
+        const int64_t lo = pass * per_pass;
+        const int64_t hi = (lo + per_pass < n) ? lo + per_pass : n;
+        const int cnt = (int)(hi - lo);
+        for (int nu = 0; nu < nodes.count; ++nu) {
+            const int j = nodes.j[nu];
+            {
+                const int base = (int)threadIdx.x * EPT;
+                int f[EPT], c = 0;
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) {
+                    const int idx = base + e;
+                    f[e] = 0;
+                    if (idx < cnt) f[e] = (!use_skip) || !((valid[lo + idx] >> j) & 1);
+                    c += f[e];
+                }
+                int inc = c;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int t = __shfl_up(inc, off, 64);
+                    if (lane >= off) inc += t;
+                }
+                if (lane == 63) wave_tot[wave] = inc;
+                __syncthreads();
+                int wbase = 0;
+                for (int w2 = 0; w2 < wave; ++w2) wbase += wave_tot[w2];
+                int pos = wbase + inc - c;
+#pragma unroll
+                for (int e = 0; e < EPT; ++e)
+                    if (f[e]) list[pos++] = (unsigned short)(base + e);
+                if (threadIdx.x == NT - 1) { nact_s = wbase + inc; redo_s = 0; f32_s = 0; }
+                __syncthreads();
+            }
+            const int nact = nact_s;
+            DBG_STAMP(1);
+            if (nact == 0) { __syncthreads(); continue; }
+            if (threadIdx.x == 0 && active_total) {        // [0] node updates recomputed, [2] light / [3] filtered block-node-updates
+                atomicAdd(active_total, (unsigned long long)nact);
+                atomicAdd(active_total + (nact <= direct_max ? 2 : 3), 1ull);
+                atomicAdd(active_total + 4 + ((nodes.pos0 + nu) & (LSQ_WALK_TRACE - 1)), (unsigned long long)nact);
+            }
+            if (nact <= direct_max) {                      // light block: full f32 gathers from L2, no staging
+                for (int ci = wave; ci < nact; ci += NW) full_f32(j, lo + __builtin_amdgcn_readfirstlane((int)list[ci]));
+                __syncthreads();
+                continue;
+            }
+            for (int ci = threadIdx.x; ci < nact; ci += NT) { bestA[ci] = 0xffffffffu; bestB[ci] = 0xffffffffu; }
+            DBG_STAMP(2);
+            walk_slices(j, lo, nact, nact == cnt);
+            DBG_STAMP(11);
+            // ---- decide.  second - best > window: the best key is the exact argmin.  Otherwise the vector is AMBIGUOUS: every
+            // candidate whose level sum lies within the window of the best (the "survivors": they provably include the exact
+            // argmin and all its exact ties) is evaluated exactly below.
+            const lsq_q16_node &nd = P->node[j];
+            const int window = nd.window;
+            constexpr int EPD = (PP + NT - 1) / NT;                // vectors per thread
+            constexpr int AREC = 2 + RW;                           // words of an ambiguous-vector record: {ci | a1 << 16 | a2 << 24, limit, record words}
+            constexpr int ACAP = (PP * 4) / (AREC * 4);            // records that fit bestB's storage
+            {
+                int64_t vi[EPD];
+                uint32_t vcode[EPD], vkey[EPD], vlim[EPD];
+                bool von[EPD], vamb[EPD], vf32[EPD];
+#pragma unroll
+                for (int e = 0; e < EPD; ++e) {
+                    const int ci = (int)threadIdx.x + e * NT;
+                    von[e] = false; vamb[e] = false; vf32[e] = false; vi[e] = lo; vcode[e] = 0; vkey[e] = 0; vlim[e] = 0;
+                    if (ci < nact) {
+                        const uint32_t kA = bestA[ci], kB = bestB[ci];
+                        vi[e] = lo + list[ci];
+                        vcode[e] = kA & 0xffffu;
+                        vkey[e] = (uint32_t)ci | ((kA & 0xffu) << 16) | ((kB & 0xffu) << 24);
+                        vlim[e] = (kA >> 16) + (uint32_t)window;
+                        vf32[e] = (qflag[vi[e]] >> j) & 1;             // a unary of this node fell outside the sampled level range: its levels mean nothing
+                        vamb[e] = !vf32[e] && ((int)(kB >> 16) - (int)(kA >> 16) <= window);
+                        von[e] = !vamb[e] && !vf32[e];
+                    }
+                }
+                // every load of the thread's vectors before its first store (one global round trip); ambiguous vectors only need their record
+                uint32_t rw[EPD][RW], rr[EPD][RW];
+                unsigned short vo[EPD], rv[EPD];
+                const bool have_ref = ref_rec && ref_valid;
+#pragma unroll
+                for (int e = 0; e < EPD; ++e) {
+                    vo[e] = 0; rv[e] = 0;
+#pragma unroll
+                    for (int w2 = 0; w2 < RW; ++w2) { rw[e][w2] = 0; rr[e][w2] = 0; }
+                    if (von[e] || vamb[e]) {
+#pragma unroll
+                        for (int w2 = 0; w2 < RW; ++w2) rw[e][w2] = reinterpret_cast<const uint32_t *>(rec + vi[e] * CS)[w2];
+                    }
+                    if (von[e]) {
+                        if (valid) vo[e] = valid[vi[e]];
+                        if (have_ref) {
+#pragma unroll
+                            for (int w2 = 0; w2 < RW; ++w2) rr[e][w2] = reinterpret_cast<const uint32_t *>(ref_rec + vi[e] * CS)[w2];
+                            rv[e] = ref_valid[vi[e]];
+                        }
+                    }
+                }
+                __syncthreads();                                       // every bestA[] / bestB[] has been read: their storage is reused below
+                uint32_t *arec = bestB;                                // ambiguous-vector records
+                unsigned short *f32l = reinterpret_cast<unsigned short *>(bestA);      // vectors for the f32 path
+#pragma unroll
+                for (int e = 0; e < EPD; ++e) {
+                    if (von[e]) {
+                        const uint8_t c8 = (uint8_t)vcode[e];
+                        const uint8_t old = (uint8_t)(rw[e][j >> 2] >> (8 * (j & 3)));
+                        rec[vi[e] * CS + j] = c8;
+                        if (valid) {
+                            unsigned short vm = (c8 != old) ? (unsigned short)(1u << j) : (unsigned short)(vo[e] | (1u << j));
+                            if (have_ref) {
+                                bool same = true;
+#pragma unroll
+                                for (int w2 = 0; w2 < RW; ++w2) {
+                                    uint32_t mine = rw[e][w2];
+                                    if (w2 == (j >> 2)) mine = (mine & ~(0xffu << (8 * (j & 3)))) | ((uint32_t)c8 << (8 * (j & 3)));
+                                    same = same && (mine == rr[e][w2]);
+                                }
+                                if (same) vm = (unsigned short)(vm | rv[e]);
+                            }
+                            valid[vi[e]] = vm;
+                        }
+                    }
+                    bool tof32 = vf32[e];
+                    if (vamb[e]) {
+                        const int slot = atomicAdd(&redo_s, 1);
+                        if (slot < ACAP) {
+                            arec[slot * AREC] = vkey[e];
+                            arec[slot * AREC + 1] = vlim[e];
+#pragma unroll
+                            for (int w2 = 0; w2 < RW; ++w2) arec[slot * AREC + 2 + w2] = rw[e][w2];
+                        } else tof32 = true;                           // more ambiguous vectors than records (degenerate data): full f32 for the rest
+                    }
+                    if (tof32) f32l[atomicAdd(&f32_s, 1)] = (unsigned short)(vkey[e] & 0xffffu);
+                }
+            }
+            __syncthreads();
+            DBG_STAMP(12);
+            // ---- exact refinement of the ambiguous vectors
+            const int namb = redo_s < ACAP ? redo_s : ACAP;
+            int nexact = q16_refine<M, SLQ, NT>(U, Uq, Tq, T, rec, valid, ref_rec, ref_valid, n, j, lo, list, bestB, namb, SLF, abl);
+            {   // vectors outside the sampled level range: one wave each, in full f32
+                const unsigned short *f32l = reinterpret_cast<const unsigned short *>(bestA);
+                const int nf32 = f32_s;
+                for (int r = wave; r < nf32; r += NW) full_f32(j, lo + list[__builtin_amdgcn_readfirstlane((int)f32l[r])]);
+                if (threadIdx.x == 0 && active_total && nf32) atomicAdd(active_total + 4 + LSQ_WALK_TRACE + 2, (unsigned long long)nf32);
+            }
+            if (active_total) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) nexact += __shfl_xor(nexact, o, 64);
+                if (lane == 0 && nexact) atomicAdd(active_total + 4 + LSQ_WALK_TRACE + 1, (unsigned long long)nexact);
+                if (threadIdx.x == 0 && namb) atomicAdd(active_total + 4 + LSQ_WALK_TRACE, (unsigned long long)namb);
+            }
+            __syncthreads();
+            DBG_STAMP(13);
+#ifdef LSQ_TUNING
+            if (dbgp && threadIdx.x == 0) { dbgp[14] = (unsigned long long)nact; dbgp[15] = (unsigned long long)namb; }
+#endif
+        }
+    }
+}
+
+}  // namespace
+
+#ifdef LSQ_TUNING
+// tools only: device buffer of 4096 x 16 u64 that block 0 of every icm_walkq_kernel launch fills with phase timestamps (wall_clock64)
+extern "C" __attribute__((visibility("default"))) int lsq_tuning_set_walkq_debug(void *buf) {
+    unsigned zero = 0;
+    LSQ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_walkq_dbg), &buf, sizeof(buf)));
+    LSQ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_walkq_dbg_slot), &zero, sizeof(zero)));
+    return LSQ_OK;
+}
+#endif
+
+int lsq_q16_slice_width(int m) { return 2 * lsq_walk_slice_width(m); }      // candidates per 16-bit slice: the same bytes per piece as the f32 walk
+
+int lsq_launch_q16_prepare(hipStream_t s, const float *X, int64_t n, int d, const float *K, const float *sci, const float *T, int m, uint16_t *Tq,
+                           int *bad, float *trange, unsigned *qrange, unsigned short *qflag, lsq_q16_params *P, int tables_changed) {
+    // bad[0]: a non-finite pair table (per call)
+    if (tables_changed) {
+        LSQ_HIP(hipMemsetAsync(bad, 0, sizeof(int), s));
+        if (m > 1) hipLaunchKernelGGL(table_range_kernel, dim3((unsigned)(m * m)), dim3(256), 0, s, T, m, trange, bad);
+    }
+    // sampled range of the unaries: about 16 384 vectors (every rts-th panel of 128 consecutive ones) through the range-only GEMM pass
+    LSQ_HIP(hipMemsetAsync(qrange, 0, sizeof(unsigned) * (2 * LSQ_MAX_M + 1), s));
+    for (int j = 0; j < m; ++j) LSQ_HIP(hipMemsetAsync(qrange + 2 * j, 0xff, sizeof(unsigned), s));      // min slots start at the largest key
+    if (n > 0) {
+        const int rts = n > 16384 ? (int)(n / 16384) : 1;
+        LSQ_TRY(lsq_launch_chain_gemm(s, X, K, sci, -2.0f, n, m * LSQ_H, d, LSQ_H, 0, 0, nullptr, 0, n, 0, nullptr, 0, nullptr, 0, nullptr, qrange, rts));
+        LSQ_HIP(hipMemsetAsync(qflag, 0, sizeof(unsigned short) * (size_t)((n + 1) & ~(int64_t)1), s));
+    }
+    hipLaunchKernelGGL(q16_params_kernel, dim3(1), dim3(64), 0, s, trange, bad, qrange, m, P);
+    if (m > 1) {
+        const int slq = lsq_q16_slice_width(m);
+        const int64_t total = (int64_t)m * (LSQ_H / slq) * (m - 1) * LSQ_H * (slq / 8);
+        const unsigned grid = (unsigned)((total + 255) / 256);
+        if (slq == 32) hipLaunchKernelGGL(tables_to_q16_slices_kernel<32>, dim3(grid), dim3(256), 0, s, T, Tq, m, P);
+        else hipLaunchKernelGGL(tables_to_q16_slices_kernel<16>, dim3(grid), dim3(256), 0, s, T, Tq, m, P);
+    }
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}
+
+template <int M, int SLQ, int DEPTH, int NT>
+static int launch_walkq_t(hipStream_t s, const float *U, const uint16_t *Uq, const uint16_t *Tq, const float *T, uint8_t *rec, unsigned short *valid,
+                          int64_t n, const WalkNodes &nodes, int use_skip, unsigned long long *active_total, int light,
+                          const uint8_t *ref_rec, const unsigned short *ref_valid, const lsq_q16_params *P, const unsigned short *qflag) {
+    constexpr int TAB = (M - 1) * LSQ_H * (SLQ / 8);
+    constexpr int PP = LSQ_WALK_PP(M, SLQ / 2);
+    constexpr int LDS_BYTES = TAB * 16 + PP * 8 + PP * 2;                // slice table + two smallest keys + active list
+    static_assert(LDS_BYTES + 256 <= 160 * 1024, "slice table + keys must fit the 160 KiB LDS");
+    int per_pass = 1, npass = 1;
+    lsq_walk_geometry(n, M, &per_pass, &npass, nullptr);
+    const int direct_max = light >= 0 ? light : LSQ_KNOB("LSQ_WALK_DIRECT", 256);
+    const int skip = (use_skip && valid) ? 1 : 0;
+    static LdsOptIn optin;
+    LSQ_TRY(optin_lds(optin, &icm_walkq_kernel<M, SLQ, DEPTH, NT>, LDS_BYTES));
+    const unsigned grid = (unsigned)(npass < 256 ? npass : 256);
+    hipLaunchKernelGGL((icm_walkq_kernel<M, SLQ, DEPTH, NT>), dim3(grid), dim3(NT), LDS_BYTES, s, U, Uq, Tq, T, rec, valid, n, nodes, per_pass, skip,
+                       direct_max, active_total, skip ? ref_rec : nullptr, skip ? ref_valid : nullptr, P, lsq_walk_slice_width(M), qflag, LSQ_KNOB("LSQ_Q16_ABL", 0));
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}
+
+// the filtered counterpart of lsq_launch_icm_walk; does nothing on the device when P->ok == 0 (the caller enqueues the f32 walk, guarded the other way)
+int lsq_launch_icm_walkq(hipStream_t s, const float *U, const uint16_t *Uq, const uint16_t *Tq, const float *T, uint8_t *rec, unsigned short *valid,
+                         int64_t n, int m, const int32_t *order, int nnodes, int pos0, int use_skip, unsigned long long *active_total, int light,
+                         const uint8_t *ref_rec, const unsigned short *ref_valid, const lsq_q16_params *P, const unsigned short *qflag) {
+    if (n <= 0 || nnodes <= 0) return LSQ_OK;
+    if (m < 1 || m > LSQ_MAX_M) { lsq_set_error("m = %d out of range 1..16", m); return LSQ_EINVAL; }
+    for (int done = 0; done < nnodes; done += LSQ_WALK_MAX_NODES) {
+        WalkNodes nodes;
+        nodes.count = (nnodes - done < LSQ_WALK_MAX_NODES) ? nnodes - done : LSQ_WALK_MAX_NODES;
+        nodes.pos0 = pos0 + done;
+        for (int t = 0; t < nodes.count; ++t) {
+            const int j = order[done + t];
+            if (j < 0 || j >= m) { lsq_set_error("node %d out of range 0..%d", j, m - 1); return LSQ_EINVAL; }
+            nodes.j[t] = (uint8_t)j;
+        }
+#define LSQ_WQ_ARGS s, U, Uq, Tq, T, rec, valid, n, nodes, use_skip, active_total, light, ref_rec, ref_valid, P, qflag
+#define LSQ_WQ_CASE(MM, SLL, DD, NTT) case MM: LSQ_TRY((launch_walkq_t<MM, SLL, DD, NTT>(LSQ_WQ_ARGS))); break;
+        switch (m) {
+            LSQ_WQ_CASE(1, 32, 3, 1024) LSQ_WQ_CASE(2, 32, 3, 1024) LSQ_WQ_CASE(3, 32, 3, 1024) LSQ_WQ_CASE(4, 32, 3, 1024)
+            LSQ_WQ_CASE(5, 32, 3, 1024) LSQ_WQ_CASE(6, 32, 3, 1024) LSQ_WQ_CASE(7, 32, 3, 1024) LSQ_WQ_CASE(8, 32, 3, 1024)
+            LSQ_WQ_CASE(9, 16, 2, 1024) LSQ_WQ_CASE(10, 16, 2, 1024) LSQ_WQ_CASE(11, 16, 2, 1024) LSQ_WQ_CASE(12, 16, 2, 1024)
+            LSQ_WQ_CASE(13, 16, 2, 1024) LSQ_WQ_CASE(14, 16, 3, 512) LSQ_WQ_CASE(15, 16, 3, 512) LSQ_WQ_CASE(16, 16, 3, 512)
+        }
+#undef LSQ_WQ_CASE
+#undef LSQ_WQ_ARGS
+    }
+    return LSQ_OK;
+}

@@ -11,7 +11,7 @@
 #define LSQ_H 256          // candidates per codebook: one wave x float4 per lane
 #define LSQ_MAX_M 16
 #define LSQ_WALK_TRACE 64        // per-position (sweep * m + rank in the node order, mod 64) recomputed node updates
-#define LSQ_WALK_COUNTERS (4 + LSQ_WALK_TRACE)      // device counters of the walk kernel: [0] node updates recomputed, [1..3] staged / light / team block-node-updates, [4..] trace
+#define LSQ_WALK_COUNTERS (4 + LSQ_WALK_TRACE + 3)      // device counters of the walk kernel: [0] node updates recomputed, [1..3] staged / light / filtered block-node-updates, [4..67] trace, [68] node updates the filter refined exactly, [69] exact candidate evaluations of those, [70] node updates sent to f32 (outside the sampled level range)
 
 // ---- tuning knobs -------------------------------------------------------------------------
 // Tuning knobs (environment variables) exist in the tuning build only; the shipped library uses the measured defaults.
@@ -76,6 +76,24 @@ __host__ __device__ inline uint32_t lsq_rng_word(uint64_t seed, uint64_t idx, ui
 
 __host__ __device__ inline uint32_t lsq_mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 
+// ---- 16-bit filtered walk: quantisation parameters (device memory, one per resident chunk) ---------------------------------
+// Every term of a conditioned sum s[a] = U_j[a] + SUM_k T_jk[b_k][a] is ALSO held as a 16-bit level on ONE common step D_j per node:
+//   U level = rint((u - loU) / D),  table level = rint((t - loT[k]) / D),  so that the sum of the m levels Q[a] fits 16 bits and
+//   s[a] = lo_sum + D * Q[a] up to (0.5 + 2^-5) D per term.  Rigorous consequence (see icm_walkq_kernel): the exact fp32 argmin lies
+//   among the candidates with Q <= Qmin + window.  ok = 0 (non-finite or degenerate bounds) sends the chunk to the fp32 walk instead.
+struct lsq_q16_node {
+    float loU, invD, D;        // U levels cover [loU, loU + 65535 D): the sampled range of U_j widened by 1/8 (vectors outside are flagged); tables use their exact range
+    int window;                // levels
+    double lo_sum;             // loU + SUM_k loT[k]
+    double slack;              // bound of |fp32 conditioned sum - real sum| + per-term level error, in s units: m (0.5 + 2^-5) D + eps
+    float loT[LSQ_MAX_M];
+};
+struct lsq_q16_params {
+    int ok;
+    int oor;                   // values the GEMM epilogue found outside the sampled level range (their vectors are flagged and take the f32 path)
+    lsq_q16_node node[LSQ_MAX_M];
+};
+
 // ---- kernel launchers (implemented in the .hip files) ------------------------------------
 // All pointers are device pointers; all launch on `s` and return immediately.
 
@@ -84,9 +102,14 @@ __host__ __device__ inline uint32_t lsq_mulhi32(uint32_t a, uint32_t b) { return
 //          = (c / h) * plane_stride + ((c % h) / slice) * (Mtot * slice) + (c % h) % slice + r * slice   (slice-major)
 // Chain = k-ascending fmaf from +0.  The launch covers output rows [rbase, rbase + M) of a Mtot-row result (A points at
 // row rbase): row r above counts from rbase -- lets the caller build the unaries panel by panel under the H2D copies.
+// Optional second output (Dq != nullptr): the same values as 16-bit fixed-point levels in slice-major u16 planes of slice width slice_q,
+// Dq[(c / h) * Mtot * h + ((c % h) / slice_q) * Mtot * slice_q + r * slice_q + (c % h) % slice_q] = rint((v - qp->node[c / h].loU) * invD).
 int lsq_launch_chain_gemm(hipStream_t s, const float *A, const float *Bm, const float *addv, float alpha,
                           int64_t M, int N, int Kd, int h, int64_t plane_stride, int64_t row_stride, float *D, int slice,
-                          int64_t Mtot, int64_t rbase);
+                          int64_t Mtot, int64_t rbase, uint16_t *Dq = nullptr, int slice_q = 0, struct lsq_q16_params *qp = nullptr,
+                          int64_t lda = 0, unsigned short *qflag = nullptr, unsigned *qrange = nullptr, int rts = 1);
+// lda: row stride of A in floats (0 = Kd).  rts: range-only pass over every rts-th 128-row panel of A.  qflag [Mtot] u16 (Mtot even-padded): bit j raised when a value of
+// plane j fell outside the level range (Dq output).  qrange != nullptr: range-only pass, nothing stored; qrange[2 j], [2 j + 1] = min / max keys.
 // sci[r] = chain_t(Kb[r][t]^2)
 int lsq_launch_sqnorms(hipStream_t s, const float *Kb, int rows, int d, float *sci);
 
@@ -122,7 +145,18 @@ int lsq_launch_tables_to_slices(hipStream_t s, const float *T, float *Ts, int m,
 void lsq_walk_geometry(int64_t n, int m, int *per_pass, int *npass, int *pp_cap);      // segments of the walk kernel over n vectors
 int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const float *T, uint8_t *rec, unsigned short *valid, int64_t n, int m,
                         const int32_t *order, int nnodes, int pos0, int use_skip, unsigned long long *active_total, int ablation, int light,
-                        const uint8_t *ref_rec, const unsigned short *ref_valid);
+                        const uint8_t *ref_rec, const unsigned short *ref_valid, const int *idle_if_set = nullptr);
+// idle_if_set (optional, device): the launch does nothing when *idle_if_set != 0 (the filtered walk handled it)
+// 16-bit filtered walk (lsq_icmq.hip).  lsq_launch_q16_prepare: per chunk, after the pair tables and before the unary GEMM -- bounds,
+// parameters P and the 16-bit slice tables Tq [m][256/SLQ][m-1][256][SLQ]; tables_changed = 1 on the first chunk of a call.
+// bad (1 int), trange (2 m m floats), qrange (2 * 16 + 1 u32): scratch.  lsq_launch_icm_walkq: same contract as lsq_launch_icm_walk plus
+// Uq (the GEMM's u16 planes), Tq and P; on the device it does nothing when P->ok == 0.
+int lsq_q16_slice_width(int m);
+int lsq_launch_q16_prepare(hipStream_t s, const float *X, int64_t n, int d, const float *K, const float *sci, const float *T, int m, uint16_t *Tq,
+                           int *bad, float *trange, unsigned *qrange, unsigned short *qflag, lsq_q16_params *P, int tables_changed);
+int lsq_launch_icm_walkq(hipStream_t s, const float *U, const uint16_t *Uq, const uint16_t *Tq, const float *T, uint8_t *rec, unsigned short *valid,
+                         int64_t n, int m, const int32_t *order, int nnodes, int pos0, int use_skip, unsigned long long *active_total, int light,
+                         const uint8_t *ref_rec, const unsigned short *ref_valid, const lsq_q16_params *P, const unsigned short *qflag);
 // ref_rec / ref_valid (optional, read-only): the vectors' current records and their validity masks; a candidate that becomes
 // equal to its current record inherits those bits (exact: validity depends on the code tuple only)
 // light: blocks with <= light active vectors gather table columns from L2 instead of staging slices (-1 = default 256)

@@ -1,5 +1,7 @@
-// lsq_wave.h -- wave64 cross-lane helpers shared by the ICM kernels (gfx950 only; not a public header).
+// lsq_wave.h -- wave64 cross-lane helpers and the pieces shared by the ICM walk kernels (gfx950 only; not a public header).
 #pragma once
+
+#include <mutex>
 
 #include "lsq_internal.h"
 
@@ -85,5 +87,122 @@ __device__ inline int wave_first_argmin(f32x4 s, int lane) {
     (void)lane;
     return best;
 }
+
+// vectors per block pass of the LDS-walk kernel: table + 10 B per vector must fit the 160 KiB LDS
+constexpr int lsq_walk_pp(int M, int SL) {
+    const int avail = 160 * 1024 - 256 - (M - 1) * LSQ_H * (SL / 4) * 16;      // bytes left beside the slice table
+    const int pp = avail / 10 / 64 * 64;
+    return pp > 4096 ? 4096 : pp;                                             // 4096 up to m = 14 (SL = 8), 4032 at m = 16
+}
+#define LSQ_WALK_PP(M, SL) lsq_walk_pp(M, SL)
+
+// Validity is a property of the code tuple alone ("code j is the first argmin of node j given the other codes").  When the
+// candidate tuple, after node j took `code`, equals the vector's CURRENT tuple (the state the ILS iteration started from, whose
+// validity bits were established earlier and are read-only during the sweeps), everything known about that tuple holds for
+// the candidate too: its bits are OR-ed in.  A vector that has fallen back to a known fixed point stops being recomputed at
+// once instead of being re-verified for another sweep.  Exact: only true statements about the same tuple are imported.
+template <int RW>
+__device__ inline unsigned short known_valid(const uint32_t (&rw)[RW], int j, uint8_t code, const uint8_t *ref, const unsigned short *refv) {
+    if (!ref || !refv) return 0;
+    bool same = true;
+#pragma unroll
+    for (int w = 0; w < RW; ++w) {
+        uint32_t mine = rw[w];
+        if (w == (j >> 2)) mine = (mine & ~(0xffu << (8 * (j & 3)))) | ((uint32_t)code << (8 * (j & 3)));
+        same = same && (mine == reinterpret_cast<const uint32_t *>(ref)[w]);
+    }
+    return same ? *refv : (unsigned short)0;
+}
+
+// Result of a node update for vector i: code j <- the index part of the packed minimum key; validity bookkeeping (exact skip):
+// a changed code invalidates every other node, an unchanged one confirms node j; what is known about the vector's current
+// state is imported when the candidate tuple equals it (known_valid).
+template <int CS>
+__device__ inline void apply_node_result(uint8_t *__restrict__ rec, unsigned short *__restrict__ valid, int64_t i, int j, unsigned long long key,
+                                         const uint8_t *__restrict__ ref_rec, const unsigned short *__restrict__ ref_valid) {
+    constexpr int RW = CS / 4;
+    const unsigned bi = (unsigned)(key & 0xffffffffull);
+    const uint8_t code = (uint8_t)(bi > 255 ? 0 : bi);
+    uint32_t rw[RW];                                     // the record before the update (one aligned load instead of a byte load)
+#pragma unroll
+    for (int w2 = 0; w2 < RW; ++w2) rw[w2] = reinterpret_cast<const uint32_t *>(rec + i * CS)[w2];
+    const uint8_t old = (uint8_t)(rw[j >> 2] >> (8 * (j & 3)));
+    rec[i * CS + j] = code;
+    if (valid) {
+        unsigned short vm = (code != old) ? (unsigned short)(1u << j) : (unsigned short)(valid[i] | (1u << j));
+        vm = (unsigned short)(vm | known_valid<RW>(rw, j, code, ref_rec ? ref_rec + i * CS : nullptr, ref_valid ? ref_valid + i : nullptr));
+        valid[i] = vm;
+    }
+}
+
+// The same bookkeeping for N vectors of one thread with ALL loads issued before the first store (one global round trip instead of N).
+template <int CS, int N>
+__device__ inline void apply_node_results(uint8_t *__restrict__ rec, unsigned short *__restrict__ valid, const int64_t (&idx)[N], const uint32_t (&code)[N],
+                                          const bool (&on)[N], int j, const uint8_t *__restrict__ ref_rec, const unsigned short *__restrict__ ref_valid) {
+    constexpr int RW = CS / 4;
+    uint32_t rw[N][RW], rr[N][RW];
+    unsigned short vo[N], rv[N];
+    const bool have_ref = ref_rec && ref_valid;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        vo[e] = 0; rv[e] = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < RW; ++w2) { rw[e][w2] = 0; rr[e][w2] = 0; }
+        if (on[e]) {
+#pragma unroll
+            for (int w2 = 0; w2 < RW; ++w2) rw[e][w2] = reinterpret_cast<const uint32_t *>(rec + idx[e] * CS)[w2];
+            if (valid) vo[e] = valid[idx[e]];
+            if (have_ref) {
+#pragma unroll
+                for (int w2 = 0; w2 < RW; ++w2) rr[e][w2] = reinterpret_cast<const uint32_t *>(ref_rec + idx[e] * CS)[w2];
+                rv[e] = ref_valid[idx[e]];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        if (!on[e]) continue;
+        const uint8_t c8 = (uint8_t)(code[e] > 255u ? 0u : code[e]);
+        const uint8_t old = (uint8_t)(rw[e][j >> 2] >> (8 * (j & 3)));
+        rec[idx[e] * CS + j] = c8;
+        if (valid) {
+            unsigned short vm = (c8 != old) ? (unsigned short)(1u << j) : (unsigned short)(vo[e] | (1u << j));
+            if (have_ref) {
+                bool same = true;
+#pragma unroll
+                for (int w2 = 0; w2 < RW; ++w2) {
+                    uint32_t mine = rw[e][w2];
+                    if (w2 == (j >> 2)) mine = (mine & ~(0xffu << (8 * (j & 3)))) | ((uint32_t)c8 << (8 * (j & 3)));
+                    same = same && (mine == rr[e][w2]);
+                }
+                if (same) vm = (unsigned short)(vm | rv[e]);
+            }
+            valid[idx[e]] = vm;
+        }
+    }
+}
+
+#define LSQ_WALK_MAX_NODES 64
+struct WalkNodes { int count; int pos0; uint8_t j[LSQ_WALK_MAX_NODES]; };      // kernel argument: the node updates of one launch, in order; pos0 = position of j[0] in the ILS iteration's node sequence (trace counters)
+
+
+// One-time, per-device opt-in to > 64 KiB of dynamic LDS for one kernel instantiation.  lsq_multi_* runs one host thread
+// per device through the launchers, so the "done" flags are guarded (unsynchronised function-local statics).
+struct LdsOptIn {
+    std::mutex mu;
+    bool done[64] = {};
+};
+template <class Kern>
+int optin_lds(LdsOptIn &st, Kern kernel, int bytes) {
+    int dev = 0;
+    LSQ_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(st.mu);
+    if (dev < 0 || dev >= 64 || !st.done[dev]) {
+        LSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        if (dev >= 0 && dev < 64) st.done[dev] = true;
+    }
+    return LSQ_OK;
+}
+
 
 }  // namespace

@@ -93,10 +93,11 @@ def test_skip_unchanged_is_exact(lsq, oracle):
     d, n, m, ils, J, npert, seed = 64, 9001, 8, [1, 3], 4, 4, 77
     X, K, B0 = make_problem(d, n, m, seed=seed)
     Bs_ref, objs_ref, st_ref = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, True, seed, want_stats=True)
-    for schedule in (4, 3):
+    for schedule in (6, 4, 3):
         counts = {}
         for skip in (1, 0):
             with lsq.Engine(0, schedule=schedule, skip=skip, profile=True) as eng:
+                eng.set_option("q16_min", 0)
                 Bs, objs = eng.encode_icm(X, B0, K, m, ils, J, npert, True, seed=seed)
                 counts[skip] = eng.timings()["icm_node_updates"]
             assert np.array_equal(Bs, Bs_ref), "schedule %d skip=%d: %d codes differ" % (schedule, skip, (Bs != Bs_ref).sum())
@@ -294,7 +295,7 @@ def test_full_size_properties(lsq):
     and invariance to sharding / chunking / schedule."""
     import torch
     n, d, m, ils, J, npert, seed = 1_000_000, 128, 8, [1, 3], 4, 4, 42
-    with lsq.Engine(0) as eng, lsq.Engine(0, chunk=300_000, schedule=2, tuning=True) as eng2:
+    with lsq.Engine(0) as eng, lsq.Engine(0, chunk=300_000, schedule=2, tuning=True) as eng2, lsq.Engine(0, schedule=4) as eng4:
         dX = eng.synth_data_u8_dev(1234, n, d)
         dB0 = eng.randinit_dev(7, n, m)
         dK = eng.synth_codebooks_dev(4321, m, d)
@@ -317,6 +318,13 @@ def test_full_size_properties(lsq):
         dBs2, sums2, _ = eng2.encode_icm_dev(dX, dB0, dK, m, ils, J, npert, True, seed=seed)
         assert torch.equal(dBs2, dBs)
         assert np.allclose(sums2, sums, rtol=1e-9)
+        # the default is the 16-bit filtered walk: the f32 walk must give the same codes, sums, counters and memoisation counts
+        tq = eng.timings()
+        dBs4, sums4, stats4 = eng4.encode_icm_dev(dX, dB0, dK, m, ils, J, npert, True, seed=seed)
+        t4 = eng4.timings()
+        assert torch.equal(dBs4, dBs) and np.array_equal(sums4, sums) and np.array_equal(stats4, stats)
+        assert tq["filtered_blocks"] > 0 and t4["filtered_blocks"] == 0 and t4["staged_blocks"] > 0
+        assert tq["icm_node_updates"] == t4["icm_node_updates"]
         h1 = 400_001
         a, sa, _ = eng.encode_icm_dev(dX[:h1].contiguous(), dB0[:h1].contiguous(), dK, m, ils, J, npert, True, seed=seed, global_offset=0)
         b, sb, _ = eng.encode_icm_dev(dX[h1:].contiguous(), dB0[h1:].contiguous(), dK, m, ils, J, npert, True, seed=seed, global_offset=h1)

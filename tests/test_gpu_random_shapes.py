@@ -47,14 +47,17 @@ def test_random_shape_matches_oracle(lsq, oracle, case):
     X, K, B0 = make_problem(d, n, m, seed=100 + t, kind=kind)
     Bs_ref, objs_ref = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, randord, 7 * t + 1, global_offset=off)
     chunk = max(1, n // 3 + 1) if (mode != "natural" and t % 2 == 0) else None      # several resident chunks in half of the other cases
-    with lsq.Engine(0, chunk=chunk) as eng:
+    with lsq.Engine(0, chunk=chunk, schedule=(4 if t % 4 == 3 else 6)) as eng:       # 6 = the default (16-bit filtered walk), 4 = the f32 walk
         if mode == "forced":
             eng.set_option("light", 0)
+            eng.set_option("q16_min", 0)
         Bs, objs = eng.encode_icm(X, B0, K, m, ils, J, npert, randord, seed=7 * t + 1, global_offset=off)
         tm = eng.timings()
     assert np.array_equal(Bs, Bs_ref), "%d of %d codes differ" % ((Bs != Bs_ref).sum(), Bs.size)
     assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0)
     staged, light = tm["staged_blocks"] + tm["filtered_blocks"], tm["light_blocks"]
+    if J > 0 and mode != "default":
+        assert (tm["staged_blocks"] > 0) == (t % 4 == 3) and (tm["filtered_blocks"] > 0) == (t % 4 != 3), tm
     if J == 0:
         assert staged == 0 and light == 0                  # no sweeps: perturbation + accept only
     elif mode == "forced":

@@ -32,7 +32,7 @@ def test_forced_staging_every_m(lsq, oracle, m):
     d, n, ils, J, npert, seed = 16, 3000 + 7 * m, [1, 2], 3, min(4, m), 500 + m
     X, K, B0 = make_problem(d, n, m, seed=seed, kind="gauss")
     Bs_ref, objs_ref, st_ref = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, True, seed, want_stats=True)
-    for schedule in (4, 3):
+    for schedule in (6, 4, 3):
         for skip in (1, 0):
             for fb in (1, 0):
                 if schedule == 3 and (skip, fb) != (1, 1):
@@ -40,12 +40,14 @@ def test_forced_staging_every_m(lsq, oracle, m):
                 with lsq.Engine(0, schedule=schedule, skip=skip) as eng:
                     eng.set_option("light", 0)
                     eng.set_option("fallback", fb)
+                    eng.set_option("q16_min", 0)             # schedule 6: the 16-bit filtered walk even at this size
                     Bs, objs = eng.encode_icm(X, B0, K, m, ils, J, npert, True, seed=seed)
-                    staged, light, team = _paths(eng)
+                    staged, light, filt = _paths(eng)
                 tag = "m=%d schedule=%d skip=%d fallback=%d" % (m, schedule, skip, fb)
                 assert np.array_equal(Bs, Bs_ref), "%s: %d of %d codes differ" % (tag, (Bs != Bs_ref).sum(), Bs.size)
                 assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0), tag
-                assert light == 0 and staged + team > 0, "%s: staged=%d light=%d team=%d" % (tag, staged, light, team)
+                assert light == 0, "%s: staged=%d light=%d filtered=%d" % (tag, staged, light, filt)
+                assert (filt > 0 and staged == 0) if schedule == 6 else (staged > 0 and filt == 0), "%s: staged=%d filtered=%d" % (tag, staged, filt)
 
 
 @pytest.mark.parametrize("m,n", [(7, 90_000), (12, 80_000), (16, 80_000), (3, 120_000)])
@@ -56,12 +58,16 @@ def test_natural_staging_per_family(lsq, oracle, m, n):
     d, ils, J, npert, seed = 16, [2], 2 if m >= 12 else 3, min(4, m), 900 + m
     X, K, B0 = make_problem(d, n, m, seed=seed, kind="gauss")
     Bs_ref, objs_ref = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, True, seed)
-    with lsq.Engine(0) as eng:
-        Bs, objs = eng.encode_icm(X, B0, K, m, ils, J, npert, True, seed=seed)
-        staged, light, team = _paths(eng)
-    assert np.array_equal(Bs, Bs_ref), "%d of %d codes differ" % ((Bs != Bs_ref).sum(), Bs.size)
-    assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0)
-    assert staged + team > 0, "no block staged: staged=%d light=%d team=%d" % (staged, light, team)
+    for schedule in (6, 4):                        # 6 = the default: 16-bit filtered walk (n >= 65 536); 4 = the f32 walk
+        with lsq.Engine(0, schedule=schedule) as eng:
+            Bs, objs = eng.encode_icm(X, B0, K, m, ils, J, npert, True, seed=seed)
+            staged, light, filt = _paths(eng)
+            t = eng.timings()
+        assert np.array_equal(Bs, Bs_ref), "schedule %d: %d of %d codes differ" % (schedule, (Bs != Bs_ref).sum(), Bs.size)
+        assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0)
+        assert (filt if schedule == 6 else staged) > 0, "schedule %d: staged=%d light=%d filtered=%d" % (schedule, staged, light, filt)
+        if schedule == 6:
+            assert t["filter_refined"] < 0.25 * t["icm_node_updates"], t      # the filter decides most node updates on 16 bits
 
 
 def test_cfg1_exact_shape_chained_calls(lsq, oracle):
@@ -169,3 +175,72 @@ def test_cfg5_chunk_walk(lsq, oracle):
         assert torch.equal(dq[0], dBs[0][:q])
         assert abs(sq[0] / q - c.astype(np.float64).mean()) <= 1e-6 * sq[0] / q
 
+
+
+# ---- the 16-bit filter under adversarial value distributions -------------------------------------------------------------------
+def _filter_case(lsq, oracle, X, K, B0, m, ils, J, npert, seed, expect_filter=True):
+    Bs_ref, objs_ref, st_ref = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, True, seed, want_stats=True)
+    with lsq.Engine(0, schedule=6) as eng:
+        eng.set_option("q16_min", 0)
+        eng.set_option("light", 0)
+        Bs, objs = eng.encode_icm(X, B0, K, m, ils, J, npert, True, seed=seed)
+        t = eng.timings()
+    assert np.array_equal(Bs, Bs_ref), "%d of %d codes differ (%r)" % ((Bs != Bs_ref).sum(), Bs.size, t)
+    assert np.array_equal(np.isnan(objs), np.isnan(objs_ref)) and np.allclose(objs[~np.isnan(objs)], objs_ref[~np.isnan(objs)], rtol=1e-5, atol=0)
+    if expect_filter:
+        assert t["filtered_blocks"] > 0 and t["staged_blocks"] == 0, t
+    else:
+        assert t["filtered_blocks"] == 0 and t["staged_blocks"] > 0, t      # unusable bounds: the f32 walk did the work
+    return t
+
+
+def test_filter_exact_ties_and_near_ties(lsq, oracle):
+    """Duplicate codewords (exact ties: equal 16-bit sums AND equal f32 sums -> the lowest index must win through the exact
+    refinement), long runs of copies (third candidate in reach -> full-f32 redo), and near-duplicates (gaps far below the
+    filter's step)."""
+    d, n, m, seed = 32, 6000, 8, 55
+    X, K, B0 = make_problem(d, n, m, seed=seed, kind="gauss")
+    K = K.reshape(m, H, d).copy()
+    K[:, 1::2] = K[:, 0::2]                              # every codeword twice
+    K[1, 200:] = K[1, 3]                                 # a run of 56 copies
+    K[2, 1::2] = K[2, 0::2] * np.float32(1 + 1e-6)      # near-duplicates
+    K = K.reshape(m * H, d)
+    t = _filter_case(lsq, oracle, X, K, B0, m, [1, 3], 3, 4, seed)
+    assert t["filter_refined"] > 0 and t["filter_exact"] > 2 * t["filter_refined"], t      # some windows hold more than two candidates
+
+
+def test_filter_offsets_scales_and_single_codebook(lsq, oracle):
+    """Value ranges that stress the bound: data far from the origin (|s| >> range: the f32 rounding term dominates the window),
+    tiny and huge scales, m = 1 (no tables), m = 16."""
+    rng = np.random.default_rng(8)
+    for (d, n, m, shift, scale) in ((16, 5000, 8, 300.0, 1.0), (16, 5000, 8, 0.0, 1e-12), (16, 5000, 8, 0.0, 1e12), (24, 4000, 1, 5.0, 1.0), (16, 3000, 16, 50.0, 3.0)):
+        X = ((rng.standard_normal((n, d)) + shift) * scale).astype(np.float32)
+        K = (((rng.standard_normal((m * H, d)) + shift) * scale) / m).astype(np.float32)
+        B0 = oracle.randinit(5, n, m, H)
+        _filter_case(lsq, oracle, X, K, B0, m, [2], 2, min(4, m), 31 + m)
+
+
+def test_filter_steps_aside_for_nonfinite_data(lsq, oracle):
+    """NaN / Inf anywhere in the chunk or the codebooks: the bounds are unusable, the filtered launch idles and the f32 walk (with the
+    reference's strict-< scan semantics for NaN) does the work -- decided on the device, no host round trip."""
+    d, n, m, seed = 16, 5000, 8, 91
+    X, K, B0 = make_problem(d, n, m, seed=seed, kind="gauss")
+    X[17, 0] = np.nan
+    X[99, 3] = np.inf
+    _filter_case(lsq, oracle, X, K, B0, m, [2], 3, 4, seed, expect_filter=False)
+    X, K, B0 = make_problem(d, n, m, seed=seed, kind="gauss")
+    K = K.copy()
+    K[300, 2] = -np.inf
+    _filter_case(lsq, oracle, X, K, B0, m, [1], 2, 4, seed, expect_filter=False)
+    # and a finite chunk after one holding a NaN vector (per-chunk, per-vector decisions): the NaN vector's unaries are flagged by the GEMM
+    # epilogue and take the f32 path (or its whole chunk does, when the range sample caught it)
+    X, K, B0 = make_problem(d, n, m, seed=seed, kind="gauss")
+    X[10, 1] = np.nan
+    Bs_ref, _ = oracle.encode_icm(X, B0, K, m, H, [2], 3, 4, True, seed)
+    with lsq.Engine(0, schedule=6, chunk=2500) as eng:
+        eng.set_option("q16_min", 0)
+        eng.set_option("light", 0)
+        Bs, _ = eng.encode_icm(X, B0, K, m, [2], 3, 4, True, seed=seed)
+        t = eng.timings()
+    assert np.array_equal(Bs, Bs_ref)
+    assert t["filtered_blocks"] > 0 and (t["staged_blocks"] > 0 or t["filter_f32"] > 0), t

@@ -21,7 +21,7 @@ def walk_rows(path, value_col, name_col):
     rows = []
     with open(path, newline="") as fh:
         for row in csv.DictReader(fh):
-            if "icm_walk_kernel" in row[name_col]:
+            if ("icm_walkq_kernel" if os.environ.get("LSQ_SB_SCHEDULE", "3") == "6" else "icm_walk_kernel") in row[name_col]:
                 rows.append(row)
     return rows
 
@@ -38,7 +38,10 @@ def main():
             J = int(extra[i + 1])
         if a == "--ils":
             ils = int(extra[i + 1])
-    bench = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-extra-legs", "--schedule", "3", "--steps", "1", "--warmup", "0"] + extra
+    sched = os.environ.get("LSQ_SB_SCHEDULE", "3")          # 3: f32 walk, one launch per node; 6: filtered walk with option per_node
+    bench = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-extra-legs", "--schedule", sched, "--steps", "1", "--warmup", "0"] + extra
+    if sched == "6":
+        bench += ["--option", "per_node=1"]
     env = dict(os.environ, TMPDIR="/tmp")
     res = {"bench_args": " ".join(extra), "per_sweep": []}
     passes = {"time": ["--kernel-trace"], "fetch": ["--pmc", "FETCH_SIZE", "--kernel-trace"], "write": ["--pmc", "WRITE_SIZE", "--kernel-trace"]}
@@ -63,7 +66,7 @@ def main():
     for i, a in enumerate(extra):
         if a == "--vectors":
             n = int(extra[i + 1])
-    with lsq.Engine(0, profile=True, schedule=3) as eng:
+    with lsq.Engine(0, profile=True, schedule=int(sched)) as eng:
         dX = eng.synth_data_u8_dev(1234, n, 128)
         dB0 = eng.randinit_dev(7, n, m)
         dK = eng.synth_codebooks_dev(4321, m, 128)
@@ -80,7 +83,7 @@ def main():
         wr = sum(data["write"][i] for i in idx) / max(len(idx), 1) if len(data["write"]) == len(data["time"]) else None
         act = sum(res["active_fraction_per_position"][sw * m:(sw + 1) * m]) / m if (sw + 1) * m <= 64 else None
         res["per_sweep"].append({"sweep": sw + 1, "launches": len(idx), "avg_us": t, "active_fraction": act,
-                                 "algorithmic_bytes": (act * n * 1033.0) if act is not None else None, "fetch_bytes_raw": fe, "write_bytes": wr,
+                                 "algorithmic_bytes": (act * n * (521.0 if sched == "6" else 1033.0)) if act is not None else None, "fetch_bytes_raw": fe, "write_bytes": wr,
                                  "traffic_bytes_fetch_x2_plus_write": (2 * fe + wr) if fe is not None and wr is not None else None})
     res["launches_seen"] = {k: len(v) for k, v in data.items()}
     json.dump(res, open(os.path.join(out_dir, "sweep_breakdown.json"), "w"), indent=1)

@@ -1,0 +1,34 @@
+"""tools/walkq_phases.py [n] -- run ON THE GPU BOX with the tuning library.  Phase timestamps (wall_clock64, 100 MHz) of block 0 of
+every icm_walkq_kernel launch (option per_node = 1: one launch per node update): compaction / per-slice walk / decide / redo."""
+import ctypes as C, importlib, sys
+import numpy as np, torch
+sys.path.insert(0, '.')
+lsq = importlib.import_module("local-search-quantization_amd")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+per_node = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+L = lsq._lib.load(tuning=True)
+buf = torch.zeros((4096, 24), dtype=torch.int64, device="cuda")
+L.lsq_tuning_set_walkq_debug.restype = C.c_int
+L.lsq_tuning_set_walkq_debug.argtypes = [C.c_void_p]
+assert L.lsq_tuning_set_walkq_debug(buf.data_ptr()) == 0
+with lsq.Engine(0, schedule=6, tuning=True) as eng:
+    eng.set_option("per_node", per_node)
+    dX = eng.synth_data_u8_dev(1234, n, 128); dB0 = eng.randinit_dev(7, n, 8); dK = eng.synth_codebooks_dev(4321, 8, 128)
+    eng.encode_icm_dev(dX, dB0, dK, 8, [2], 4, 4, True, seed=42)
+torch.cuda.synchronize()
+t = buf.cpu().numpy()
+rows = t[(t[:, 0] != 0)]
+print("launches recorded", len(rows))
+names = ["start->compact", "compact->walk", "slice0", "slice1", "slice2", "slice3", "slice4", "slice5", "slice6", "slice7->walk end", "decide", "redo"]
+for li, r in enumerate(rows[:72]):
+    if r[13] == 0:
+        print(li, "no staged work (light or idle)", "nact", r[14]); continue
+    ts = [r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], r[10], r[11], r[12], r[13]]
+    d = [(ts[i + 1] - ts[i]) / 100.0 for i in range(len(ts) - 1)]       # us at 100 MHz
+    st = [int(r[k]) for k in range(16, 21)]
+    rf = [(st[k + 1] - st[k]) / 100.0 if st[k] and st[k + 1] else -1 for k in range(4)]
+    if st[0] and st[4]:
+        rf[3] = (st[4] - st[0]) / 100.0          # whole q16_refine
+        rf[0] = (st[0] - int(r[12])) / 100.0     # from the end of the decide phase to the function entry
+    print("%3d nact %5d amb %3d total %7.1f us | compact %5.1f pre %5.1f | slices %s | decide %5.1f refine+ %5.1f [entry +%4.1f, .. %4.1f .. %4.1f, whole refine %4.1f]" %
+          (li, r[14], r[15], (ts[-1] - ts[0]) / 100.0, d[0], d[1], " ".join("%5.1f" % x for x in d[2:11]), d[11], d[12], rf[0], rf[1], rf[2], rf[3]))
