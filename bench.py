@@ -174,9 +174,11 @@ def pmc_traffic(lib_sha):
             continue
         if pmc.get("_build", {}).get("lib_sha16") != lib_sha:
             continue
-        wk = [k for k in pmc if k.startswith("icm_walk_kernel") and "FETCH_SIZE" in pmc[k] and "WRITE_SIZE" in pmc[k]]
+        wk = [k for k in pmc if k.startswith("icm_walk") and "FETCH_SIZE" in pmc[k] and "WRITE_SIZE" in pmc[k]]
         if not wk:
             continue
+        # the walk that did the work (its idle twin -- the f32 walk when the filtered one ran -- moves no bytes): largest total fetch
+        wk = [max(wk, key=lambda k: pmc[k]["FETCH_SIZE"]["mean_per_dispatch"] * pmc[k]["FETCH_SIZE"]["dispatches"])]
         # FETCH_SIZE / WRITE_SIZE are reported in KiB; FETCH_SIZE x 2 = the guide's gfx950 correction for wide streaming reads
         tot = sum((2.0 * pmc[k]["FETCH_SIZE"]["mean_per_dispatch"] * pmc[k]["FETCH_SIZE"]["dispatches"]
                    + pmc[k]["WRITE_SIZE"]["mean_per_dispatch"] * pmc[k]["WRITE_SIZE"]["dispatches"]) * 1024.0 for k in wk)
@@ -286,7 +288,10 @@ def main():
     launches = max(tm["icm_launches"], 1)
     avg_launch_s = tm["icm_ms"] * 1e-3 / launches
     nu_per_launch = tm["icm_node_updates"] / launches
-    hbm_bytes = nu_per_launch * (4 * h + cs + 1)      # M2 data-flow: U_j row (4h B) + code record read + 1 code byte, per RECOMPUTED node update
+    # which walk did the work: the 16-bit filtered one (u16 unary row: 2h B) or the f32 one (4h B); + code record read + 1 code byte
+    filtered = tm["filtered_blocks"] > tm["staged_blocks"]
+    bytes_nu = (2 * h if filtered else 4 * h) + cs + 1
+    hbm_bytes = nu_per_launch * bytes_nu              # M2 data-flow, per RECOMPUTED node update
     achieved = hbm_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
     mine = {"rank": rank, "device": dev_index, "vectors": n, "global_offset": goff, "ms_per_step": dt_local / args.steps * 1e3,
             "vectors_per_s": n * args.steps / dt_local, "hbm_frac": achieved / HBM_PEAK_GBS, "icm_ms_per_step": tm["icm_ms"] / args.steps}
@@ -297,28 +302,33 @@ def main():
 
     if rank == 0:
         value = n_total * args.steps / dt
-        table_bytes = nu_per_launch * (m - 1) * 4 * h        # (m-1) x 1 KiB of table columns per node update: LDS reads (or L2 gathers in light blocks)
+        table_bytes = nu_per_launch * (m - 1) * (2 if filtered else 4) * h      # (m-1) table rows per node update (u16 levels or f32): LDS reads (L2 gathers in light blocks)
         total_nu = n * args.ils * args.icmiter * m           # node updates one step resolves on this rank
         m1_bytes = n * (4 * d + 2 * m + 2 * m + 4 + 4 * m * h + 4 * m * h + 4 * d)      # SURVEY 8(d) model M1 per step
         step_s = dt / args.steps
         roof = {
-            "kernel": "icm_walk_kernel<%d,SL>" % m,
+            "kernel": ("icm_walkq_kernel<%d,SLQ> (16-bit filtered walk, exact f32 refinement)" if filtered else "icm_walk_kernel<%d,SL> (f32 walk)") % m,
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "frac_of_achievable_6300": achieved / HBM_ACHIEVABLE_GBS,
             "traffic": None,
             "avg_launch_us": avg_launch_s * 1e6, "launches": int(tm["icm_launches"]),
             "algorithmic_bytes_per_launch": hbm_bytes,
-            "bytes_per_node_update": 4 * h + cs + 1,
+            "bytes_per_node_update": bytes_nu,
             "node_updates_recomputed_per_launch": nu_per_launch,
             "recomputed_fraction": tm["icm_node_updates"] / max(total_nu * args.steps, 1),
-            "blocks": {"staged": int(tm["staged_blocks"]), "light": int(tm["light_blocks"]), "filtered": int(tm["filtered_blocks"])},
-            "data_flow": "M2 (SURVEY 8(d)): the unary row of a node is re-read from HBM at every recomputed node update; `achieved` counts only "
-                         "node updates that were actually recomputed (memoised ones move no bytes).  It is a fraction of the traffic this "
-                         "design chose to create, not of the compulsory bytes -- see m1_compulsory.",
+            "blocks": {"staged_f32": int(tm["staged_blocks"]), "light_f32": int(tm["light_blocks"]), "filtered_u16": int(tm["filtered_blocks"])},
+            "filter": {"ambiguous_node_updates": int(tm["filter_refined"]), "ambiguous_fraction": tm["filter_refined"] / max(tm["icm_node_updates"], 1),
+                       "exact_candidate_evaluations": int(tm["filter_exact"]), "out_of_sampled_range_node_updates": int(tm["filter_f32"]),
+                       "note": "node updates whose two best 16-bit level sums lie within the rigorous window are re-decided in exact f32 (every candidate inside "
+                               "the window); the others are decided by the level sums alone -- same codes as the f32 walk, bit for bit"},
+            "data_flow": "M2 (SURVEY 8(d)): the unary row of a node is re-read from HBM at every recomputed node update -- as 16-bit levels (512 B) by "
+                         "the filtered walk, as f32 (1 KiB) by the f32 walk; `achieved` counts only node updates that were actually recomputed (memoised "
+                         "ones move no bytes).  It is a fraction of the traffic this design chose to create, not of the compulsory bytes -- see "
+                         "m1_compulsory.  The filtered walk is bound by LDS bank conflicts of the table-row reads and VALU issue, not by HBM (DESIGN 4.2).",
             "gather": {"achieved": table_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0, "peak": LDS_PEAK_GBS, "unit": "GB/s",
                        "frac": (table_bytes / avg_launch_s / 1e9 / LDS_PEAK_GBS) if avg_launch_s > 0 else 0.0,
-                       "note": "(m-1) x 1 KiB of pair-table columns per recomputed node update, read from LDS-staged slices with ds_read_b128 "
-                               "(16 random 64-byte rows per wave read: ~2.1-way bank conflicts are intrinsic to the lookup); peak = guide's aggregate"},
+                       "note": "(m-1) pair-table rows per recomputed node update (512 B each as u16 levels, 1 KiB as f32), read from LDS-staged slices with "
+                               "ds_read_b128 (16 random 64-byte rows per wave read: ~2.1-way bank conflicts are intrinsic to the lookup); peak = guide's aggregate"},
             "m1_compulsory": {"bytes_per_step": m1_bytes, "achieved": m1_bytes / step_s / 1e9, "unit": "GB/s",
                               "frac": m1_bytes / step_s / 1e9 / HBM_PEAK_GBS,
                               "note": "SURVEY 8(d) model M1 (X once, codes in/out, unaries written once and read once, X re-read for the cost) / whole step time"},
