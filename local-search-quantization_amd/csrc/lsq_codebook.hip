@@ -25,10 +25,12 @@ struct CodeView {
     int m, cols;
 };
 
+// Euclidean norm with a double accumulator: at training scale (n ~ 1e5..1e6) a sequential Float32 sum loses sqrt(n) eps .. n eps, which
+// reaches the sqrt(eps) stopping tolerance (the reference's IterativeSolvers calls BLAS nrm2, which does not have that problem).
 inline float norm2(const std::vector<float> &v) {
-    float s = 0.0f;
-    for (float x : v) s += x * x;
-    return std::sqrt(s);
+    double s = 0.0;
+    for (float x : v) s += (double)x * (double)x;
+    return (float)std::sqrt(s);
 }
 
 // LSQR for one right-hand side b (length n); x (length cols) starts at 0.  Returns the iteration count.
@@ -36,14 +38,17 @@ int lsqr_one(const CodeView &A, const std::vector<float> &b, std::vector<float> 
     const int64_t n = A.n;
     const int m = A.m, cols = A.cols;
     std::fill(x.begin(), x.end(), 0.0f);
-    std::vector<float> u(b), v((size_t)cols, 0.0f), w, tmpm((size_t)n), tmpn((size_t)cols);
+    std::vector<float> u(b), v((size_t)cols, 0.0f), w, tmpm((size_t)n);
+    std::vector<double> tmpn((size_t)cols);                  // S' u: up to n / h addends per column -> accumulated in double
     const float ctol = conlim > 0 ? 1.0f / conlim : 0.0f;
     float Anorm = 0, Acond = 0, ddnorm = 0, res2 = 0, xnorm = 0, xxnorm = 0, z = 0, sn2 = 0, cs2 = -1;
     float beta = norm2(u), alpha = 0;
     if (beta > 0) {
         const float ib = 1.0f / beta;
         for (auto &e : u) e *= ib;
-        for (int64_t i = 0; i < n; ++i) { const float ui = u[(size_t)i]; const int32_t *c = A.col + i * m; for (int j = 0; j < m; ++j) v[(size_t)c[j]] += ui; }
+        std::fill(tmpn.begin(), tmpn.end(), 0.0);
+        for (int64_t i = 0; i < n; ++i) { const double ui = u[(size_t)i]; const int32_t *c = A.col + i * m; for (int j = 0; j < m; ++j) tmpn[(size_t)c[j]] += ui; }
+        for (int c = 0; c < cols; ++c) v[(size_t)c] = (float)tmpn[(size_t)c];
         alpha = norm2(v);
     }
     if (alpha > 0) { const float ia = 1.0f / alpha; for (auto &e : v) e *= ia; }
@@ -65,9 +70,9 @@ int lsqr_one(const CodeView &A, const std::vector<float> &b, std::vector<float> 
             for (auto &e : u) e *= ib;
             Anorm = std::sqrt(Anorm * Anorm + alpha * alpha + beta * beta);
             // v = S' u - beta v
-            std::fill(tmpn.begin(), tmpn.end(), 0.0f);
-            for (int64_t i = 0; i < n; ++i) { const float ui = u[(size_t)i]; const int32_t *c = A.col + i * m; for (int j = 0; j < m; ++j) tmpn[(size_t)c[j]] += ui; }
-            for (int c = 0; c < cols; ++c) v[(size_t)c] = -beta * v[(size_t)c] + tmpn[(size_t)c];
+            std::fill(tmpn.begin(), tmpn.end(), 0.0);
+            for (int64_t i = 0; i < n; ++i) { const double ui = u[(size_t)i]; const int32_t *c = A.col + i * m; for (int j = 0; j < m; ++j) tmpn[(size_t)c[j]] += ui; }
+            for (int c = 0; c < cols; ++c) v[(size_t)c] = (float)(-(double)beta * (double)v[(size_t)c] + tmpn[(size_t)c]);
             alpha = norm2(v);
             if (alpha > 0) { const float ia = 1.0f / alpha; for (auto &e : v) e *= ia; }
         }
@@ -81,15 +86,15 @@ int lsqr_one(const CodeView &A, const std::vector<float> &b, std::vector<float> 
         phibar = sn * phibar;
         const float tau = sn * phi;
         const float t1 = phi / rho, t2 = -theta / rho;
-        float dk2 = 0.0f;
+        double dk2 = 0.0;
         for (int c = 0; c < cols; ++c) {
             const float wc = w[(size_t)c];
             x[(size_t)c] += t1 * wc;
             const float wr = wc / rho;
-            dk2 += wr * wr;
+            dk2 += (double)wr * (double)wr;
             w[(size_t)c] = t2 * wc + v[(size_t)c];
         }
-        ddnorm += dk2;
+        ddnorm += (float)dk2;
         // norm estimates and the stopping rules of Paige & Saunders
         const float delta = sn2 * rho, gambar = -cs2 * rho, rhs = phi - delta * z, zbar = rhs / gambar;
         xnorm = std::sqrt(xxnorm + zbar * zbar);

@@ -92,3 +92,44 @@ def test_train_chainq_decreases_error(lsq):
         mask = np.ones(12, dtype=bool)
         mask[od[i]] = False
         assert np.all(C[i][mask] == 0)
+
+
+# ---- sanity oracles named by SURVEY 8(f)-4: sklearn k-means, numpy SVD Procrustes -------------------------------------------------
+def test_kmeans_objective_close_to_sklearn(lsq):
+    """The reference delegates to Clustering.jl's kmeans (un-pinned).  Sanity oracle: scikit-learn's Lloyd iterations on the same data
+    from the same number of centers -- the objectives of two correct k-means runs on well-clustered data agree within a few percent
+    (different seedings), and ours started FROM sklearn's centers must not get worse (Lloyd steps never increase the objective)."""
+    from importlib import import_module
+    from sklearn.cluster import KMeans
+    ini = import_module("local-search-quantization_amd.initializers")
+    X = clustered(8, 3000, k=16, seed=11, spread=0.2)
+    C, a, cost = ini.kmeans(X, 16, niter=30, seed=5)
+    km = KMeans(n_clusters=16, n_init=4, max_iter=100, random_state=0, algorithm="lloyd").fit(X.T.astype(np.float64))
+    ref = float(km.inertia_)
+    assert cost <= 1.25 * ref and ref <= 1.25 * cost, (cost, ref)
+    # one assignment step of ours on sklearn's converged centers reproduces sklearn's labels (nearest-center rule) and its inertia
+    lab, costs = ini._assign(km.cluster_centers_.T.astype(np.float32), X)
+    assert (lab == km.labels_).mean() > 0.999
+    assert abs(float(costs.sum()) - ref) <= 1e-3 * ref
+
+
+def test_procrustes_rotation_matches_numpy_svd(lsq):
+    """OPQ's rotation update (src/opq/OPQ.jl: SVD of X * CB') vs the textbook orthogonal-Procrustes solution from numpy's SVD:
+    R = U V' maximises trace(R' X CB'), is orthogonal, and no random orthogonal matrix does better."""
+    from importlib import import_module
+    ini = import_module("local-search-quantization_amd.initializers")
+    rng = np.random.default_rng(2)
+    d, n = 10, 500
+    X = rng.standard_normal((d, n)).astype(np.float32)
+    Q = np.linalg.qr(rng.standard_normal((d, d)))[0].astype(np.float32)
+    CB = (Q.T @ X + 0.05 * rng.standard_normal((d, n))).astype(np.float32)       # CB ~ R' X for a hidden rotation
+    R = ini._procrustes(X, CB)
+    U, _, Vt = np.linalg.svd(X.astype(np.float64) @ CB.astype(np.float64).T)
+    Rref = U @ Vt
+    assert np.allclose(R.T @ R, np.eye(d), atol=1e-4)
+    assert np.allclose(R, Rref, atol=1e-3)
+    err = np.linalg.norm(R.T @ X - CB)
+    for _ in range(5):
+        Rr = np.linalg.qr(rng.standard_normal((d, d)))[0]
+        assert err <= np.linalg.norm(Rr.T @ X - CB) + 1e-6
+    assert np.allclose(R, Q, atol=0.05)                                          # and it recovers the hidden rotation

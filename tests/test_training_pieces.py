@@ -37,6 +37,30 @@ def test_update_codebooks_matches_scipy_lsqr(lsq):
     assert np.linalg.norm(resid) <= 1.05 * np.linalg.norm(X - sum(c for c in [S @ Kref.T]).T)
 
 
+def test_update_codebooks_training_scale_matches_scipy(lsq):
+    """n = 120 000 (the reference trains on 1e4..1e5 vectors, README 64-66 / 171-177): the Float32 LSQR with double-accumulated norms and
+    products must still agree with scipy's double-precision LSQR of the same system (sequential Float32 sums lose
+    sqrt(n) eps .. n eps, the size of the sqrt(eps) stopping tolerance, at this scale)."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    rng = np.random.default_rng(3)
+    d, n, m = 4, 120_000, 4
+    X, B = _problem(rng, d, n, m, noise=0.05)
+    C = lsq.update_codebooks(X, B, H, nthreads=4)
+    K = np.concatenate(C, axis=1)
+    rows = np.tile(np.arange(n), m)
+    cols = np.concatenate([(B[j] - 1) + j * H for j in range(m)])
+    S = sp.csr_matrix((np.ones(n * m), (rows, cols)), shape=(n, m * H))
+    tol = float(np.sqrt(np.finfo(np.float32).eps))
+    Kref = np.stack([spl.lsqr(S, X[t].astype(np.float64), atol=tol, btol=tol)[0] for t in range(d)])
+    # S has a (m - 1)-dimensional null space (constant shifts between codebooks): compare what is determined -- the reconstruction
+    rec = (S @ K.T).T
+    rec_ref = (S @ Kref.T).T
+    assert np.linalg.norm(rec - rec_ref) <= 2e-4 * np.linalg.norm(rec_ref)
+    r0 = np.linalg.norm(X - rec_ref)
+    assert np.linalg.norm(X - rec) <= r0 * (1 + 1e-4)
+
+
 def test_update_codebooks_errors(lsq):
     X = np.zeros((4, 10), np.float32)
     B = np.ones((2, 10), np.int16)
