@@ -1,0 +1,108 @@
+"""Pins the oracle against the REFERENCE ITSELF when a maintainer has produced a fixture with tools/make_reference_fixture.jl (Julia 0.6
++ the reference checkout; neither exists in the build image, so without a fixture these tests SKIP WITH A MESSAGE and parity stays
+"unpinned", as DESIGN.md says).  The fixture holds the reference's own outputs of get_unaries / get_binaries / veccost and of one
+deterministic encode_icm_fully! call (npert = 0, randord = false: no random numbers).
+
+Comparison rules: the reference's GEMMs run in OpenBLAS, whose summation order differs from the oracle's k-ascending fmaf chain, so
+tables and costs are compared with a relative tolerance; codes are compared exactly on the vectors whose every argmin had a margin
+above the accumulated table error (the others are reported, not failed: both answers are correct roundings of a tie)."""
+import glob
+import os
+import struct
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIXTURES = sorted(glob.glob(os.path.join(HERE, "golden", "ref_*.bin")))
+H = 256
+
+
+def load_fixture(path):
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"LSQREF01", "not a reference fixture"
+    d, n, m, h, ncbi = struct.unpack("<5i", raw[8:28])
+    off = 28
+
+    def take(dtype, *shape):                       # Julia arrays are column-major
+        nonlocal off
+        cnt = int(np.prod(shape))
+        a = np.frombuffer(raw, dtype=dtype, count=cnt, offset=off).reshape(shape[::-1]).T
+        off += cnt * np.dtype(dtype).itemsize
+        return np.ascontiguousarray(a)
+
+    fx = {"d": d, "n": n, "m": m, "h": h}
+    fx["X"] = take(np.float32, d, n)                                   # (d, n)
+    fx["C"] = [take(np.float32, d, h) for _ in range(m)]               # (d, h) each
+    fx["B0"] = take(np.int16, m, n)
+    fx["unaries"] = [take(np.float32, h, n) for _ in range(m)]
+    fx["binaries"] = [take(np.float32, h, h) for _ in range(ncbi)]
+    fx["cbi"] = take(np.int32, 2, ncbi)
+    fx["cost0"] = take(np.float32, n)
+    fx["B1"] = take(np.int16, m, n)
+    fx["cost1"] = take(np.float32, n)
+    assert off == len(raw)
+    return fx
+
+
+def test_fixture_loader_roundtrip(tmp_path):
+    """The loader itself (always runs): a file written in the generator's layout from numpy arrays loads back identically."""
+    rng = np.random.default_rng(0)
+    d, n, m, h = 3, 5, 2, 256
+    X = rng.standard_normal((d, n)).astype(np.float32)
+    C = [rng.standard_normal((d, h)).astype(np.float32) for _ in range(m)]
+    B0 = rng.integers(1, h + 1, size=(m, n)).astype(np.int16)
+    un = [rng.standard_normal((h, n)).astype(np.float32) for _ in range(m)]
+    bi = [rng.standard_normal((h, h)).astype(np.float32)]
+    cbi = np.array([[1], [2]], np.int32)
+    c0, c1 = rng.random(n).astype(np.float32), rng.random(n).astype(np.float32)
+    p = tmp_path / "ref_test.bin"
+    with open(p, "wb") as f:
+        f.write(b"LSQREF01" + struct.pack("<5i", d, n, m, h, 1))
+        for a in [X] + C + [B0] + un + bi + [cbi, c0, B0, c1]:
+            f.write(np.asfortranarray(a).tobytes(order="F"))
+    fx = load_fixture(str(p))
+    assert np.array_equal(fx["X"], X) and np.array_equal(fx["C"][1], C[1]) and np.array_equal(fx["B0"], B0)
+    assert np.array_equal(fx["unaries"][1], un[1]) and np.array_equal(fx["binaries"][0], bi[0]) and np.array_equal(fx["cost1"], c1)
+
+
+@pytest.mark.skipif(not FIXTURES, reason="no tests/golden/ref_*.bin: the oracle is NOT pinned by the reference (generate one with "
+                                         "tools/make_reference_fixture.jl on a box with Julia 0.6 + the reference checkout)")
+@pytest.mark.parametrize("path", FIXTURES or ["<none>"], ids=lambda p: os.path.basename(p))
+def test_oracle_matches_reference_fixture(oracle, path):
+    fx = load_fixture(path)
+    d, n, m = fx["d"], fx["n"], fx["m"]
+    X = np.ascontiguousarray(fx["X"].T)                                              # (n, d) rows
+    K = np.ascontiguousarray(np.concatenate([c.T for c in fx["C"]], axis=0))          # (m*h, d) = hcat(C...) rows
+    B0 = np.ascontiguousarray(fx["B0"].T)                                             # (n, m)
+    # tables: BLAS order vs fmaf chain -> relative tolerance d * eps of the magnitudes involved
+    U = oracle.unaries(X, K, m, H)                                                    # (m, n, h)
+    scale = float(np.abs(U).max())
+    for j in range(m):
+        assert np.allclose(U[j], fx["unaries"][j].T, rtol=0, atol=4e-6 * d * scale), "get_unaries differs beyond summation-order error"
+    T = oracle.tables(K, m, H)                                                        # T[j,k,b,a] = 2 <c_ja, c_kb>
+    tscale = float(np.abs(T).max())
+    for idx in range(fx["cbi"].shape[1]):
+        i, j = int(fx["cbi"][0, idx]) - 1, int(fx["cbi"][1, idx]) - 1                 # binaries[idx][a, b] = 2 <c_i,a , c_j,b>
+        assert np.allclose(T[i, j].T, fx["binaries"][idx], rtol=0, atol=4e-6 * d * tscale), "get_binaries differs"
+    c0 = oracle.veccost(X, K, (B0 - 1).astype(np.uint8), H)
+    assert np.allclose(c0, fx["cost0"], rtol=1e-4), "veccost differs"
+    # the deterministic encode: 4 sweeps, natural order, no perturbation, NO accept test (encode_icm_fully! is the worker)
+    Bo = (B0 - 1).astype(np.uint8).copy()
+    margins = np.full(n, np.inf)
+    for sweep in range(4):
+        for j in range(m):
+            s = U[j].copy()
+            for k in range(m):
+                if k != j:
+                    s = s + T[j, k, Bo[:, k], :]
+            srt = np.partition(s, 1, axis=1)
+            margins = np.minimum(margins, srt[:, 1] - srt[:, 0])
+            Bo[:, j] = s.argmin(axis=1)
+    ref = fx["B1"].T.astype(np.int32) - 1
+    # worst-case difference between two summation orders of a d-term dot product: d * eps * magnitude; x4 safety, over the m terms of a sum
+    safe = margins > 4 * d * 1.2e-7 * (scale + m * tscale)
+    assert safe.mean() > 0.5, "fixture too degenerate to pin anything"
+    assert np.array_equal(Bo[safe], ref[safe]), "%d of %d safely-decided vectors differ from the reference" % ((Bo[safe] != ref[safe]).any(axis=1).sum(), safe.sum())
+    c1 = oracle.veccost(X, K, Bo, H)
+    assert np.allclose(c1[safe], fx["cost1"][safe], rtol=1e-4)
