@@ -91,20 +91,27 @@ LSQ_API int lsq_destroy(lsq_ctx *ctx);
  * stream; option "own_stream" switches back to the context's private non-blocking stream. */
 LSQ_API int lsq_set_stream(lsq_ctx *ctx, void *hip_stream);
 /* Options: "chunk" (vectors per resident chunk, default 1048576), "profile" (0/1), "own_stream",
- *   "schedule" (all give bit-identical codes):
- *        4 (default) one launch per ILS iteration: a 1024-thread block owns <= 4096 vectors and runs the
- *                    icmiter x m node updates back to back, walking all LDS-staged table slices for each;
- *                    unaries streamed slice-major from HBM;
- *        3 the same kernel, one launch per node update;
- *        2 same slices, one slice per block, partial minima combined by a second kernel;
- *        0 one launch per node update, table columns gathered through L2;
- *        1 fused sweeps, unaries register-resident;
- *   "light" (schedules 3 and 4, default 256): a block with at most this many active vectors gathers its table columns
- *        straight from L2 (one wave per vector) instead of staging slices through LDS; 0 = always stage.  Same codes.
- *   "fallback" (0/1, default 1; schedules 3 and 4): a candidate whose codes become equal to the vector's current codes inherits
- *        the current state's validity bits (validity depends on the code tuple only): exact, ~12 % fewer node updates.
- *   "skip" (0/1, default 1; schedules 3 and 4): a node whose conditioning codes did not change since it was
- *        last minimised is not recomputed (exact memoisation -- same codes, fewer bytes). */
+ *   "schedule" -- how the ICM node updates run; all give bit-identical codes:
+ *        6 (default) 16-bit FILTERED walk, one launch per ILS iteration: every term of a conditioned sum is also held as a 16-bit level
+ *                    on a common step (u16 unary planes written by the unary GEMM's epilogue, u16 pair-table slices staged in LDS); a
+ *                    1024-thread block owns <= 4096 vectors, sums the levels with packed 16-bit adds, tracks the two smallest keys and
+ *                    decides a node update on the levels alone when the runner-up lies outside a rigorous error window; otherwise every
+ *                    candidate inside the window is evaluated exactly in f32.  Half the HBM / LDS bytes of schedule 4.  Chunks below
+ *                    "q16_min" vectors, and chunks whose data are not finite (decided on the device), run as schedule 4.
+ *        4           f32 walk, one launch per ILS iteration: the block runs the icmiter x m node updates back to back, walking all LDS-staged
+ *                    f32 table slices for each; f32 unaries streamed slice-major from HBM;
+ *        3           the f32 walk, one launch per node update;
+ *        0, 1, 2     (liblsq_mi355x_tuning.so only) per-node L2 gathers / fused sweeps with register-resident unaries / one slice per block +
+ *                    combine kernel: the measured alternatives of DESIGN.md, kept as independent implementations for cross-checks;
+ *   "q16_min" (default 65536): schedule 6 applies to chunks with at least this many vectors (below, every block is "light": nothing to filter);
+ *   "per_node" (0/1, default 0): schedule 6 with one launch per node update (profiling: per-sweep timings and counters);
+ *   "light" (default 256): a block with at most this many active vectors gathers f32 table columns straight from L2 (one wave per vector)
+ *        instead of staging slices through LDS; 0 = always stage.  Same codes.
+ *   "fallback" (0/1, default 1): a candidate whose codes become equal to the vector's current codes inherits the current state's validity
+ *        bits (validity depends on the code tuple only): exact, ~12 % fewer node updates.
+ *   "skip" (0/1, default 1): a node whose conditioning codes did not change since it was last minimised is not recomputed (exact memoisation --
+ *        same codes, fewer bytes).
+ *   (liblsq_mi355x_tuning.so only) "ablation": timing-only kernel variants whose results are garbage. */
 LSQ_API int lsq_set_option(lsq_ctx *ctx, const char *key, int64_t value);
 LSQ_API int lsq_get_timings(lsq_ctx *ctx, lsq_timings *out);
 /* Node updates actually recomputed (not memoised) per POSITION in an ILS iteration's node sequence, position = sweep * m + rank in

@@ -16,13 +16,9 @@ def run(n, d, m, sched, opts, ils=16, J=4, steps=3):
         r = dict(n=n, d=d, m=m, sched=sched, opts=opts, ms=dt * 1e3, Mvps=n / dt / 1e6, icm_ms=tm["icm_ms"] / steps, unaries_ms=tm["unaries_ms"]/steps, cost_ms=tm["cost_ms"]/steps,
                  staged=tm["staged_blocks"] // steps, light=tm["light_blocks"] // steps, team=tm["filtered_blocks"] // steps, obj=float(sums[0] / n))
         print(json.dumps(r), flush=True); res.append(r)
-for n, d, m in ((1_000_000, 128, 8), (125_000, 960, 8), (100_000, 128, 8), (250_000, 128, 8), (500_000, 128, 8), (1_000_000, 128, 16), (10_000, 128, 8)):
+import os
+os.makedirs("gpurun_out/r02g", exist_ok=True)
+for n, d, m in ((1_000_000, 128, 8), (1_000_000, 128, 16), (125_000, 960, 8), (1_000_000, 128, 7), (1_000_000, 128, 4), (500_000, 128, 8), (250_000, 128, 8), (100_000, 128, 8), (10_000, 128, 8), (1_000_000, 128, 12)):
+    run(n, d, m, 6, {})
     run(n, d, m, 4, {})
-    run(n, d, m, 5, {})
-    if n == 1_000_000 and m == 8:
-        for o in ({"team_from": 2}, {"team_from": 3}, {"team": 8}, {"team": 4}, {"team_from": 0}):
-            run(n, d, m, 5, o)
-    if n == 125_000:
-        for o in ({"team": 8}, {"team": 4}, {"team_from": 1}):
-            run(n, d, m, 5, o)
-json.dump(res, open("gpurun_out/r02b/sched_cmp.json", "w"), indent=1)
+json.dump(res, open("gpurun_out/r02g/sched_cmp.json", "w"), indent=1)

@@ -1,5 +1,9 @@
 // tools/ubench_lds.hip -- which LDS row layout serves 16 random 64-byte rows per ds_read_b128 with the fewest bank-conflict cycles?
-// One 1024-thread block per CU (like icm_walk_kernel), 7 dependent-free ds_read_b128 per iteration, addresses from random codes.
+// One 1024-thread block per CU (like icm_walk_kernel / icm_walkq_kernel), 7 dependent-free ds_read_b128 per iteration, addresses from
+// random codes.  r02 repair (VERDICT r1 weak #4-iv): the conflict-free reference used loop-invariant addresses, so the compiler hoisted
+// its reads out of the loop and the leg "measured" 232 TB/s -- above the 256 B/clk/CU hardware limit.  Every pattern's address now
+// depends on the iteration, every loaded value feeds the result, and the kernel reports shader clocks (s_memtime) so that the rate can
+// be read as bytes per clock per CU against the guide's 256 B/clk/CU for ds_read_b128.
 // hipcc --offload-arch=gfx950 -O3 tools/ubench_lds.hip -o tools/bin/ubench_lds
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -16,7 +20,7 @@ __device__ inline unsigned addr_of(unsigned code, unsigned q, unsigned lane) {
         case 2: return code * 96u + q * 16u;                                   // padded to 96
         case 3: return code * 64u + ((q ^ ((code >> 2) & 3u)) * 16u);          // quads permuted by code bits
         case 4: return code * 32u + (q & 1u) * 16u + (q >> 1) * (8192u + 64u); // two half planes, second skewed by 64 bytes
-        case 5: return lane * 16u;                                             // conflict-free reference
+        case 5: return ((lane + code) & 63u) * 16u + ((code >> 6) & 3u) * 1024u;     // conflict-free reference: the 64 lanes cover one 1 KiB window (all 64 banks once), rotating with the iteration
         case 6: return (code & ~15u) * 64u + q * 16u;                          // few distinct rows (broadcast-heavy)
         case 7: return code * 16u + q * (4096u + 64u);                         // four quad planes, skewed by 64 bytes each
         default: return 0;
@@ -24,7 +28,7 @@ __device__ inline unsigned addr_of(unsigned code, unsigned q, unsigned lane) {
 }
 
 template <int PAT>
-__global__ __launch_bounds__(1024) void k(const unsigned char *codes, float *out, int iters) {
+__global__ __launch_bounds__(1024) void k(const unsigned char *codes, float *out, int iters, unsigned long long *clk) {
     extern __shared__ f32x4 lds[];
     for (int e = threadIdx.x; e < 7 * 2048; e += 1024) lds[e] = (f32x4){(float)e, 1.f, 2.f, 3.f};
     __syncthreads();
@@ -34,13 +38,18 @@ __global__ __launch_bounds__(1024) void k(const unsigned char *codes, float *out
     unsigned c[7];
     for (int t = 0; t < 7; ++t) c[t] = cp[t];
     const char *base = reinterpret_cast<const char *>(lds);
+    __syncthreads();
+    const unsigned long long t0 = clock64();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int t = 0; t < 7; ++t) {
-            const unsigned a = addr_of<PAT>((c[t] + (unsigned)it * 37u) & 255u, q, lane) + (unsigned)t * 22528u;   // 7 tables of 22 KiB
+            const unsigned code = (PAT == 5) ? (unsigned)(it * 7 + t) & 255u : (c[t] + (unsigned)it * 37u) & 255u;
+            const unsigned a = addr_of<PAT>(code, q, lane) + (unsigned)t * 22528u;   // 7 tables of 22 KiB
             acc = acc + *reinterpret_cast<const f32x4 *>(base + a);
         }
     }
+    __syncthreads();
+    if (threadIdx.x == 0 && clk) clk[blockIdx.x] = clock64() - t0;
     out[(size_t)blockIdx.x * 1024 + threadIdx.x] = acc.x + acc.y + acc.z + acc.w;
 }
 
@@ -49,13 +58,20 @@ static void run(const unsigned char *dc, float *dout, const char *name) {
     const int iters = 4000, lds_bytes = 160 * 1024 - 512;
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k<PAT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    hipLaunchKernelGGL(k<PAT>, dim3(256), dim3(1024), lds_bytes, 0, dc, dout, 10);
+    static unsigned long long *dclk = nullptr;
+    if (!dclk) CK(hipMalloc(&dclk, 256 * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(k<PAT>, dim3(256), dim3(1024), lds_bytes, 0, dc, dout, 10, nullptr);
     CK(hipEventRecord(a));
-    hipLaunchKernelGGL(k<PAT>, dim3(256), dim3(1024), lds_bytes, 0, dc, dout, iters);
+    hipLaunchKernelGGL(k<PAT>, dim3(256), dim3(1024), lds_bytes, 0, dc, dout, iters, dclk);
     CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b));
+    unsigned long long hclk[256];
+    CK(hipMemcpy(hclk, dclk, sizeof(hclk), hipMemcpyDeviceToHost));
+    double cyc = 0; for (int i = 0; i < 256; ++i) cyc += (double)hclk[i]; cyc /= 256.0;
     const double reads = 256.0 * 16 * iters * 7;             // wave-level ds_read_b128 per launch
-    printf("%-44s %8.3f ms  %6.2f ns per wave read per CU  %7.1f TB/s aggregate\n", name, ms, ms * 1e6 / (16.0 * iters * 7), reads * 1024 / (ms * 1e-3) / 1e12);
+    const double bytes_cu = 16.0 * iters * 7 * 1024.0;       // LDS bytes read per CU
+    printf("%-44s %8.3f ms  %6.2f ns per wave read per CU  %7.1f TB/s aggregate  %7.1f B per s_memtime tick per CU (%.0f ticks, %.1f MHz)\n", name, ms,
+           ms * 1e6 / (16.0 * iters * 7), reads * 1024 / (ms * 1e-3) / 1e12, bytes_cu / cyc, cyc, cyc / (ms * 1e3));
 }
 
 int main() {
