@@ -34,6 +34,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int BM = 128, BN = 128;
+// LDS row stride = BK + LSQ_GEMM_PAD floats.  A wave's MFMA operand read touches rows l31 = 0..31 at k = kk + lhi (lhi = 0, 1): bank =
+// (row * LD + lhi) mod 64.  LD = 17 maps rows 0..31 to 32 distinct banks but the lhi = 1 half lands on banks of the lhi = 0 half (17 r' + 1 ==
+// 17 r mod 64 has solutions): the 25 % SQ_LDS_BANK_CONFLICT of profiles/r01h.  LD = 18: 18 r mod 64 = 2 (9 r mod 32) covers the even banks once,
+// + lhi the odd ones: conflict-free for the reads (and 8-byte aligned rows for the staging stores).
+#ifndef LSQ_GEMM_PAD
+#define LSQ_GEMM_PAD 2
+#endif
 
 // One K chunk of a 128-row panel: global -> registers (tile_load), registers -> LDS (tile_store).  Split in two so
 // that the loads of chunk c+1 are in flight while the MFMAs of chunk c run (register double buffering).
@@ -68,7 +75,7 @@ __device__ inline void tile_load(const float *__restrict__ src, int64_t rows_tot
 
 template <bool VEC4, int BK>
 __device__ inline void tile_store(const TileRegs<VEC4, BK> &t, float scale, float *__restrict__ dst, int tid) {
-    constexpr int LD = BK + 1, Q4 = BK / 4, NE = BM * BK / 4 / 256;
+    constexpr int LD = BK + LSQ_GEMM_PAD, Q4 = BK / 4, NE = BM * BK / 4 / 256;
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         const int e = tid + i * 256;
@@ -92,9 +99,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                          int64_t Mtot, int64_t rbase, uint16_t *__restrict__ Dq, int slice_q,
                                                          lsq_q16_params *__restrict__ qp, int64_t lda, unsigned short *__restrict__ qflag,
                                                          unsigned *__restrict__ qrange, int rts) {
-    constexpr int LD = BK + 1;
-    __shared__ float As[2][BM * LD];
-    __shared__ float Bs[2][BN * LD];
+    constexpr int LD = BK + LSQ_GEMM_PAD;
+    __shared__ float smem[2 * BM * LD + 2 * BN * LD];      // A and B panels, double-buffered; reused by the u16 epilogue as a 128 x 128 level tile
+    float (*As)[BM * LD] = reinterpret_cast<float (*)[BM * LD]>(smem);
+    float (*Bs)[BN * LD] = reinterpret_cast<float (*)[BN * LD]>(smem + 2 * BM * LD);
 
     const int64_t b = blockIdx.x;
     const int xcd = (int)(b & 7);
@@ -151,6 +159,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
     float bmin = __builtin_inff(), bmax = -__builtin_inff();      // range-only pass: the block tile lies in ONE column plane (h is a multiple of 128)
     bool bnan = false;
+    constexpr int QLD = BN + 8;                                  // u16 level tile: 128 rows x (128 + 8) columns = 34 816 B <= the panels' 36 864 B
+    static_assert(Q16 != 1 || BM * QLD * 2 <= (int)sizeof(float) * (2 * BM * LD + 2 * BN * LD), "level tile must fit the panel storage");
+    uint16_t *qtile = reinterpret_cast<uint16_t *>(smem);        // free: the K loop ended with a barrier
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj) {
         const int c = col0 + wx * 64 + tj * 32 + l31;
@@ -164,13 +175,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                    : (int64_t)(c / h) * plane_stride + a;
         const int64_t rstride = slice ? (int64_t)slice : row_stride;
         float qlo = 0.f, qinv = 0.f;
-        int64_t qoff = 0;
         int noor = 0;
         const bool q16 = Q16 == 1 && qp->ok != 0;          // unusable bounds (non-finite data): the f32 walk handles the chunk, nothing to emit
         if (q16) {
             qlo = qp->node[c / h].loU;
             qinv = qp->node[c / h].invD;
-            qoff = (int64_t)(c / h) * (Mtot * (int64_t)h) + (int64_t)(a / slice_q) * (Mtot * slice_q) + (a % slice_q);
         }
         float vmin = __builtin_inff(), vmax = -__builtin_inff();
 #pragma unroll
@@ -186,15 +195,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     if (q16) {
                         const float qf = rintf((v - qlo) * qinv);
                         if (!(qf >= 0.0f && qf <= 65535.0f)) { atomicOr(reinterpret_cast<unsigned *>(qflag + ((rbase + row) & ~(int64_t)1)), (1u << (c / h)) << (16 * (int)((rbase + row) & 1))); ++noor; }
-                        const uint32_t q16v = (uint32_t)fminf(fmaxf(qf, 0.0f), 65535.0f);
-                        const uint32_t nb = (uint32_t)__shfl_down((int)q16v, 1, 64);          // the next candidate of the same row (same lhi half)
-                        if (!(l31 & 1)) *reinterpret_cast<uint32_t *>(Dq + qoff + (rbase + row) * slice_q) = q16v | (nb << 16);
+                        // levels go through an LDS tile so that they leave the chip as 16-byte stores (8 candidates of a row), not 2-byte ones
+                        qtile[(wy * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * QLD + wx * 64 + tj * 32 + l31] = (uint16_t)fminf(fmaxf(qf, 0.0f), 65535.0f);
                     }
                 }
             }
         }
         if (q16 && noor) atomicAdd(&qp->oor, noor);
         if (Q16 == 2) { bmin = fminf(bmin, vmin); bmax = fmaxf(bmax, vmax); bnan = bnan || !(vmin == vmin && vmax == vmax); }
+    }
+    if (Q16 == 1) {
+        if (qp->ok != 0) {                                 // block-uniform
+            __syncthreads();
+            const int plane = col0 / h, a0 = col0 % h;
+#pragma unroll
+            for (int i = 0; i < BM * BN / 8 / 256; ++i) {
+                const int e = tid + i * 256, rl = e / (BN / 8), ch = e % (BN / 8);
+                const int64_t row = row0 + rl;
+                const int a = a0 + 8 * ch;
+                if (row < M && col0 + 8 * ch < N)
+                    *reinterpret_cast<uint4 *>(Dq + (int64_t)plane * (Mtot * (int64_t)h) + ((int64_t)(a / slice_q) * Mtot + (rbase + row)) * slice_q + (a % slice_q)) =
+                        *reinterpret_cast<const uint4 *>(qtile + rl * QLD + 8 * ch);
+            }
+        }
     }
     if (Q16 == 2) {                                        // one pair of atomics per block (not per wave: they all hit the plane's two words)
         __shared__ float rmin[4], rmax[4];
