@@ -59,6 +59,9 @@ __global__ __launch_bounds__(NT) void icm_walk_kernel(const float *__restrict__ 
     unsigned short *list = reinterpret_cast<unsigned short *>(best64 + PP);                    // [PP] active local indices
     __shared__ int wave_tot[16];
     __shared__ int nact_s;
+    __shared__ unsigned stat_s[4 + LSQ_WALK_TRACE];      // per-block statistics, flushed once per launch (per-node device atomics stalled every node's first barrier)
+    for (int e = threadIdx.x; e < 4 + LSQ_WALK_TRACE; e += NT) stat_s[e] = 0u;
+    __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -253,10 +256,10 @@ __global__ __launch_bounds__(NT) void icm_walk_kernel(const float *__restrict__ 
         }
         const int nact = nact_s;
         if (nact == 0) { __syncthreads(); continue; }          // block-uniform (the barrier protects nact_s / wave_tot reuse)
-        if (threadIdx.x == 0 && active_total) {            // [0] node updates recomputed, [1] staged / [2] light block-node-updates ([3]: filtered walk)
-            atomicAdd(active_total, (unsigned long long)nact);
-            atomicAdd(active_total + (nact <= direct_max ? 2 : 1), 1ull);
-            atomicAdd(active_total + 4 + ((nodes.pos0 + nu) & (LSQ_WALK_TRACE - 1)), (unsigned long long)nact);
+        if (threadIdx.x == 0) {                            // [0] node updates recomputed, [1] staged / [2] light block-node-updates ([3]: filtered walk)
+            stat_s[0] += (unsigned)nact;
+            stat_s[nact <= direct_max ? 2 : 1] += 1u;
+            stat_s[4 + ((nodes.pos0 + nu) & (LSQ_WALK_TRACE - 1))] += (unsigned)nact;
         }
         if (nact <= direct_max) {
             // LIGHT block (few active vectors: small n, or a late sweep): staging the whole (m-1) x 256 KiB table through
@@ -311,6 +314,10 @@ __global__ __launch_bounds__(NT) void icm_walk_kernel(const float *__restrict__ 
         __syncthreads();
         }   // node updates
     }
+    __syncthreads();
+    if (active_total)
+        for (int e = threadIdx.x; e < 4 + LSQ_WALK_TRACE; e += NT)
+            if (stat_s[e]) atomicAdd(active_total + e, (unsigned long long)stat_s[e]);
 }
 
 // Ts[j][slice][kk][b][SL] <- T[j][k(kk)][b][slice*SL ..]   (one thread per float4)

@@ -348,6 +348,11 @@ __global__ __launch_bounds__(NT) void icm_walkq_kernel(const float *__restrict__
     __shared__ int nact_s;
     __shared__ int redo_s;
     __shared__ int f32_s;
+    // statistics are accumulated per block in LDS and flushed ONCE per launch: per-node device atomics from 256 blocks on the same few
+    // words sat in front of every node update's first barrier (5-9 us per node, profiles/r02j_walkq_phases.txt "pre")
+    __shared__ unsigned stat_s[LSQ_WALK_COUNTERS];
+    for (int e = threadIdx.x; e < LSQ_WALK_COUNTERS; e += NT) stat_s[e] = 0u;
+    __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -541,10 +546,10 @@ __global__ __launch_bounds__(NT) void icm_walkq_kernel(const float *__restrict__
             const int nact = nact_s;
             DBG_STAMP(1);
             if (nact == 0) { __syncthreads(); continue; }
-            if (threadIdx.x == 0 && active_total) {        // [0] node updates recomputed, [2] light / [3] filtered block-node-updates
-                atomicAdd(active_total, (unsigned long long)nact);
-                atomicAdd(active_total + (nact <= direct_max ? 2 : 3), 1ull);
-                atomicAdd(active_total + 4 + ((nodes.pos0 + nu) & (LSQ_WALK_TRACE - 1)), (unsigned long long)nact);
+            if (threadIdx.x == 0) {                        // [0] node updates recomputed, [2] light / [3] filtered block-node-updates
+                stat_s[0] += (unsigned)nact;
+                stat_s[nact <= direct_max ? 2 : 3] += 1u;
+                stat_s[4 + ((nodes.pos0 + nu) & (LSQ_WALK_TRACE - 1))] += (unsigned)nact;
             }
             if (nact <= direct_max) {                      // light block: full f32 gathers from L2, no staging
                 for (int ci = wave; ci < nact; ci += NW) full_f32(j, lo + __builtin_amdgcn_readfirstlane((int)list[ci]));
@@ -650,13 +655,13 @@ __global__ __launch_bounds__(NT) void icm_walkq_kernel(const float *__restrict__
                 const unsigned short *f32l = reinterpret_cast<const unsigned short *>(bestA);
                 const int nf32 = f32_s;
                 for (int r = wave; r < nf32; r += NW) full_f32(j, lo + list[__builtin_amdgcn_readfirstlane((int)f32l[r])]);
-                if (threadIdx.x == 0 && active_total && nf32) atomicAdd(active_total + 4 + LSQ_WALK_TRACE + 2, (unsigned long long)nf32);
+                if (threadIdx.x == 0 && nf32) atomicAdd(&stat_s[4 + LSQ_WALK_TRACE + 2], (unsigned)nf32);
             }
-            if (active_total) {
+            {
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) nexact += __shfl_xor(nexact, o, 64);
-                if (lane == 0 && nexact) atomicAdd(active_total + 4 + LSQ_WALK_TRACE + 1, (unsigned long long)nexact);
-                if (threadIdx.x == 0 && namb) atomicAdd(active_total + 4 + LSQ_WALK_TRACE, (unsigned long long)namb);
+                if (lane == 0 && nexact) atomicAdd(&stat_s[4 + LSQ_WALK_TRACE + 1], (unsigned)nexact);
+                if (threadIdx.x == 0 && namb) atomicAdd(&stat_s[4 + LSQ_WALK_TRACE], (unsigned)namb);
             }
             __syncthreads();
             DBG_STAMP(13);
@@ -665,6 +670,10 @@ __global__ __launch_bounds__(NT) void icm_walkq_kernel(const float *__restrict__
 #endif
         }
     }
+    __syncthreads();
+    if (active_total)
+        for (int e = threadIdx.x; e < LSQ_WALK_COUNTERS; e += NT)
+            if (stat_s[e]) atomicAdd(active_total + e, (unsigned long long)stat_s[e]);
 }
 
 }  // namespace

@@ -13,6 +13,8 @@ L.lsq_tuning_set_walkq_debug.argtypes = [C.c_void_p]
 assert L.lsq_tuning_set_walkq_debug(buf.data_ptr()) == 0
 with lsq.Engine(0, schedule=6, tuning=True) as eng:
     eng.set_option("per_node", per_node)
+    eng.set_option("q16_min", 0)
+    eng.set_option("light", 0)
     dX = eng.synth_data_u8_dev(1234, n, 128); dB0 = eng.randinit_dev(7, n, 8); dK = eng.synth_codebooks_dev(4321, 8, 128)
     eng.encode_icm_dev(dX, dB0, dK, 8, [2], 4, 4, True, seed=42)
 torch.cuda.synchronize()
