@@ -244,3 +244,46 @@ def test_filter_steps_aside_for_nonfinite_data(lsq, oracle):
         t = eng.timings()
     assert np.array_equal(Bs, Bs_ref)
     assert t["filtered_blocks"] > 0 and (t["staged_blocks"] > 0 or t["filter_f32"] > 0), t
+
+
+def test_filter_outliers_beyond_the_sampled_range(lsq, oracle):
+    """The level range comes from a sample of the chunk; vectors whose unaries leave it are flagged by the GEMM epilogue and take the
+    f32 routine one by one.  A few mild outliers (outside the sample for one of the two panel parities), a heavy tail (inside it: coarse step, many refinements),
+    and a chunk whose second half is scaled up."""
+    d, n, m, seed = 16, 40_000, 8, 77
+    rng = np.random.default_rng(seed)
+    X, K, B0 = make_problem(d, n, m, seed=seed, kind="gauss")
+    ta = {"filter_f32": 0}
+    for parity in (0, 1):                                # the sample takes every other 128-vector panel at this n: one parity is unseen
+        rows = np.array([i for i in rng.choice(n, size=400, replace=False) if (i // 128) % 2 == parity][:9])
+        Xa = X.copy()
+        Xa[rows] *= np.float32(3.0)
+        t = _filter_case(lsq, oracle, Xa, K, B0, m, [2], 2, 4, seed)
+        ta["filter_f32"] += t["filter_f32"]
+    Xb = (X * rng.standard_cauchy((n, 1)).astype(np.float32)).astype(np.float32)
+    tb = _filter_case(lsq, oracle, Xb, K, B0, m, [2], 2, 4, seed)
+    Xc = X.copy()
+    Xc[n // 2:] *= np.float32(1.7)
+    tc = _filter_case(lsq, oracle, Xc, K, B0, m, [1], 2, 4, seed)
+    assert ta["filter_f32"] + tb["filter_f32"] + tc["filter_f32"] > 0, (ta, tb, tc)      # at least one case exercised the per-vector flags
+
+
+def test_filter_degenerate_ranges(lsq, oracle):
+    """All-zero codebooks (every conditioned sum is 0: step 0 -> unusable bounds -> the f32 walk; index 0 wins every argmin), constant
+    data, and a single distinct codeword per codebook."""
+    d, n, m, seed = 16, 5000, 8, 12
+    X, K, B0 = make_problem(d, n, m, seed=seed, kind="gauss")
+    _filter_case(lsq, oracle, X, np.zeros_like(K), B0, m, [1], 2, 4, seed, expect_filter=False)
+    Kc = np.repeat(K.reshape(m, H, d)[:, :1], H, axis=1).reshape(m * H, d).copy()       # h copies of one codeword: all sums tie
+    oracle_B, _ = oracle.encode_icm(X, B0, Kc, m, H, [1], 2, 4, True, seed)
+    with lsq.Engine(0, schedule=6) as eng:
+        eng.set_option("q16_min", 0)
+        eng.set_option("light", 0)
+        Bs, _ = eng.encode_icm(X, B0, Kc, m, [1], 2, 4, True, seed=seed)
+    assert np.array_equal(Bs, oracle_B)
+    Xk = np.full_like(X, 3.25)
+    with lsq.Engine(0, schedule=6) as eng:
+        eng.set_option("q16_min", 0)
+        Bs, _ = eng.encode_icm(Xk, B0, K, m, [2], 2, 4, True, seed=seed)
+    ref, _ = oracle.encode_icm(Xk, B0, K, m, H, [2], 2, 4, True, seed)
+    assert np.array_equal(Bs, ref)

@@ -1,0 +1,10 @@
+"""tools/print_bench.py < bench output: one compact line per bench JSON line (value, ms/step, breakdown, filter counters)."""
+import json
+import sys
+
+for l in sys.stdin:
+    l = l.strip()
+    if l.startswith("{"):
+        d = json.loads(l)
+        print("%.2f M/s  %.2f ms" % (d["value"] / 1e6, d["ms_per_step"]), {k: round(v, 2) for k, v in d.get("time_breakdown_ms_per_step", {}).items()},
+              "frac %.3f" % d["roofline"]["frac"] if d.get("roofline") else "", d.get("filter"))
