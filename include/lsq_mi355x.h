@@ -105,8 +105,9 @@ LSQ_API int lsq_set_stream(lsq_ctx *ctx, void *hip_stream);
  *                    combine kernel: the measured alternatives of DESIGN.md, kept as independent implementations for cross-checks;
  *   "q16_min" (default 65536): schedule 6 applies to chunks with at least this many vectors (below, every block is "light": nothing to filter);
  *   "per_node" (0/1, default 0): schedule 6 with one launch per node update (profiling: per-sweep timings and counters);
- *   "light" (default 256): a block with at most this many active vectors gathers f32 table columns straight from L2 (one wave per vector)
- *        instead of staging slices through LDS; 0 = always stage.  Same codes.
+ *   "light" (default 160 in the filtered walk, 256 in the f32 walk: the measured crossovers): a block with at most this many active vectors
+ *        gathers f32 table columns straight from L2 (one wave per vector, two vectors in flight) instead of staging slices through LDS;
+ *        0 = always stage.  Same codes.
  *   "fallback" (0/1, default 1): a candidate whose codes become equal to the vector's current codes inherits the current state's validity
  *        bits (validity depends on the code tuple only): exact, ~12 % fewer node updates.
  *   "skip" (0/1, default 1): a node whose conditioning codes did not change since it was last minimised is not recomputed (exact memoisation --

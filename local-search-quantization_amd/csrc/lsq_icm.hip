@@ -266,30 +266,17 @@ __global__ __launch_bounds__(NT) void icm_walk_kernel(const float *__restrict__ 
             // LDS would cost more than the vectors need.  One wave per vector instead, the (m-1) 1 KiB table columns
             // gathered straight from L2 (row-major T) -- the icm_node_kernel arithmetic on the slice-major U layout.
             const float *__restrict__ Tj = T + (int64_t)j * M * LSQ_H * LSQ_H;
-            for (int ci = wave; ci < nact; ci += NW) {
-                const int64_t i = lo + __builtin_amdgcn_readfirstlane((int)list[ci]);
-                const CodeRec cr = load_rec<CS>(rec, i);
-                f32x4 s = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(Usj + ((int64_t)(lane / LPV) * n + i) * SL) + (lane % LPV));
-                f32x4 c[M > 1 ? M - 1 : 1];
+            constexpr int LB = LSQ_LIGHT_LB(M);
+            for (int r0 = wave; r0 < nact; r0 += NW * LB) {
+                int64_t vi[LB];
+                bool on[LB];
 #pragma unroll
-                for (int kk = 0; kk < M - 1; ++kk) {
-                    const int k = kk + (kk >= j ? 1 : 0);
-                    c[kk] = reinterpret_cast<const f32x4 *>(Tj + ((int64_t)(k * LSQ_H) + cr.get(k)) * LSQ_H)[lane];
+                for (int e = 0; e < LB; ++e) {
+                    const int r = r0 + e * NW;
+                    on[e] = r < nact;
+                    vi[e] = lo + __builtin_amdgcn_readfirstlane((int)list[on[e] ? r : r0]);
                 }
-#pragma unroll
-                for (int kk = 0; kk < M - 1; ++kk) s = s + c[kk];      // ascending k, plain f32 adds
-                const uint32_t code = (uint32_t)wave_first_argmin(s, lane);
-                if (lane == 0) {
-                    rec[i * CS + j] = (uint8_t)code;
-                    if (valid) {
-                        unsigned short vm = (code != cr.get(j)) ? (unsigned short)(1u << j) : (unsigned short)(valid[i] | (1u << j));
-                        uint32_t rw[RW];
-                        rw[0] = (uint32_t)cr.lo; rw[1] = (uint32_t)(cr.lo >> 32);
-                        if (RW == 4) { rw[RW - 2] = (uint32_t)cr.hi; rw[RW - 1] = (uint32_t)(cr.hi >> 32); }
-                        vm = (unsigned short)(vm | known_valid<RW>(rw, j, (uint8_t)code, ref_rec ? ref_rec + i * CS : nullptr, ref_valid ? ref_valid + i : nullptr));
-                        valid[i] = vm;
-                    }
-                }
+                light_update<M, CS, LB>(rec, valid, ref_rec, ref_valid, Usj, Tj, n, SL, j, vi, on, lane);
             }
             __syncthreads();
             continue;

@@ -32,6 +32,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ unsigned long long *g_walkq_dbg = nullptr;      // [launch slot][block][16] timestamps (tools only)
 __device__ unsigned int g_walkq_dbg_slot = 0;
 __device__ unsigned long long *g_walkq_dbg_cur = nullptr;   // block 0's record of the running launch (for q16_refine's stamps)
+#define LSQ_WALKQ_DBG_WORDS (24 + 2 * 65)                  // 24 phase stamps of the launch's last node, then start clock / active count of every node + the end clock
 #define DBG_STAMP(k) do { if (dbgp && threadIdx.x == 0) dbgp[k] = wall_clock64(); } while (0)
 #else
 #define DBG_STAMP(k) do {} while (0)
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(NT) void icm_walkq_kernel(const float *__restrict__
         if (threadIdx.x == 0) dbg_slot_s = (blockIdx.x == 0) ? atomicAdd(&g_walkq_dbg_slot, 1u) : 0u;
         __syncthreads();
         // only block 0 knows the slot; other blocks use the launch's slot through a second counter-free trick: they record nothing
-        if (blockIdx.x == 0 && dbg_slot_s < 4096) dbgp = g_walkq_dbg + (size_t)dbg_slot_s * 24;
+        if (blockIdx.x == 0 && dbg_slot_s < 4096) dbgp = g_walkq_dbg + (size_t)dbg_slot_s * LSQ_WALKQ_DBG_WORDS;
     }
     DBG_STAMP(0);
     if (blockIdx.x == 0 && threadIdx.x == 0) g_walkq_dbg_cur = dbgp;
@@ -360,7 +361,6 @@ __global__ __launch_bounds__(NT) void icm_walkq_kernel(const float *__restrict__
     constexpr int NW = NT / 64;
     constexpr int EPT = 4096 / NT;
     constexpr int step = NW * VPW;
-    const int LPF = SLF / 4;                             // f32 unary planes (light blocks, exact refinement): slices of SLF floats
 
     struct Item { u32x4 u; uint32_t r[RW]; };
 
@@ -491,22 +491,24 @@ __global__ __launch_bounds__(NT) void icm_walkq_kernel(const float *__restrict__
         __syncthreads();
     };
 
-    // one wave per vector, everything in f32: the light-block routine of icm_walk_kernel (also the last resort of the filter)
-    auto full_f32 = [&](const int j, const int64_t i) {
+    // one wave per vector, everything in f32: the light-block routine of icm_walk_kernel (also the last resort of the filter);
+    // `count` list entries, entry r names the local index through pick(r)
+    constexpr int LB = LSQ_LIGHT_LB(M);
+    int64_t lo_cur = 0;                                  // first vector of the block's current pass
+    auto light_list = [&](const int j, const int count, auto pick) {
         const float *__restrict__ Usj = U + (int64_t)j * n * LSQ_H;
         const float *__restrict__ Tj = T + (int64_t)j * M * LSQ_H * LSQ_H;
-        const CodeRec cr = load_rec<CS>(rec, i);
-        f32x4 s = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(Usj + ((int64_t)(lane / LPF) * n + i) * SLF) + (lane % LPF));
-        f32x4 c[M > 1 ? M - 1 : 1];
+        for (int r0 = wave; r0 < count; r0 += NW * LB) {
+            int64_t vi[LB];
+            bool on[LB];
 #pragma unroll
-        for (int kk = 0; kk < M - 1; ++kk) {
-            const int k = kk + (kk >= j ? 1 : 0);
-            c[kk] = reinterpret_cast<const f32x4 *>(Tj + ((int64_t)(k * LSQ_H) + cr.get(k)) * LSQ_H)[lane];
+            for (int e = 0; e < LB; ++e) {
+                const int r = r0 + e * NW;
+                on[e] = r < count;
+                vi[e] = lo_cur + __builtin_amdgcn_readfirstlane((int)pick(on[e] ? r : r0));
+            }
+            light_update<M, CS, LB>(rec, valid, ref_rec, ref_valid, Usj, Tj, n, SLF, j, vi, on, lane);
         }
-#pragma unroll
-        for (int kk = 0; kk < M - 1; ++kk) s = s + c[kk];
-        const uint32_t code = (uint32_t)wave_first_argmin(s, lane);
-        if (lane == 0) apply_node_result<CS>(rec, valid, i, j, (unsigned long long)code, ref_rec, ref_valid);
     };
 
     const int64_t npass = (n + per_pass - 1) / per_pass;
@@ -514,8 +516,12 @@ __global__ __launch_bounds__(NT) void icm_walkq_kernel(const float *__restrict__
         const int64_t lo = pass * per_pass;
         const int64_t hi = (lo + per_pass < n) ? lo + per_pass : n;
         const int cnt = (int)(hi - lo);
+        lo_cur = lo;
         for (int nu = 0; nu < nodes.count; ++nu) {
             const int j = nodes.j[nu];
+#ifdef LSQ_TUNING
+            if (dbgp && threadIdx.x == 0 && pass == (int64_t)blockIdx.x && nu < 64) dbgp[24 + nu] = wall_clock64();
+#endif
             {
                 const int base = (int)threadIdx.x * EPT;
                 int f[EPT], c = 0;
@@ -545,6 +551,9 @@ __global__ __launch_bounds__(NT) void icm_walkq_kernel(const float *__restrict__
             }
             const int nact = nact_s;
             DBG_STAMP(1);
+#ifdef LSQ_TUNING
+            if (dbgp && threadIdx.x == 0 && pass == (int64_t)blockIdx.x && nu < 64) dbgp[24 + 65 + nu] = (unsigned long long)nact;
+#endif
             if (nact == 0) { __syncthreads(); continue; }
             if (threadIdx.x == 0) {                        // [0] node updates recomputed, [2] light / [3] filtered block-node-updates
                 stat_s[0] += (unsigned)nact;
@@ -552,7 +561,7 @@ __global__ __launch_bounds__(NT) void icm_walkq_kernel(const float *__restrict__
                 stat_s[4 + ((nodes.pos0 + nu) & (LSQ_WALK_TRACE - 1))] += (unsigned)nact;
             }
             if (nact <= direct_max) {                      // light block: full f32 gathers from L2, no staging
-                for (int ci = wave; ci < nact; ci += NW) full_f32(j, lo + __builtin_amdgcn_readfirstlane((int)list[ci]));
+                light_list(j, nact, [&](int r) { return list[r]; });
                 __syncthreads();
                 continue;
             }
@@ -654,7 +663,7 @@ __global__ __launch_bounds__(NT) void icm_walkq_kernel(const float *__restrict__
             {   // vectors outside the sampled level range: one wave each, in full f32
                 const unsigned short *f32l = reinterpret_cast<const unsigned short *>(bestA);
                 const int nf32 = f32_s;
-                for (int r = wave; r < nf32; r += NW) full_f32(j, lo + list[__builtin_amdgcn_readfirstlane((int)f32l[r])]);
+                light_list(j, nf32, [&](int r) { return list[f32l[r]]; });
                 if (threadIdx.x == 0 && nf32) atomicAdd(&stat_s[4 + LSQ_WALK_TRACE + 2], (unsigned)nf32);
             }
             {
@@ -671,6 +680,9 @@ __global__ __launch_bounds__(NT) void icm_walkq_kernel(const float *__restrict__
         }
     }
     __syncthreads();
+#ifdef LSQ_TUNING
+    if (dbgp && threadIdx.x == 0) dbgp[24 + 64] = wall_clock64();
+#endif
     if (active_total)
         for (int e = threadIdx.x; e < LSQ_WALK_COUNTERS; e += NT)
             if (stat_s[e]) atomicAdd(active_total + e, (unsigned long long)stat_s[e]);
@@ -679,7 +691,7 @@ __global__ __launch_bounds__(NT) void icm_walkq_kernel(const float *__restrict__
 }  // namespace
 
 #ifdef LSQ_TUNING
-// tools only: device buffer of 4096 x 16 u64 that block 0 of every icm_walkq_kernel launch fills with phase timestamps (wall_clock64)
+// tools only: device buffer of 4096 x LSQ_WALKQ_DBG_WORDS (154) u64 that block 0 of every icm_walkq_kernel launch fills with phase timestamps (wall_clock64)
 extern "C" __attribute__((visibility("default"))) int lsq_tuning_set_walkq_debug(void *buf) {
     unsigned zero = 0;
     LSQ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_walkq_dbg), &buf, sizeof(buf)));
@@ -727,7 +739,7 @@ static int launch_walkq_t(hipStream_t s, const float *U, const uint16_t *Uq, con
     static_assert(LDS_BYTES + 256 <= 160 * 1024, "slice table + keys must fit the 160 KiB LDS");
     int per_pass = 1, npass = 1;
     lsq_walk_geometry(n, M, &per_pass, &npass, nullptr);
-    const int direct_max = light >= 0 ? light : LSQ_KNOB("LSQ_WALK_DIRECT", 256);
+    const int direct_max = light >= 0 ? light : LSQ_KNOB("LSQ_WALK_DIRECT", 160);
     const int skip = (use_skip && valid) ? 1 : 0;
     static LdsOptIn optin;
     LSQ_TRY(optin_lds(optin, &icm_walkq_kernel<M, SLQ, DEPTH, NT>, LDS_BYTES));

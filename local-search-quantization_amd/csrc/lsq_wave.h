@@ -182,6 +182,69 @@ __device__ inline void apply_node_results(uint8_t *__restrict__ rec, unsigned sh
     }
 }
 
+// LIGHT routine (blocks with few active vectors, and the filtered walk's last resort): one wave per vector, everything in f32 --
+// the unary row from the slice-major planes (slices of SL floats), the (m-1) 1 KiB table rows gathered from L2 (row-major T), plain
+// f32 adds in ascending k, first argmin, validity bookkeeping.  LB vectors of a wave are in flight together and every load of
+// the bookkeeping (record, validity, reference record) is issued with the first batch: a vector costs one dependent round trip
+// (record -> table rows) instead of three, shared between LB vectors.  `on[e]` is wave-uniform.
+template <int M, int CS, int LB>
+__device__ inline void light_update(uint8_t *__restrict__ rec, unsigned short *__restrict__ valid, const uint8_t *__restrict__ ref_rec,
+                                    const unsigned short *__restrict__ ref_valid, const float *__restrict__ Usj, const float *__restrict__ Tj,
+                                    int64_t n, int SL, int j, const int64_t (&vi)[LB], const bool (&on)[LB], int lane) {
+    constexpr int RW = CS / 4;
+    const int LPV = SL / 4;
+    const bool have_ref = ref_rec && ref_valid;
+    CodeRec cr[LB], rr[LB];
+    uint32_t vo[LB], rv[LB];
+    f32x4 s[LB];
+#pragma unroll
+    for (int e = 0; e < LB; ++e) {
+        cr[e].lo = cr[e].hi = rr[e].lo = rr[e].hi = 0ull;
+        vo[e] = rv[e] = 0u;
+        s[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (on[e]) {
+            cr[e] = load_rec<CS>(rec, vi[e]);
+            s[e] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(Usj + ((int64_t)(lane / LPV) * n + vi[e]) * SL) + (lane % LPV));
+            if (valid) vo[e] = (uint32_t)__builtin_amdgcn_readfirstlane((int)valid[vi[e]]);
+            if (have_ref) {
+                rr[e] = load_rec<CS>(ref_rec, vi[e]);
+                rv[e] = (uint32_t)__builtin_amdgcn_readfirstlane((int)ref_valid[vi[e]]);
+            }
+        }
+    }
+    f32x4 c[LB][M > 1 ? M - 1 : 1];
+#pragma unroll
+    for (int e = 0; e < LB; ++e)
+        if (on[e]) {
+#pragma unroll
+            for (int kk = 0; kk < M - 1; ++kk) {
+                const int k = kk + (kk >= j ? 1 : 0);
+                c[e][kk] = reinterpret_cast<const f32x4 *>(Tj + ((int64_t)(k * LSQ_H) + cr[e].get(k)) * LSQ_H)[lane];
+            }
+        }
+#pragma unroll
+    for (int e = 0; e < LB; ++e)
+        if (on[e]) {
+#pragma unroll
+            for (int kk = 0; kk < M - 1; ++kk) s[e] = s[e] + c[e][kk];      // ascending k, plain f32 adds
+            const uint8_t code = (uint8_t)wave_first_argmin(s[e], lane);
+            if (lane == 0) {
+                rec[vi[e] * CS + j] = code;
+                if (valid) {
+                    unsigned short vm = (code != cr[e].get(j)) ? (unsigned short)(1u << j) : (unsigned short)(vo[e] | (1u << j));
+                    if (have_ref) {
+                        CodeRec mine = cr[e];
+                        mine.set(j, code);
+                        if (mine.lo == rr[e].lo && (RW == 2 || mine.hi == rr[e].hi)) vm = (unsigned short)(vm | rv[e]);      // known_valid()
+                    }
+                    valid[vi[e]] = vm;
+                }
+            }
+        }
+}
+// vectors of a wave in flight in the light routine: the table rows of one vector take 4 (m-1) VGPRs
+#define LSQ_LIGHT_LB(M) ((M) <= 8 ? 2 : 1)
+
 #define LSQ_WALK_MAX_NODES 64
 struct WalkNodes { int count; int pos0; uint8_t j[LSQ_WALK_MAX_NODES]; };      // kernel argument: the node updates of one launch, in order; pos0 = position of j[0] in the ILS iteration's node sequence (trace counters)
 

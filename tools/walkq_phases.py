@@ -7,14 +7,15 @@ lsq = importlib.import_module("local-search-quantization_amd")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 per_node = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 L = lsq._lib.load(tuning=True)
-buf = torch.zeros((4096, 24), dtype=torch.int64, device="cuda")
+W = 24 + 2 * 65
+buf = torch.zeros((4096, W), dtype=torch.int64, device="cuda")
 L.lsq_tuning_set_walkq_debug.restype = C.c_int
 L.lsq_tuning_set_walkq_debug.argtypes = [C.c_void_p]
 assert L.lsq_tuning_set_walkq_debug(buf.data_ptr()) == 0
 with lsq.Engine(0, schedule=6, tuning=True) as eng:
     eng.set_option("per_node", per_node)
     eng.set_option("q16_min", 0)
-    eng.set_option("light", 0)
+    eng.set_option("light", int(sys.argv[3]) if len(sys.argv) > 3 else 0)
     dX = eng.synth_data_u8_dev(1234, n, 128); dB0 = eng.randinit_dev(7, n, 8); dK = eng.synth_codebooks_dev(4321, 8, 128)
     eng.encode_icm_dev(dX, dB0, dK, 8, [2], 4, 4, True, seed=42)
 torch.cuda.synchronize()
@@ -34,3 +35,13 @@ for li, r in enumerate(rows[:72]):
         rf[0] = (st[0] - int(r[12])) / 100.0     # from the end of the decide phase to the function entry
     print("%3d nact %5d amb %3d total %7.1f us | compact %5.1f pre %5.1f | slices %s | decide %5.1f refine+ %5.1f [entry +%4.1f, .. %4.1f .. %4.1f, whole refine %4.1f]" %
           (li, r[14], r[15], (ts[-1] - ts[0]) / 100.0, d[0], d[1], " ".join("%5.1f" % x for x in d[2:11]), d[11], d[12], rf[0], rf[1], rf[2], rf[3]))
+
+if not per_node:
+    # one launch per ILS iteration: block 0's clock at the start of every node update of its first pass (the production schedule)
+    for li, r in enumerate(rows[:4]):
+        cl = [int(x) for x in r[24:24 + 65]]
+        na = [int(x) for x in r[24 + 65:24 + 65 + 64]]
+        k = max(i for i in range(64) if cl[i]) + 1
+        ends = cl[1:k] + [cl[64]]
+        print("launch %d: %d nodes, total %.1f us" % (li, k, (cl[64] - cl[0]) / 100.0))
+        print("   " + " ".join("%d:%.0f" % (na[i], (ends[i] - cl[i]) / 100.0) for i in range(k)))
