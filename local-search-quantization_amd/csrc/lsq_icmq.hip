@@ -54,9 +54,11 @@ __device__ inline void top2_merge(uint32_t &lo, uint32_t &hi, uint32_t olo, uint
     lo = umin(lo, olo);
     hi = nhi;
 }
+// quad permutations only (every source lane exists): old = 0 + bound_ctrl lets the compiler fold the permutation into the consuming
+// v_min_u32 / v_max_u32 (4 instructions per top2_merge stage instead of 7 with a self-referencing old operand)
 template <int CTRL>
 __device__ inline uint32_t dpp_u32(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
 }
 
 // ---- parameters -----------------------------------------------------------------------------------------------------------------

@@ -53,6 +53,58 @@ __global__ __launch_bounds__(1024) void k(const unsigned char *codes, float *out
     out[(size_t)blockIdx.x * 1024 + threadIdx.x] = acc.x + acc.y + acc.z + acc.w;
 }
 
+// Two lanes per vector (32 vectors per wave), two ds_read_b128 per lane and table: the same wave-level reads per vector and table as the
+// four-lane mapping, with half the per-vector address arithmetic.  q = lane & 1, r = which of the lane's two reads.
+template <int PAT>
+__device__ inline unsigned addr2_of(unsigned code, unsigned q, unsigned r) {
+    switch (PAT) {
+        case 0: return code * 64u + q * 16u + r * 32u;                         // 64-byte rows, lanes interleaved (chunks q, q + 2)
+        case 1: return code * 64u + q * 32u + r * 16u;                         // 64-byte rows, 32 contiguous bytes per lane
+        case 2: return code * 32u + q * 16u + r * (8192u + 64u);               // two half planes (plane r), second skewed by 64 bytes
+        case 3: return code * 16u + (2u * r + q) * (4096u + 64u);              // four quad planes, skewed
+        case 4: return code * 32u + q * 16u + r * (8192u + 128u);              // two half planes, second skewed by 128 bytes
+        default: return 0;
+    }
+}
+template <int PAT>
+__global__ __launch_bounds__(1024) void k2(const unsigned char *codes, float *out, int iters, unsigned long long *clk) {
+    extern __shared__ f32x4 lds[];
+    for (int e = threadIdx.x; e < 7 * 2048; e += 1024) lds[e] = (f32x4){(float)e, 1.f, 2.f, 3.f};
+    __syncthreads();
+    const unsigned lane = threadIdx.x & 63, v = lane >> 1, q = lane & 1;
+    const unsigned char *cp = codes + ((size_t)blockIdx.x * 1024 + (threadIdx.x & ~63u) + v) * 8;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    unsigned c[7];
+    for (int t = 0; t < 7; ++t) c[t] = cp[t];
+    const char *base = reinterpret_cast<const char *>(lds);
+    __syncthreads();
+    const unsigned long long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            const unsigned code = (c[t] + (unsigned)it * 37u) & 255u;
+#pragma unroll
+            for (unsigned r = 0; r < 2; ++r) acc = acc + *reinterpret_cast<const f32x4 *>(base + addr2_of<PAT>(code, q, r) + (unsigned)t * 22528u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && clk) clk[blockIdx.x] = clock64() - t0;
+    out[(size_t)blockIdx.x * 1024 + threadIdx.x] = acc.x + acc.y + acc.z + acc.w;
+}
+
+template <int PAT>
+static void run2(const unsigned char *dc, float *dout, const char *name) {
+    const int iters = 2000, lds_bytes = 160 * 1024 - 512;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k2<PAT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    hipLaunchKernelGGL(k2<PAT>, dim3(256), dim3(1024), lds_bytes, 0, dc, dout, 10, nullptr);
+    CK(hipEventRecord(a));
+    hipLaunchKernelGGL(k2<PAT>, dim3(256), dim3(1024), lds_bytes, 0, dc, dout, iters, nullptr);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    printf("2 lanes/vector: %-44s %8.3f ms  %6.2f ns per wave read per CU\n", name, ms, ms * 1e6 / (16.0 * iters * 14));
+}
+
 template <int PAT>
 static void run(const unsigned char *dc, float *dout, const char *name) {
     const int iters = 4000, lds_bytes = 160 * 1024 - 512;
@@ -89,5 +141,10 @@ int main() {
     run<4>(dc, dout, "two 32-byte half planes, skewed");
     run<7>(dc, dout, "four 16-byte quad planes, skewed");
     run<6>(dc, dout, "16 distinct rows only (broadcast-heavy)");
+    run2<0>(dc, dout, "64-byte rows, chunks q and q + 2");
+    run2<1>(dc, dout, "64-byte rows, 32 contiguous bytes per lane");
+    run2<2>(dc, dout, "two half planes, skew 64");
+    run2<4>(dc, dout, "two half planes, skew 128");
+    run2<3>(dc, dout, "four quad planes, skewed");
     return 0;
 }
