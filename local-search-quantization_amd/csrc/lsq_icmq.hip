@@ -314,7 +314,18 @@ __device__ inline int q16_refine(const float *__restrict__ U, const uint16_t *__
 // Block / pass / node structure, compaction of the active vectors, light blocks and the validity bookkeeping are those of
 // icm_walk_kernel; the slice walk runs on 16-bit levels (slices of SLQ = 32 candidates for m <= 8, 16 above: the same 64 / 32-byte
 // pieces and the same LDS table footprint as the f32 walk, half as many slices).
-template <int M, int SLQ, int DEPTH, int NT>
+// LDS placement of a slice table.  A lane owns CPL = 8 NR candidates of its vector's slice: NR 16-byte chunks, chunk c = r LPV + q (r-th read of
+// lane q).  The table is stored as NR planes (plane r = the chunks every lane reads r-th, LPV per row), later planes skewed by 128 bytes:
+// the layout tools/ubench_lds.hip measured best for two lanes per vector (NR = 1: plain rows).  Global Tq keeps plain rows.
+template <int SLQ, int CPL>
+struct WalkqTab {
+    static constexpr int NR = CPL / 8, LPV = SLQ / CPL, EPR = SLQ / 8;                      // reads per lane and table / lanes per vector / entries per row
+    static constexpr int PLANE_E = LSQ_H * LPV + (NR > 1 ? 8 : 0), TS_E = NR * PLANE_E;     // 16-byte entries per plane / per table
+    __device__ static constexpr int entry(int kk, int code, int c) { return kk * TS_E + (c / LPV) * PLANE_E + code * LPV + (c % LPV); }
+    static constexpr int lds_entries(int m) { return (m - 1) * TS_E; }
+};
+
+template <int M, int SLQ, int CPL, int DEPTH, int NT>
 __global__ __launch_bounds__(NT) void icm_walkq_kernel(const float *__restrict__ U, const uint16_t *__restrict__ Uq, const uint16_t *__restrict__ Tq,
                                                        const float *__restrict__ T, uint8_t *__restrict__ rec, unsigned short *__restrict__ valid,
                                                        int64_t n, const WalkNodes nodes, int per_pass, int use_skip, int direct_max,
@@ -323,11 +334,15 @@ __global__ __launch_bounds__(NT) void icm_walkq_kernel(const float *__restrict__
                                                        const lsq_q16_params *__restrict__ P, int SLF, const unsigned short *__restrict__ qflag, int abl) {
     constexpr int CS = (M <= 8) ? 8 : 16;
     constexpr int NS = LSQ_H / SLQ;
-    constexpr int LPV = SLQ / 8;                         // lanes per vector: 8 levels (16 B) per lane
+    using TL = WalkqTab<SLQ, CPL>;
+    constexpr int NR = TL::NR;                           // 16-byte reads per lane and table (8 levels each)
+    constexpr int LPV = TL::LPV;                         // lanes per vector: CPL levels per lane
+    constexpr int EPR = TL::EPR;                         // 16-byte entries per table row (global layout)
     constexpr int VPW = 64 / LPV;
     constexpr int CW = (M - 1 + 3) / 4;
     constexpr int RW = CS / 4;
-    constexpr int TAB = (M - 1) * LSQ_H * LPV;           // 16-byte entries of one slice table
+    constexpr int TAB = (M - 1) * LSQ_H * EPR;           // 16-byte entries of one slice table (global)
+    constexpr int LTAB = TL::lds_entries(M);             // ... in LDS (planes, skew)
     constexpr int PP = LSQ_WALK_PP(M, SLQ / 2);          // same LDS budget as the f32 walk with slices of SLQ / 2 floats
     if (P->ok == 0) return;                              // non-finite / degenerate bounds: icm_walk_kernel (enqueued next) does this launch's work
 #ifdef LSQ_TUNING
@@ -344,7 +359,7 @@ __global__ __launch_bounds__(NT) void icm_walkq_kernel(const float *__restrict__
 #endif
     extern __shared__ u32x4 lds_walkq[];
     u32x4 *tab = lds_walkq;
-    uint32_t *bestA = reinterpret_cast<uint32_t *>(lds_walkq + TAB);                           // [PP] smallest key (Q << 16 | candidate)
+    uint32_t *bestA = reinterpret_cast<uint32_t *>(lds_walkq + LTAB);                           // [PP] smallest key (Q << 16 | candidate)
     uint32_t *bestB = bestA + PP;                                                              // [PP] second smallest key
     unsigned short *list = reinterpret_cast<unsigned short *>(bestB + PP);                     // [PP] active local indices
     __shared__ int wave_tot[16];
@@ -364,7 +379,7 @@ __global__ __launch_bounds__(NT) void icm_walkq_kernel(const float *__restrict__
     constexpr int EPT = 4096 / NT;
     constexpr int step = NW * VPW;
 
-    struct Item { u32x4 u; uint32_t r[RW]; };
+    struct Item { u32x4 u[NR]; uint32_t r[RW]; };
 
     auto walk_slices = [&](const int j, const int64_t lo, const int nact, const bool dense) {
 #ifndef LSQ_TUNING
@@ -397,23 +412,34 @@ __global__ __launch_bounds__(NT) void icm_walkq_kernel(const float *__restrict__
         prefetch_tab(0);
         const int ipw = (wave * VPW < nact) ? (nact - wave * VPW + step - 1) / step : 0;
         int ls = 0, lit = 0;
+        // the slice plane of the level stream the NEXT loaded item belongs to: advanced when the wave's items wrap around (uniform, scalar)
+        const char *ub = reinterpret_cast<const char *>(Uqj + lo * SLQ);
+        const char *const rb = reinterpret_cast<const char *>(rec + lo * CS);
+        const int64_t plane_bytes = n * (int64_t)(SLQ * 2);
         auto load_next = [&](Item &it) {
             int ci = wave * VPW + lit * step + v;
             ci = ci < nact ? ci : nact - 1;
-            const int lsc = ls < NS ? ls : NS - 1;
             uint32_t li = (uint32_t)ci;
             if (!dense) li = list[ci];
-            const char *ub = reinterpret_cast<const char *>(Uqj + ((int64_t)lsc * n + lo) * SLQ);
-            const char *rb = reinterpret_cast<const char *>(rec + lo * CS);
+#ifdef LSQ_TUNING
+            const uint32_t uo = ((abl & 32) ? (li & 63u) : li) * (uint32_t)(SLQ * 2) + (uint32_t)q * 16u;      // ablation: the level stream from L2 instead of HBM
+#else
             const uint32_t uo = li * (uint32_t)(SLQ * 2) + (uint32_t)q * 16u;
-            it.u = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(ub + uo));
+#endif
+#pragma unroll
+            for (int r = 0; r < NR; ++r) it.u[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(ub + uo + r * (LPV * 16)));
             const uint32_t *rp = reinterpret_cast<const uint32_t *>(rb + li * (uint32_t)CS);
 #pragma unroll
             for (int w = 0; w < RW; ++w) it.r[w] = rp[w];
-            if (++lit >= ipw) { lit = 0; ++ls; }
+            if (++lit >= ipw) {
+                lit = 0;
+                if (++ls < NS) ub += plane_bytes;           // past the last slice the (unused) preloads re-read the last plane
+            }
         };
         auto compute = [&](const Item &cur, int slice, int c0) {
-            u32x4 s = cur.u;
+            u32x4 s[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) s[r] = cur.u[r];
 #pragma unroll
             for (int w = 0; w < CW; ++w) {
                 const uint32_t hiw = (w + 1 < RW) ? cur.r[w + 1] : 0u;
@@ -425,23 +451,44 @@ __global__ __launch_bounds__(NT) void icm_walkq_kernel(const float *__restrict__
                         uint32_t code;
                         if (t == 0) asm("v_and_b32 %0, 0xff, %1" : "=v"(code) : "v"(cw));
                         else code = (cw >> (8 * t)) & 0xffu;
-                        const u32x4 row = tab[(kk * LSQ_H + code) * LPV + q];
-                        s.x = pk_add_u16(s.x, row.x); s.y = pk_add_u16(s.y, row.y);      // levels add exactly: the sum of the m levels fits 16 bits
-                        s.z = pk_add_u16(s.z, row.z); s.w = pk_add_u16(s.w, row.w);
+#ifdef LSQ_TUNING
+                        if (abl & 64) continue;              // ablation: no table rows
+#endif
+#pragma unroll
+                        for (int r = 0; r < NR; ++r) {
+                            const u32x4 row = tab[kk * TL::TS_E + r * TL::PLANE_E + (int)code * LPV + q];
+                            s[r].x = pk_add_u16(s[r].x, row.x); s[r].y = pk_add_u16(s[r].y, row.y);      // levels add exactly: the sum of the m levels fits 16 bits
+                            s[r].z = pk_add_u16(s[r].z, row.z); s[r].w = pk_add_u16(s[r].w, row.w);
+                        }
                     }
                 }
             }
-            // keys (Q << 16 | candidate): two smallest of the lane's 8, then of the vector's LPV lanes
+#ifdef LSQ_TUNING
+            if (abl & 128) {                                 // ablation: no keys / top-2 / LDS atomics
+                if ((q == 0) & (c0 + v < nact) & (s[0].x == 0x12345678u)) bestA[c0 + v] = s[0].y ^ s[NR - 1].z;
+                return;
+            }
+#endif
+            // keys (Q << 16 | candidate): the two smallest of the lane's CPL, then of the vector's LPV lanes.  Inside the lane the keys carry the
+            // candidate's offset from the lane's first one (inline constants: chunk r starts LPV * 8 r further); the base is added to the two survivors
+            uint32_t l0 = 0, h0 = 0;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                constexpr uint32_t HI = 0xffff0000u;
+                const uint32_t o = (uint32_t)(r * LPV * 8);
+                const uint32_t k0 = (s[r].x << 16) | o, k1 = (s[r].x & HI) | (o + 1u);
+                const uint32_t k2 = (s[r].y << 16) | (o + 2u), k3 = (s[r].y & HI) | (o + 3u);
+                const uint32_t k4 = (s[r].z << 16) | (o + 4u), k5 = (s[r].z & HI) | (o + 5u);
+                const uint32_t k6 = (s[r].w << 16) | (o + 6u), k7 = (s[r].w & HI) | (o + 7u);
+                uint32_t la = umin3(k0, k1, k2), ha = umed3(k0, k1, k2);      // two triples + a pair: 6 + 2 x 3 instructions instead of 8 + 3 x 3
+                const uint32_t lb = umin3(k3, k4, k5), hb = umed3(k3, k4, k5);
+                const uint32_t lc = umin(k6, k7), hc = umax(k6, k7);
+                top2_merge(la, ha, lb, hb);
+                top2_merge(la, ha, lc, hc);
+                if (r == 0) { l0 = la; h0 = ha; } else top2_merge(l0, h0, la, ha);
+            }
             const uint32_t base = (uint32_t)(SLQ * slice) + 8u * (uint32_t)q;
-            uint32_t k0 = (s.x << 16) | base, k1 = (s.x & 0xffff0000u) | (base + 1u);
-            uint32_t k2 = (s.y << 16) | (base + 2u), k3 = (s.y & 0xffff0000u) | (base + 3u);
-            uint32_t k4 = (s.z << 16) | (base + 4u), k5 = (s.z & 0xffff0000u) | (base + 5u);
-            uint32_t k6 = (s.w << 16) | (base + 6u), k7 = (s.w & 0xffff0000u) | (base + 7u);
-            uint32_t l0 = umin3(k0, k1, k2), h0 = umed3(k0, k1, k2);      // two triples + a pair: 6 + 2 x 3 instructions instead of 8 + 3 x 3
-            uint32_t l1 = umin3(k3, k4, k5), h1 = umed3(k3, k4, k5);
-            uint32_t l2 = umin(k6, k7), h2 = umax(k6, k7);
-            top2_merge(l0, h0, l1, h1);
-            top2_merge(l0, h0, l2, h2);
+            l0 += base; h0 += base;                                          // candidate < 256: never carries into the level
             if (LPV >= 2) top2_merge(l0, h0, dpp_u32<DPP_XOR1>(l0), dpp_u32<DPP_XOR1>(h0));
             if (LPV >= 4) top2_merge(l0, h0, dpp_u32<DPP_XOR2>(l0), dpp_u32<DPP_XOR2>(h0));
             if ((q == 0) & (c0 + v < nact)) {
@@ -461,7 +508,7 @@ __global__ __launch_bounds__(NT) void icm_walkq_kernel(const float *__restrict__
 #pragma unroll
             for (int r = 0; r < NST; ++r) {
                 const int e = (int)threadIdx.x + r * NT;
-                if (e < TAB) tab[e] = nxt[r];
+                if (e < TAB) tab[TL::entry(e / (LSQ_H * EPR), (e / EPR) % LSQ_H, e % EPR)] = nxt[r];      // NT = 1024, EPR = 4: table r, the thread's fixed (code, chunk)
             }
             __syncthreads();
             if (slice + 1 < NS) prefetch_tab(slice + 1);
@@ -731,22 +778,21 @@ int lsq_launch_q16_prepare(hipStream_t s, const float *X, int64_t n, int d, cons
     return LSQ_OK;
 }
 
-template <int M, int SLQ, int DEPTH, int NT>
+template <int M, int SLQ, int CPL, int DEPTH, int NT>
 static int launch_walkq_t(hipStream_t s, const float *U, const uint16_t *Uq, const uint16_t *Tq, const float *T, uint8_t *rec, unsigned short *valid,
                           int64_t n, const WalkNodes &nodes, int use_skip, unsigned long long *active_total, int light,
                           const uint8_t *ref_rec, const unsigned short *ref_valid, const lsq_q16_params *P, const unsigned short *qflag) {
-    constexpr int TAB = (M - 1) * LSQ_H * (SLQ / 8);
     constexpr int PP = LSQ_WALK_PP(M, SLQ / 2);
-    constexpr int LDS_BYTES = TAB * 16 + PP * 8 + PP * 2;                // slice table + two smallest keys + active list
+    constexpr int LDS_BYTES = WalkqTab<SLQ, CPL>::lds_entries(M) * 16 + PP * 8 + PP * 2;      // slice table (planes, skew) + two smallest keys + active list
     static_assert(LDS_BYTES + 256 <= 160 * 1024, "slice table + keys must fit the 160 KiB LDS");
     int per_pass = 1, npass = 1;
     lsq_walk_geometry(n, M, &per_pass, &npass, nullptr);
     const int direct_max = light >= 0 ? light : LSQ_KNOB("LSQ_WALK_DIRECT", 160);
     const int skip = (use_skip && valid) ? 1 : 0;
     static LdsOptIn optin;
-    LSQ_TRY(optin_lds(optin, &icm_walkq_kernel<M, SLQ, DEPTH, NT>, LDS_BYTES));
+    LSQ_TRY(optin_lds(optin, &icm_walkq_kernel<M, SLQ, CPL, DEPTH, NT>, LDS_BYTES));
     const unsigned grid = (unsigned)(npass < 256 ? npass : 256);
-    hipLaunchKernelGGL((icm_walkq_kernel<M, SLQ, DEPTH, NT>), dim3(grid), dim3(NT), LDS_BYTES, s, U, Uq, Tq, T, rec, valid, n, nodes, per_pass, skip,
+    hipLaunchKernelGGL((icm_walkq_kernel<M, SLQ, CPL, DEPTH, NT>), dim3(grid), dim3(NT), LDS_BYTES, s, U, Uq, Tq, T, rec, valid, n, nodes, per_pass, skip,
                        direct_max, active_total, skip ? ref_rec : nullptr, skip ? ref_valid : nullptr, P, lsq_walk_slice_width(M), qflag, LSQ_KNOB("LSQ_Q16_ABL", 0));
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
@@ -768,12 +814,22 @@ int lsq_launch_icm_walkq(hipStream_t s, const float *U, const uint16_t *Uq, cons
             nodes.j[t] = (uint8_t)j;
         }
 #define LSQ_WQ_ARGS s, U, Uq, Tq, T, rec, valid, n, nodes, use_skip, active_total, light, ref_rec, ref_valid, P, qflag
-#define LSQ_WQ_CASE(MM, SLL, DD, NTT) case MM: LSQ_TRY((launch_walkq_t<MM, SLL, DD, NTT>(LSQ_WQ_ARGS))); break;
+#define LSQ_WQ_CASE(MM, SLL, CPLL, DD, NTT) case MM: LSQ_TRY((launch_walkq_t<MM, SLL, CPLL, DD, NTT>(LSQ_WQ_ARGS))); break;
+        // m <= 8: slices of 32 candidates, four lanes per vector (8 candidates per lane); above: slices of 16, two lanes of 8
+#ifdef LSQ_TUNING
+        if (m <= 8 && LSQ_KNOB("LSQ_WALKQ_CPL", 8) == 16) {      // two lanes per vector, 16 candidates per lane: 22 % fewer instructions per candidate, dense
+            switch (m) {                                          // node updates 7 % faster, sparse ones up to 30 % slower (coarser items): DESIGN.md 4.2
+                LSQ_WQ_CASE(1, 32, 16, 3, 1024) LSQ_WQ_CASE(2, 32, 16, 3, 1024) LSQ_WQ_CASE(3, 32, 16, 3, 1024) LSQ_WQ_CASE(4, 32, 16, 3, 1024)
+                LSQ_WQ_CASE(5, 32, 16, 3, 1024) LSQ_WQ_CASE(6, 32, 16, 3, 1024) LSQ_WQ_CASE(7, 32, 16, 3, 1024) LSQ_WQ_CASE(8, 32, 16, 3, 1024)
+            }
+            continue;
+        }
+#endif
         switch (m) {
-            LSQ_WQ_CASE(1, 32, 3, 1024) LSQ_WQ_CASE(2, 32, 3, 1024) LSQ_WQ_CASE(3, 32, 3, 1024) LSQ_WQ_CASE(4, 32, 3, 1024)
-            LSQ_WQ_CASE(5, 32, 3, 1024) LSQ_WQ_CASE(6, 32, 3, 1024) LSQ_WQ_CASE(7, 32, 3, 1024) LSQ_WQ_CASE(8, 32, 3, 1024)
-            LSQ_WQ_CASE(9, 16, 2, 1024) LSQ_WQ_CASE(10, 16, 2, 1024) LSQ_WQ_CASE(11, 16, 2, 1024) LSQ_WQ_CASE(12, 16, 2, 1024)
-            LSQ_WQ_CASE(13, 16, 2, 1024) LSQ_WQ_CASE(14, 16, 3, 512) LSQ_WQ_CASE(15, 16, 3, 512) LSQ_WQ_CASE(16, 16, 3, 512)
+            LSQ_WQ_CASE(1, 32, 8, 3, 1024) LSQ_WQ_CASE(2, 32, 8, 3, 1024) LSQ_WQ_CASE(3, 32, 8, 3, 1024) LSQ_WQ_CASE(4, 32, 8, 3, 1024)
+            LSQ_WQ_CASE(5, 32, 8, 3, 1024) LSQ_WQ_CASE(6, 32, 8, 3, 1024) LSQ_WQ_CASE(7, 32, 8, 3, 1024) LSQ_WQ_CASE(8, 32, 8, 3, 1024)
+            LSQ_WQ_CASE(9, 16, 8, 2, 1024) LSQ_WQ_CASE(10, 16, 8, 2, 1024) LSQ_WQ_CASE(11, 16, 8, 2, 1024) LSQ_WQ_CASE(12, 16, 8, 2, 1024)
+            LSQ_WQ_CASE(13, 16, 8, 2, 1024) LSQ_WQ_CASE(14, 16, 8, 3, 512) LSQ_WQ_CASE(15, 16, 8, 3, 512) LSQ_WQ_CASE(16, 16, 8, 3, 512)
         }
 #undef LSQ_WQ_CASE
 #undef LSQ_WQ_ARGS
