@@ -174,12 +174,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const int64_t coff = slice ? (int64_t)(c / h) * plane_stride + (int64_t)(a / slice) * (Mtot * slice) + (a % slice)
                                    : (int64_t)(c / h) * plane_stride + a;
         const int64_t rstride = slice ? (int64_t)slice : row_stride;
-        float qlo = 0.f, qinv = 0.f;
+        float qlo = 0.f, qinv = 0.f, qhi = 0.f;
         int noor = 0;
         const bool q16 = Q16 == 1 && qp->ok != 0;          // unusable bounds (non-finite data): the f32 walk handles the chunk, nothing to emit
         if (q16) {
             qlo = qp->node[c / h].loU;
             qinv = qp->node[c / h].invD;
+            qhi = qp->node[c / h].hiq;
         }
         float vmin = __builtin_inff(), vmax = -__builtin_inff();
 #pragma unroll
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     D[coff + (rbase + row) * rstride] = v;
                     if (q16) {
                         const float qf = rintf((v - qlo) * qinv);
-                        if (!(qf >= 0.0f && qf <= 65535.0f)) { atomicOr(reinterpret_cast<unsigned *>(qflag + ((rbase + row) & ~(int64_t)1)), (1u << (c / h)) << (16 * (int)((rbase + row) & 1))); ++noor; }
+                        if (!(qf >= 0.0f && qf <= qhi)) { atomicOr(reinterpret_cast<unsigned *>(qflag + ((rbase + row) & ~(int64_t)1)), (1u << (c / h)) << (16 * (int)((rbase + row) & 1))); ++noor; }
                         // levels go through an LDS tile so that they leave the chip as 16-byte stores (8 candidates of a row), not 2-byte ones
                         qtile[(wy * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * QLD + wx * 64 + tj * 32 + l31] = (uint16_t)fminf(fmaxf(qf, 0.0f), 65535.0f);
                     }

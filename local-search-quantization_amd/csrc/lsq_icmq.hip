@@ -101,7 +101,7 @@ __global__ __launch_bounds__(64) void q16_params_kernel(const float *__restrict_
         const unsigned kl = qrange[2 * j], kh = qrange[2 * j + 1];
         lsq_q16_node nd;
         for (int k = 0; k < LSQ_MAX_M; ++k) nd.loT[k] = 0.0f;
-        nd.loU = 0.0f; nd.invD = 0.0f; nd.D = 0.0f; nd.window = 65535; nd.lo_sum = 0.0; nd.slack = 0.0;
+        nd.loU = 0.0f; nd.invD = 0.0f; nd.D = 0.0f; nd.hiq = 0.0f; nd.window = 65535; nd.lo_sum = 0.0; nd.slack = 0.0;
         if (kl > kh) { ok = false; P->node[j] = nd; continue; }      // empty sample
         const double sl = (double)__uint_as_float((kl & 0x80000000u) ? (kl ^ 0x80000000u) : ~kl);
         const double sh = (double)__uint_as_float((kh & 0x80000000u) ? (kh ^ 0x80000000u) : ~kh);
@@ -125,6 +125,8 @@ __global__ __launch_bounds__(64) void q16_params_kernel(const float *__restrict_
         const double slack = (double)m * (0.5 + 1.0 / 32.0) * D + eps + 65535.0 * D * 2.384185791015625e-7;      // + the f32 rounding of D and 1/D over 65535 levels
         nd.D = (float)D;
         nd.invD = (float)(1.0 / D);
+        // levels of one sum: U <= hiq, table k <= R_k / D + 1/2  =>  sum <= 65500 + m / 2 + rounding < 65535: packed (and plain 32-bit) adds never carry
+        nd.hiq = (float)fmin(floor((hiU - loU) / D), 65535.0);
         nd.lo_sum = lo_sum;
         nd.slack = slack;
         const double w = 2.0 * slack / D;
@@ -323,10 +325,16 @@ struct WalkqTab {
     static constexpr int PLANE_E = LSQ_H * LPV + (NR > 1 ? 8 : 0), TS_E = NR * PLANE_E;     // 16-byte entries per plane / per table
     __device__ static constexpr int entry(int kk, int code, int c) { return kk * TS_E + (c / LPV) * PLANE_E + code * LPV + (c % LPV); }
     static constexpr int lds_entries(int m) { return (m - 1) * TS_E; }
+    // vectors per block pass with BPC blocks per CU: the slice table + 10 B per vector within the block's share of the 160 KiB
+    static constexpr int pp(int m, int bpc) {
+        const int avail = 160 * 1024 / bpc - 768 - lds_entries(m) * 16;
+        const int v = avail / 10 / 64 * 64;
+        return v > 4096 / bpc ? 4096 / bpc : v;
+    }
 };
 
-template <int M, int SLQ, int CPL, int DEPTH, int NT>
-__global__ __launch_bounds__(NT) void icm_walkq_kernel(const float *__restrict__ U, const uint16_t *__restrict__ Uq, const uint16_t *__restrict__ Tq,
+template <int M, int SLQ, int CPL, int DEPTH, int NT, int BPC>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BPC / 4, NT / 64 * BPC / 4))) void icm_walkq_kernel(const float *__restrict__ U, const uint16_t *__restrict__ Uq, const uint16_t *__restrict__ Tq,
                                                        const float *__restrict__ T, uint8_t *__restrict__ rec, unsigned short *__restrict__ valid,
                                                        int64_t n, const WalkNodes nodes, int per_pass, int use_skip, int direct_max,
                                                        unsigned long long *__restrict__ active_total,
@@ -343,7 +351,7 @@ __global__ __launch_bounds__(NT) void icm_walkq_kernel(const float *__restrict__
     constexpr int RW = CS / 4;
     constexpr int TAB = (M - 1) * LSQ_H * EPR;           // 16-byte entries of one slice table (global)
     constexpr int LTAB = TL::lds_entries(M);             // ... in LDS (planes, skew)
-    constexpr int PP = LSQ_WALK_PP(M, SLQ / 2);          // same LDS budget as the f32 walk with slices of SLQ / 2 floats
+    constexpr int PP = TL::pp(M, BPC);                   // BPC = 1: the f32 walk's geometry (4096 up to m = 14); BPC = 2: two 512-thread blocks share a CU
     if (P->ok == 0) return;                              // non-finite / degenerate bounds: icm_walk_kernel (enqueued next) does this launch's work
 #ifdef LSQ_TUNING
     unsigned long long *dbgp = nullptr;
@@ -440,6 +448,9 @@ __global__ __launch_bounds__(NT) void icm_walkq_kernel(const float *__restrict__
             u32x4 s[NR];
 #pragma unroll
             for (int r = 0; r < NR; ++r) s[r] = cur.u[r];
+            // The two 16-bit halves of a word never carry into each other (the sum of the m levels of a candidate stays below 65536: lsq_q16_node::hiq),
+            // so plain 32-bit adds are exact on the packed levels -- and v_add3_u32 takes two table rows per instruction where v_pk_add_u16 takes one.
+            uint32_t code[M > 1 ? M - 1 : 1];
 #pragma unroll
             for (int w = 0; w < CW; ++w) {
                 const uint32_t hiw = (w + 1 < RW) ? cur.r[w + 1] : 0u;
@@ -448,18 +459,25 @@ __global__ __launch_bounds__(NT) void icm_walkq_kernel(const float *__restrict__
                 for (int t = 0; t < 4; ++t) {
                     const int kk = 4 * w + t;
                     if (kk < M - 1) {
-                        uint32_t code;
-                        if (t == 0) asm("v_and_b32 %0, 0xff, %1" : "=v"(code) : "v"(cw));
-                        else code = (cw >> (8 * t)) & 0xffu;
+                        if (t == 0) asm("v_and_b32 %0, 0xff, %1" : "=v"(code[kk]) : "v"(cw));
+                        else code[kk] = (cw >> (8 * t)) & 0xffu;
+                    }
+                }
+            }
 #ifdef LSQ_TUNING
-                        if (abl & 64) continue;              // ablation: no table rows
+            if (!(abl & 64))                                 // ablation: no table rows
 #endif
 #pragma unroll
-                        for (int r = 0; r < NR; ++r) {
-                            const u32x4 row = tab[kk * TL::TS_E + r * TL::PLANE_E + (int)code * LPV + q];
-                            s[r].x = pk_add_u16(s[r].x, row.x); s[r].y = pk_add_u16(s[r].y, row.y);      // levels add exactly: the sum of the m levels fits 16 bits
-                            s[r].z = pk_add_u16(s[r].z, row.z); s[r].w = pk_add_u16(s[r].w, row.w);
-                        }
+            for (int kk = 0; kk < M - 1; kk += 2) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const u32x4 ra = tab[kk * TL::TS_E + r * TL::PLANE_E + (int)code[kk] * LPV + q];
+                    if (kk + 1 < M - 1) {
+                        const u32x4 rb2 = tab[(kk + 1) * TL::TS_E + r * TL::PLANE_E + (int)code[kk + 1 < M - 1 ? kk + 1 : kk] * LPV + q];
+                        s[r].x = s[r].x + ra.x + rb2.x; s[r].y = s[r].y + ra.y + rb2.y;
+                        s[r].z = s[r].z + ra.z + rb2.z; s[r].w = s[r].w + ra.w + rb2.w;
+                    } else {
+                        s[r].x += ra.x; s[r].y += ra.y; s[r].z += ra.z; s[r].w += ra.w;
                     }
                 }
             }
@@ -749,7 +767,12 @@ extern "C" __attribute__((visibility("default"))) int lsq_tuning_set_walkq_debug
 }
 #endif
 
-int lsq_q16_slice_width(int m) { return 2 * lsq_walk_slice_width(m); }      // candidates per 16-bit slice: the same bytes per piece as the f32 walk
+int lsq_q16_slice_width(int m) {
+#ifdef LSQ_TUNING
+    if (m <= 8 && LSQ_KNOB("LSQ_WALKQ_BPC", 1) == 2) return 16;
+#endif
+    return 2 * lsq_walk_slice_width(m);
+}      // candidates per 16-bit slice: the same bytes per piece as the f32 walk
 
 int lsq_launch_q16_prepare(hipStream_t s, const float *X, int64_t n, int d, const float *K, const float *sci, const float *T, int m, uint16_t *Tq,
                            int *bad, float *trange, unsigned *qrange, unsigned short *qflag, lsq_q16_params *P, int tables_changed) {
@@ -778,21 +801,24 @@ int lsq_launch_q16_prepare(hipStream_t s, const float *X, int64_t n, int d, cons
     return LSQ_OK;
 }
 
-template <int M, int SLQ, int CPL, int DEPTH, int NT>
+template <int M, int SLQ, int CPL, int DEPTH, int NT, int BPC>
 static int launch_walkq_t(hipStream_t s, const float *U, const uint16_t *Uq, const uint16_t *Tq, const float *T, uint8_t *rec, unsigned short *valid,
                           int64_t n, const WalkNodes &nodes, int use_skip, unsigned long long *active_total, int light,
                           const uint8_t *ref_rec, const unsigned short *ref_valid, const lsq_q16_params *P, const unsigned short *qflag) {
-    constexpr int PP = LSQ_WALK_PP(M, SLQ / 2);
+    constexpr int PP = WalkqTab<SLQ, CPL>::pp(M, BPC);
     constexpr int LDS_BYTES = WalkqTab<SLQ, CPL>::lds_entries(M) * 16 + PP * 8 + PP * 2;      // slice table (planes, skew) + two smallest keys + active list
-    static_assert(LDS_BYTES + 256 <= 160 * 1024, "slice table + keys must fit the 160 KiB LDS");
-    int per_pass = 1, npass = 1;
-    lsq_walk_geometry(n, M, &per_pass, &npass, nullptr);
+    static_assert((LDS_BYTES + 768) * BPC <= 160 * 1024, "slice table + keys must fit the block's share of the 160 KiB LDS");
+    constexpr int NBLK = 256 * BPC;
+    const int64_t rounds = (n + NBLK * (int64_t)PP - 1) / (NBLK * (int64_t)PP);      // passes per block
+    int64_t per = rounds > 0 ? (n + NBLK * rounds - 1) / (NBLK * rounds) : 1;
+    per = per > PP ? PP : (per < 1 ? 1 : per);
+    const int per_pass = (int)per, npass = (int)((n + per - 1) / per);
     const int direct_max = light >= 0 ? light : LSQ_KNOB("LSQ_WALK_DIRECT", 160);
     const int skip = (use_skip && valid) ? 1 : 0;
     static LdsOptIn optin;
-    LSQ_TRY(optin_lds(optin, &icm_walkq_kernel<M, SLQ, CPL, DEPTH, NT>, LDS_BYTES));
-    const unsigned grid = (unsigned)(npass < 256 ? npass : 256);
-    hipLaunchKernelGGL((icm_walkq_kernel<M, SLQ, CPL, DEPTH, NT>), dim3(grid), dim3(NT), LDS_BYTES, s, U, Uq, Tq, T, rec, valid, n, nodes, per_pass, skip,
+    LSQ_TRY(optin_lds(optin, &icm_walkq_kernel<M, SLQ, CPL, DEPTH, NT, BPC>, LDS_BYTES));
+    const unsigned grid = (unsigned)(npass < NBLK ? npass : NBLK);
+    hipLaunchKernelGGL((icm_walkq_kernel<M, SLQ, CPL, DEPTH, NT, BPC>), dim3(grid), dim3(NT), LDS_BYTES, s, U, Uq, Tq, T, rec, valid, n, nodes, per_pass, skip,
                        direct_max, active_total, skip ? ref_rec : nullptr, skip ? ref_valid : nullptr, P, lsq_walk_slice_width(M), qflag, LSQ_KNOB("LSQ_Q16_ABL", 0));
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
@@ -814,13 +840,23 @@ int lsq_launch_icm_walkq(hipStream_t s, const float *U, const uint16_t *Uq, cons
             nodes.j[t] = (uint8_t)j;
         }
 #define LSQ_WQ_ARGS s, U, Uq, Tq, T, rec, valid, n, nodes, use_skip, active_total, light, ref_rec, ref_valid, P, qflag
-#define LSQ_WQ_CASE(MM, SLL, CPLL, DD, NTT) case MM: LSQ_TRY((launch_walkq_t<MM, SLL, CPLL, DD, NTT>(LSQ_WQ_ARGS))); break;
+#define LSQ_WQ_CASE(MM, SLL, CPLL, DD, NTT) case MM: LSQ_TRY((launch_walkq_t<MM, SLL, CPLL, DD, NTT, 1>(LSQ_WQ_ARGS))); break;
+#define LSQ_WQ_CASE2(MM, SLL, CPLL, DD, NTT) case MM: LSQ_TRY((launch_walkq_t<MM, SLL, CPLL, DD, NTT, 2>(LSQ_WQ_ARGS))); break;
         // m <= 8: slices of 32 candidates, four lanes per vector (8 candidates per lane); above: slices of 16, two lanes of 8
 #ifdef LSQ_TUNING
         if (m <= 8 && LSQ_KNOB("LSQ_WALKQ_CPL", 8) == 16) {      // two lanes per vector, 16 candidates per lane: 22 % fewer instructions per candidate, dense
             switch (m) {                                          // node updates 7 % faster, sparse ones up to 30 % slower (coarser items): DESIGN.md 4.2
                 LSQ_WQ_CASE(1, 32, 16, 3, 1024) LSQ_WQ_CASE(2, 32, 16, 3, 1024) LSQ_WQ_CASE(3, 32, 16, 3, 1024) LSQ_WQ_CASE(4, 32, 16, 3, 1024)
                 LSQ_WQ_CASE(5, 32, 16, 3, 1024) LSQ_WQ_CASE(6, 32, 16, 3, 1024) LSQ_WQ_CASE(7, 32, 16, 3, 1024) LSQ_WQ_CASE(8, 32, 16, 3, 1024)
+            }
+            continue;
+        }
+#endif
+#ifdef LSQ_TUNING
+        if (m <= 8 && LSQ_KNOB("LSQ_WALKQ_BPC", 1) == 2) {       // two 512-thread blocks per CU, slices of 16 candidates
+            switch (m) {
+                LSQ_WQ_CASE2(1, 16, 8, 3, 512) LSQ_WQ_CASE2(2, 16, 8, 3, 512) LSQ_WQ_CASE2(3, 16, 8, 3, 512) LSQ_WQ_CASE2(4, 16, 8, 3, 512)
+                LSQ_WQ_CASE2(5, 16, 8, 3, 512) LSQ_WQ_CASE2(6, 16, 8, 3, 512) LSQ_WQ_CASE2(7, 16, 8, 3, 512) LSQ_WQ_CASE2(8, 16, 8, 3, 512)
             }
             continue;
         }
@@ -832,6 +868,7 @@ int lsq_launch_icm_walkq(hipStream_t s, const float *U, const uint16_t *Uq, cons
             LSQ_WQ_CASE(13, 16, 8, 2, 1024) LSQ_WQ_CASE(14, 16, 8, 3, 512) LSQ_WQ_CASE(15, 16, 8, 3, 512) LSQ_WQ_CASE(16, 16, 8, 3, 512)
         }
 #undef LSQ_WQ_CASE
+#undef LSQ_WQ_CASE2
 #undef LSQ_WQ_ARGS
     }
     return LSQ_OK;

@@ -82,7 +82,9 @@ __host__ __device__ inline uint32_t lsq_mulhi32(uint32_t a, uint32_t b) { return
 //   s[a] = lo_sum + D * Q[a] up to (0.5 + 2^-5) D per term.  Rigorous consequence (see icm_walkq_kernel): the exact fp32 argmin lies
 //   among the candidates with Q <= Qmin + window.  ok = 0 (non-finite or degenerate bounds) sends the chunk to the fp32 walk instead.
 struct lsq_q16_node {
-    float loU, invD, D;        // U levels cover [loU, loU + 65535 D): the sampled range of U_j widened by 1/8 (vectors outside are flagged); tables use their exact range
+    float loU, invD, D;        // U levels start at loU: the sampled range of U_j widened by 1/8; tables use their exact range
+    float hiq;                 // largest U level of the widened sampled range: a vector with a level outside [0, hiq] is flagged (beyond it the sum of
+                               // the m levels could pass 65535 and wrap)
     int window;                // levels
     double lo_sum;             // loU + SUM_k loT[k]
     double slack;              // bound of |fp32 conditioned sum - real sum| + per-term level error, in s units: m (0.5 + 2^-5) D + eps
