@@ -287,3 +287,20 @@ def test_filter_degenerate_ranges(lsq, oracle):
         Bs, _ = eng.encode_icm(Xk, B0, K, m, [2], 2, 4, True, seed=seed)
     ref, _ = oracle.encode_icm(Xk, B0, K, m, H, [2], 2, 4, True, seed)
     assert np.array_equal(Bs, ref)
+
+
+def test_filter_mild_outliers_are_flagged_before_levels_can_wrap(lsq, oracle):
+    """A unary just above the widened sampled range still has a 16-bit level, but with the table levels on top the sum could pass 65535 and wrap
+    into a small key.  Such vectors must be flagged (lsq_q16_node::hiq), not only the ones whose own level leaves 16 bits."""
+    d, n, m, seed = 16, 40_000, 8, 78
+    rng = np.random.default_rng(seed)
+    X, K, B0 = make_problem(d, n, m, seed=seed, kind="gauss")
+    K = (K * np.float32(2.5)).astype(np.float32)         # table ranges comparable to the unary range: the 16-bit span is much wider than the unaries'
+    flagged = 0
+    for scale in (1.2, 1.45, 1.8):
+        for parity in (0, 1):                            # the sample takes every other 128-vector panel at this n
+            rows = np.array([i for i in rng.choice(n, size=3000, replace=False) if (i // 128) % 2 == parity][:300])
+            Xa = X.copy()
+            Xa[rows] *= np.float32(scale)
+            flagged += _filter_case(lsq, oracle, Xa, K, B0, m, [1], 2, 4, seed)["filter_f32"]
+    assert flagged > 0
