@@ -436,7 +436,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
 #endif
 #pragma unroll
             for (int r = 0; r < NR; ++r) it.u[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(ub + uo + r * (LPV * 16)));
+#ifdef LSQ_TUNING
+            const uint32_t *rp = reinterpret_cast<const uint32_t *>(rb + ((abl & 512) ? (li & 63u) : li) * (uint32_t)CS);      // ablation: records from 64 hot lines
+#else
             const uint32_t *rp = reinterpret_cast<const uint32_t *>(rb + li * (uint32_t)CS);
+#endif
 #pragma unroll
             for (int w = 0; w < RW; ++w) it.r[w] = rp[w];
             if (++lit >= ipw) {
