@@ -292,7 +292,7 @@ __device__ inline int q16_refine(const float *__restrict__ U, const uint16_t *__
         if (act && t16 == 0) {                                            // apply_node_result, its loads done above
             const uint8_t c8 = (uint8_t)bi;
             const uint8_t old = (uint8_t)(rw[j >> 2] >> (8 * (j & 3)));
-            rec[i * CS + j] = c8;
+            if (c8 != old) store_code<CS>(rec, i, j, c8, rw);
             if (valid) {
                 unsigned short vm = (c8 != old) ? (unsigned short)(1u << j) : (unsigned short)(vo | (1u << j));
                 if (have_ref) {
@@ -697,7 +697,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
                     if (von[e]) {
                         const uint8_t c8 = (uint8_t)vcode[e];
                         const uint8_t old = (uint8_t)(rw[e][j >> 2] >> (8 * (j & 3)));
-                        rec[vi[e] * CS + j] = c8;
+                        if (c8 != old) store_code<CS>(rec, vi[e], j, c8, rw[e]);      // an unchanged record is not written
                         if (valid) {
                             unsigned short vm = (c8 != old) ? (unsigned short)(1u << j) : (unsigned short)(vo[e] | (1u << j));
                             if (have_ref) {

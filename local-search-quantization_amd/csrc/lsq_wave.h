@@ -96,6 +96,21 @@ constexpr int lsq_walk_pp(int M, int SL) {
 }
 #define LSQ_WALK_PP(M, SL) lsq_walk_pp(M, SL)
 
+// Code j of vector i changes: the whole record leaves as aligned words (a wave's stores cover whole lines: no byte-masked partial writes);
+// callers skip the store when the code is unchanged.
+template <int CS>
+__device__ inline void store_code(uint8_t *__restrict__ rec, int64_t i, int j, uint8_t code, const uint32_t (&rw)[CS / 4]) {
+    constexpr int RW = CS / 4;
+    uint32_t out[RW];
+#pragma unroll
+    for (int w = 0; w < RW; ++w) out[w] = (w == (j >> 2)) ? ((rw[w] & ~(0xffu << (8 * (j & 3)))) | ((uint32_t)code << (8 * (j & 3)))) : rw[w];
+    if (RW == 2) *reinterpret_cast<uint64_t *>(rec + i * CS) = (uint64_t)out[0] | ((uint64_t)out[1] << 32);
+    else {
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<u32x4_t *>(rec + i * CS) = (u32x4_t){out[0], out[RW > 1 ? 1 : 0], out[RW > 2 ? 2 : 0], out[RW > 3 ? 3 : 0]};
+    }
+}
+
 // Validity is a property of the code tuple alone ("code j is the first argmin of node j given the other codes").  When the
 // candidate tuple, after node j took `code`, equals the vector's CURRENT tuple (the state the ILS iteration started from, whose
 // validity bits were established earlier and are read-only during the sweeps), everything known about that tuple holds for
@@ -127,7 +142,7 @@ __device__ inline void apply_node_result(uint8_t *__restrict__ rec, unsigned sho
 #pragma unroll
     for (int w2 = 0; w2 < RW; ++w2) rw[w2] = reinterpret_cast<const uint32_t *>(rec + i * CS)[w2];
     const uint8_t old = (uint8_t)(rw[j >> 2] >> (8 * (j & 3)));
-    rec[i * CS + j] = code;
+    if (code != old) store_code<CS>(rec, i, j, code, rw);
     if (valid) {
         unsigned short vm = (code != old) ? (unsigned short)(1u << j) : (unsigned short)(valid[i] | (1u << j));
         vm = (unsigned short)(vm | known_valid<RW>(rw, j, code, ref_rec ? ref_rec + i * CS : nullptr, ref_valid ? ref_valid + i : nullptr));
@@ -164,7 +179,7 @@ __device__ inline void apply_node_results(uint8_t *__restrict__ rec, unsigned sh
         if (!on[e]) continue;
         const uint8_t c8 = (uint8_t)(code[e] > 255u ? 0u : code[e]);
         const uint8_t old = (uint8_t)(rw[e][j >> 2] >> (8 * (j & 3)));
-        rec[idx[e] * CS + j] = c8;
+        if (c8 != old) store_code<CS>(rec, idx[e], j, c8, rw[e]);
         if (valid) {
             unsigned short vm = (c8 != old) ? (unsigned short)(1u << j) : (unsigned short)(vo[e] | (1u << j));
             if (have_ref) {
@@ -229,7 +244,12 @@ __device__ inline void light_update(uint8_t *__restrict__ rec, unsigned short *_
             for (int kk = 0; kk < M - 1; ++kk) s[e] = s[e] + c[e][kk];      // ascending k, plain f32 adds
             const uint8_t code = (uint8_t)wave_first_argmin(s[e], lane);
             if (lane == 0) {
-                rec[vi[e] * CS + j] = code;
+                if (code != cr[e].get(j)) {
+                    CodeRec mine = cr[e];
+                    mine.set(j, code);
+                    *reinterpret_cast<uint64_t *>(rec + vi[e] * CS) = mine.lo;
+                    if (RW == 4) *reinterpret_cast<uint64_t *>(rec + vi[e] * CS + 8) = mine.hi;
+                }
                 if (valid) {
                     unsigned short vm = (code != cr[e].get(j)) ? (unsigned short)(1u << j) : (unsigned short)(vo[e] | (1u << j));
                     if (have_ref) {
