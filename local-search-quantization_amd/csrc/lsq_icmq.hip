@@ -869,7 +869,7 @@ int lsq_launch_icm_walkq(hipStream_t s, const float *U, const uint16_t *Uq, cons
             LSQ_WQ_CASE(1, 32, 8, 3, 1024) LSQ_WQ_CASE(2, 32, 8, 3, 1024) LSQ_WQ_CASE(3, 32, 8, 3, 1024) LSQ_WQ_CASE(4, 32, 8, 3, 1024)
             LSQ_WQ_CASE(5, 32, 8, 3, 1024) LSQ_WQ_CASE(6, 32, 8, 3, 1024) LSQ_WQ_CASE(7, 32, 8, 3, 1024) LSQ_WQ_CASE(8, 32, 8, 3, 1024)
             LSQ_WQ_CASE(9, 16, 8, 2, 1024) LSQ_WQ_CASE(10, 16, 8, 2, 1024) LSQ_WQ_CASE(11, 16, 8, 2, 1024) LSQ_WQ_CASE(12, 16, 8, 2, 1024)
-            LSQ_WQ_CASE(13, 16, 8, 2, 1024) LSQ_WQ_CASE(14, 16, 8, 3, 512) LSQ_WQ_CASE(15, 16, 8, 3, 512) LSQ_WQ_CASE(16, 16, 8, 3, 512)
+            LSQ_WQ_CASE(13, 16, 8, 2, 1024) LSQ_WQ_CASE(14, 16, 8, 2, 1024) LSQ_WQ_CASE(15, 16, 8, 2, 1024) LSQ_WQ_CASE(16, 16, 8, 2, 1024)
         }
 #undef LSQ_WQ_CASE
 #undef LSQ_WQ_CASE2
