@@ -1,0 +1,25 @@
+#!/bin/bash
+# tools/final_round.sh TAG -- run ON THE GPU BOX (through gpurun), from the repo root: everything DESIGN.md / BASELINE.md quote for one build.
+#   gpurun_out/final_TAG/  <- profile_round.sh (stats + PMC + bench line), the other BASELINE configs on one GPU, the shape sweep,
+#                             the per-sweep breakdown, the in-kernel phase / per-node timings (tuning build), the LDS micro-benchmark
+set -u
+TAG=${1:-rXX}
+R=$(pwd)
+O=$R/gpurun_out/final_$TAG
+mkdir -p "$O"
+bash tools/profile_round.sh "$TAG" > "$O/profile_round.log" 2>&1
+cp gpurun_out/prof_$TAG/${TAG}_bench_kernel_stats.csv gpurun_out/prof_$TAG/${TAG}_pmc_per_kernel.json gpurun_out/prof_$TAG/${TAG}_bench_line.json "$O/" 2>/dev/null
+B="python bench.py --no-cpu-baseline --steps 5"
+$B --codebooks 16 > "$O/${TAG}_bench_cfg3.json" 2> "$O/cfg3.err"
+$B --scaling strong --total 125000 --dim 960 > "$O/${TAG}_bench_cfg4_share.json" 2> "$O/cfg4.err"
+$B --vectors 12500000 --steps 2 --no-extra-legs > "$O/${TAG}_bench_cfg5_share.json" 2> "$O/cfg5.err"
+LSQ_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 \
+    --scaling strong --total 250000 --dim 960 --steps 3 --no-cpu-baseline > "$O/${TAG}_bench_cfg4_2rank_1gpu_gloo.json" 2> "$O/gloo.err"
+python tools/sched_cmp.py > "$O/sched_cmp.log" 2>&1 && cp gpurun_out/r02g/sched_cmp.json "$O/${TAG}_schedule6_vs_4_shapes.json"
+LSQ_SB_SCHEDULE=6 python tools/sweep_breakdown.py "$O/sb6" > "$O/sb6.log" 2>&1 && cp "$O/sb6/sweep_breakdown.json" "$O/${TAG}_sweep_breakdown_schedule6_per_node.json"
+{ echo "== one launch per node update (phases of block 0)"; python tools/walkq_phases.py 1000000 1 0 2>&1 | tail -66;
+  echo "== production schedule (one launch per ILS iteration): active count : microseconds per node update of block 0"; python tools/walkq_phases.py 1000000 0 160 2>&1 | tail -4;
+  echo "== 125 000 vectors, production schedule"; python tools/walkq_phases.py 125000 0 160 2>&1 | tail -4; } > "$O/${TAG}_walkq_phases.txt"
+[ -x tools/bin/ubench_lds ] && tools/bin/ubench_lds > "$O/ubench_lds_${TAG}.txt" 2>&1
+find "$O" -name "*.csv" -size +4M -delete
+ls -la "$O"
