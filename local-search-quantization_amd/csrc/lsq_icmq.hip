@@ -7,16 +7,16 @@
 // second-best candidate differ by ~6000 while the values span ~10^6.  So:
 //
 //   FILTER   every term is also stored as a 16-bit level on ONE common step D_j per node (lsq_q16_params): U by the GEMM epilogue
-//            (Uq, slice-major u16), the pair tables by tables_to_q16_slices_kernel (Tq).  The levels of a candidate are summed with
-//            packed 16-bit adds, Q[a] = qU[a] + SUM_k qT_k[a] <= 65535 by construction, two candidates per VALU lane-op, 512 B of
-//            unaries and (m-1) x 512 B of table rows per vector and node.  A wave tracks the two smallest keys (Q << 16 | a).
+//            (Uq, slice-major u16), the pair tables by tables_to_q16_slices_kernel (Tq).  The levels of a candidate are summed as
+//            packed pairs, Q[a] = qU[a] + SUM_k qT_k[a] < 65536 by construction (lsq_q16_node::hiq), so plain 32-bit three-operand
+//            adds are exact: 512 B of unaries and (m-1) x 512 B of table rows per vector and node.  A wave tracks the two smallest keys.
 //   BOUND    |lo_sum + D Q[a] - s_f32[a]| <= slack := m (0.5 + 2^-5) D + eps_f32  for every candidate (rounding of each level,
 //            rounding of the f32 chain).  Hence the exact argmin a* obeys  Q[a*] <= Qmin + window,  window = floor(2 slack / D) + 1.
-//   REFINE   second - best > window: the best key IS the exact argmin (>= 98 % of the node updates).  Otherwise both candidates are
-//            evaluated EXACTLY (the f32 unaries the GEMM also wrote, the f32 tables, canonical order), and every other candidate c
-//            has s_f32[c] >= lo_sum + D (Q_second - m (0.5 + 2^-5)) - eps =: L3; if L3 > min(e1, e2) the lexicographic
-//            (value, index) minimum of the two is the answer, else (third candidate in reach, < 0.1 %) the vector is redone by
-//            one wave in full f32 (the light-block routine).
+//   REFINE   second - best > window: the best key IS the exact argmin (>= 98 % of the node updates).  Otherwise (q16_refine) every
+//            candidate whose level sum lies within the window of the best -- the SURVIVORS: they provably contain the exact argmin
+//            and all its exact ties -- is evaluated EXACTLY (the f32 unaries the GEMM also wrote, the f32 tables, canonical order)
+//            and the lexicographic (value, index) minimum is taken: the reference's strict-< scan.  Vectors with a unary outside
+//            the sampled level range are flagged by the GEMM and take the full-f32 routine (one wave per vector).
 // Non-finite inputs / degenerate ranges set params.ok = 0 and the launch leaves the chunk to icm_walk_kernel (both are enqueued;
 // exactly one of them works).  Parity: every test that compares icm_walk_kernel with the oracle also runs this kernel.
 #include <stdlib.h>
