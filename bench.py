@@ -337,6 +337,12 @@ def main():
         if tr is not None:
             roof["traffic"] = tr["bytes_per_icm_launch"]
             roof["traffic_source"] = tr
+            if avg_launch_s > 0:
+                # the rate at which the kernel's MEASURED traffic moves (profiled launch bytes / live launch time): how close the launch as a
+                # whole is to the memory system's limit, whatever fraction of those bytes was algorithmically necessary
+                roof["traffic_rate"] = {"value": tr["bytes_per_icm_launch"] / avg_launch_s / 1e9, "unit": "GB/s",
+                                        "frac_of_peak": tr["bytes_per_icm_launch"] / avg_launch_s / 1e9 / HBM_PEAK_GBS,
+                                        "frac_of_achievable_6300": tr["bytes_per_icm_launch"] / avg_launch_s / 1e9 / HBM_ACHIEVABLE_GBS}
         workload = ("BASELINE configs[1]" if (d, m, args.scaling, n) == (128, 8, "weak", 1_000_000) else
                     "BASELINE configs[2]" if (d, m, args.scaling, n) == (128, 16, "weak", 1_000_000) else
                     "BASELINE configs[3]" if (d, m, args.scaling) == (960, 8, "strong") else
