@@ -324,7 +324,7 @@ def main():
             "data_flow": "M2 (SURVEY 8(d)): the unary row of a node is re-read from HBM at every recomputed node update -- as 16-bit levels (512 B) by "
                          "the filtered walk, as f32 (1 KiB) by the f32 walk; `achieved` counts only node updates that were actually recomputed (memoised "
                          "ones move no bytes).  It is a fraction of the traffic this design chose to create, not of the compulsory bytes -- see "
-                         "m1_compulsory.  The filtered walk is bound by instruction issue in its slice loop (removing every LDS read changes nothing, removing VALU work shortens it in proportion) with its measured traffic already at ~5 TB/s of the ~6.3 TB/s a streaming kernel reaches on this part (DESIGN 4.2).",
+                         "m1_compulsory.  The filtered walk's slice loop was bound by VALU issue (removing every LDS read changed nothing, removing VALU work shortened it); after the instruction-count work of round 2 its measured traffic moves at ~5.1 TB/s of the ~6.3 TB/s a streaming kernel reaches on this part (traffic_rate below): the launch is HBM-bound on the bytes it creates, 1.5x the algorithmic ones (DESIGN 4.2).",
             "gather": {"achieved": table_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0, "peak": LDS_PEAK_GBS, "unit": "GB/s",
                        "frac": (table_bytes / avg_launch_s / 1e9 / LDS_PEAK_GBS) if avg_launch_s > 0 else 0.0,
                        "note": "(m-1) pair-table rows per recomputed node update (512 B each as u16 levels, 1 KiB as f32), read from LDS-staged slices with "
