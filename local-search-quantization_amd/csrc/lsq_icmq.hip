@@ -32,6 +32,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ unsigned long long *g_walkq_dbg = nullptr;      // [launch slot][block][16] timestamps (tools only)
 __device__ unsigned int g_walkq_dbg_slot = 0;
 __device__ unsigned long long *g_walkq_dbg_cur = nullptr;   // block 0's record of the running launch (for q16_refine's stamps)
+__device__ unsigned long long *g_walkq_blk = nullptr;       // [block][2] start / end clock of every block of the latest launch (tools only: launch tails)
 #define LSQ_WALKQ_DBG_WORDS (24 + 2 * 65)                  // 24 phase stamps of the launch's last node, then start clock / active count of every node + the end clock
 #define DBG_STAMP(k) do { if (dbgp && threadIdx.x == 0) dbgp[k] = wall_clock64(); } while (0)
 #else
@@ -364,6 +365,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
     }
     DBG_STAMP(0);
     if (blockIdx.x == 0 && threadIdx.x == 0) g_walkq_dbg_cur = dbgp;
+    if (g_walkq_blk && threadIdx.x == 0) g_walkq_blk[2 * blockIdx.x] = wall_clock64();
 #endif
     extern __shared__ u32x4 lds_walkq[];
     u32x4 *tab = lds_walkq;
@@ -753,6 +755,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
     __syncthreads();
 #ifdef LSQ_TUNING
     if (dbgp && threadIdx.x == 0) dbgp[24 + 64] = wall_clock64();
+    if (g_walkq_blk && threadIdx.x == 0) g_walkq_blk[2 * blockIdx.x + 1] = wall_clock64();
 #endif
     if (active_total)
         for (int e = threadIdx.x; e < LSQ_WALK_COUNTERS; e += NT)
@@ -767,6 +770,11 @@ extern "C" __attribute__((visibility("default"))) int lsq_tuning_set_walkq_debug
     unsigned zero = 0;
     LSQ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_walkq_dbg), &buf, sizeof(buf)));
     LSQ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_walkq_dbg_slot), &zero, sizeof(zero)));
+    return LSQ_OK;
+}
+// tools only: device buffer of 512 x 2 u64: start / end clock (wall_clock64, 100 MHz) of every block of the latest icm_walkq_kernel launch
+extern "C" __attribute__((visibility("default"))) int lsq_tuning_set_walkq_block_clock(void *buf) {
+    LSQ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_walkq_blk), &buf, sizeof(buf)));
     return LSQ_OK;
 }
 #endif
