@@ -419,21 +419,24 @@ static int encode_chunk(lsq_ctx *c, const float *dXc, const float *dK, int64_t c
     uint8_t *cur = c->recCur.as<uint8_t>(), *nw = c->recNew.as<uint8_t>();
     float *prev = c->prev.as<float>();
     unsigned long long *counters = c->counters.as<unsigned long long>();
+    // The perturbation of ILS iteration t (encode_icm.jl:55-70) rides on the exit of the cost kernel that precedes it: every lane there knows
+    // its vector's final record and validity word, so the copy-and-perturb pass over the records and its launch are gone (lsq_perturb stays
+    // as the stand-alone entry point).
+    lsq_perturb_next pn;
+    pn.on = 1; pn.m = P.m; pn.npert = P.npert; pn.seed = P.seed; pn.goff = goff; pn.dst = nw; pn.vdst = vnew;
     {
         Timer t(c, CAT_COST);
-        LSQ_TRY(lsq_launch_cost(c->stream, dXc, dK, cur, cur, prev, counters, cn, P.d, P.m, 0, nullptr, nullptr));   // encode_icm.jl:149
+        pn.it = P.it0;
+        LSQ_TRY(lsq_launch_cost(c->stream, dXc, dK, cur, cur, prev, counters, cn, P.d, P.m, 0, nullptr, vcur, I > 0 ? &pn : nullptr));   // encode_icm.jl:149
     }
     for (int64_t it = 0; it < I; ++it) {
         int32_t order[LSQ_MAX_M];
         LSQ_TRY(lsq_node_order(P.seed, P.it0 + (uint32_t)it, P.m, P.randord, order));
-        {
-            Timer t(c, CAT_PERTURB);
-            LSQ_TRY(lsq_launch_perturb(c->stream, cur, nw, cn, P.m, P.npert, P.seed, P.it0 + (uint32_t)it, goff, vcur, vnew));
-        }
         LSQ_TRY(run_sweeps(c, nw, vnew, cn, P.m, order, P.icmiter, cur, vcur));
         {
             Timer t(c, CAT_COST);
-            LSQ_TRY(lsq_launch_cost(c->stream, dXc, dK, nw, cur, prev, counters + 2 * it, cn, P.d, P.m, 1, vnew, vcur));
+            pn.it = P.it0 + (uint32_t)it + 1u;
+            LSQ_TRY(lsq_launch_cost(c->stream, dXc, dK, nw, cur, prev, counters + 2 * it, cn, P.d, P.m, 1, vnew, vcur, it + 1 < I ? &pn : nullptr));
         }
         for (int r = 0; r < P.nr; ++r)
             if (P.ilsiters[r] == it + 1) {

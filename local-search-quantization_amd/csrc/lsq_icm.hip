@@ -325,19 +325,10 @@ __global__ __launch_bounds__(256) void tables_to_slices_kernel(const float *__re
         *reinterpret_cast<const f32x4 *>(T + (((int64_t)j * m + k) * LSQ_H + b) * LSQ_H + slice * SL + qq * 4);
 }
 
-// ---- perturbation (cudautils.cu:27-80 / encode_icm.jl:55-70), one thread per vector ------------
-template <int CS>
-__global__ __launch_bounds__(256) void perturb_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int64_t n,
-                                                      int m, int npert, uint64_t seed, uint32_t it, uint64_t goff,
-                                                      const unsigned short *__restrict__ vsrc, unsigned short *__restrict__ vdst) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint64_t w[2];
-    const uint64_t *p = reinterpret_cast<const uint64_t *>(src + i * CS);
-    w[0] = p[0];
-    w[1] = (CS == 16) ? p[1] : 0ull;
+// ---- perturbation (cudautils.cu:27-80 / encode_icm.jl:55-70) ------------------------------------
+// npert distinct positions (selection sampling, ascending) of the record w get uniform codes; Philox keyed by (seed, global index, ILS iteration)
+__device__ inline bool perturb_record(uint64_t (&w)[2], int m, int npert, uint64_t seed, uint32_t it, uint64_t gi) {
     int need = npert < m ? npert : m;
-    const uint64_t gi = goff + (uint64_t)i;
     lsq_u32x4 sel = {{0, 0, 0, 0}};
     bool changed = false;
     for (int pp = 0; pp < m && need > 0; ++pp) {
@@ -352,6 +343,34 @@ __global__ __launch_bounds__(256) void perturb_kernel(const uint8_t *__restrict_
             --need;
         }
     }
+    return changed;
+}
+
+// The cost kernels can perturb for the NEXT ILS iteration on their way out (lsq_perturb_next::on): the lane that looked at vector i knows its
+// final record (accepted candidate or current one) and validity word, so the separate pass over the records and its launch disappear.
+template <int CS>
+__device__ inline void perturb_next_store(const lsq_perturb_next &pn, int64_t i, const uint32_t (&fin)[CS / 4], unsigned short vfin) {
+    uint64_t w[2];
+    w[0] = (uint64_t)fin[0] | ((uint64_t)fin[1] << 32);
+    w[1] = (CS == 16) ? ((uint64_t)fin[CS / 4 - 2] | ((uint64_t)fin[CS / 4 - 1] << 32)) : 0ull;
+    const bool changed = perturb_record(w, pn.m, pn.npert, pn.seed, pn.it, pn.goff + (uint64_t)i);
+    uint64_t *q = reinterpret_cast<uint64_t *>(pn.dst + i * CS);
+    q[0] = w[0];
+    if (CS == 16) q[1] = w[1];
+    if (pn.vdst) pn.vdst[i] = changed ? (unsigned short)0 : vfin;      // a changed code invalidates every node
+}
+
+template <int CS>
+__global__ __launch_bounds__(256) void perturb_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int64_t n,
+                                                      int m, int npert, uint64_t seed, uint32_t it, uint64_t goff,
+                                                      const unsigned short *__restrict__ vsrc, unsigned short *__restrict__ vdst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t w[2];
+    const uint64_t *p = reinterpret_cast<const uint64_t *>(src + i * CS);
+    w[0] = p[0];
+    w[1] = (CS == 16) ? p[1] : 0ull;
+    const bool changed = perturb_record(w, m, npert, seed, it, goff + (uint64_t)i);
     uint64_t *q = reinterpret_cast<uint64_t *>(dst + i * CS);
     q[0] = w[0];
     if (CS == 16) q[1] = w[1];
@@ -366,7 +385,7 @@ template <int M>
 __global__ __launch_bounds__(256) void cost_kernel(const float *__restrict__ X, const float *__restrict__ K,
                                                    const uint8_t *rec, uint8_t *cur, float *__restrict__ prev,
                                                    unsigned long long *__restrict__ counters, int64_t n, int d, int mode,
-                                                   const unsigned short *__restrict__ vnew, unsigned short *__restrict__ vcur) {
+                                                   const unsigned short *vnew, unsigned short *vcur, const lsq_perturb_next pn) {
     constexpr int CS = (M <= 8) ? 8 : 16;
     constexpr int RW = CS / 4;
     constexpr int NV = 2;                     // vectors in flight per wave (memory-level parallelism)
@@ -382,17 +401,21 @@ __global__ __launch_bounds__(256) void cost_kernel(const float *__restrict__ X, 
         const int64_t il = base + lane;
         const bool live = il < n;
         const int64_t ic = live ? il : n - 1;
-        uint32_t rn[RW];
+        uint32_t rn[RW], cw[RW];
         bool same = (mode == 1);
 #pragma unroll
         for (int q = 0; q < RW; ++q) {
             rn[q] = reinterpret_cast<const uint32_t *>(rec + ic * CS)[q];
-            if (mode == 1) same = same && (rn[q] == reinterpret_cast<const uint32_t *>(cur + ic * CS)[q]);
+            cw[q] = (mode == 1) ? reinterpret_cast<const uint32_t *>(cur + ic * CS)[q] : rn[q];
+            same = same && (rn[q] == cw[q]);
         }
         const float pl = (mode == 1) ? prev[ic] : 0.0f;
         const bool skip = live && same && (pl == pl);
         n_eq += (unsigned)__popcll(__ballot(skip)) * (lane == 0 ? 1u : 0u);
-        if (same && live && vcur) vcur[il] = (unsigned short)(vcur[il] | vnew[il]);      // same tuple: what the sweeps learnt about it is kept
+        unsigned short vfin = (live && vcur) ? vcur[il] : (unsigned short)0;       // the vector's validity word after this kernel (for the fused perturbation)
+        const unsigned short vn = (live && vcur && mode == 1) ? vnew[il] : (unsigned short)0;
+        if (same && live && vcur) { vfin = (unsigned short)(vfin | vn); vcur[il] = vfin; }      // same tuple: what the sweeps learnt about it is kept
+        uint64_t accepted = 0;                                                       // bit l: the candidate of vector base + l replaced the current record
         uint64_t todo = __ballot(live && !skip);
         while (todo) {
             CodeRec cr[NV];
@@ -442,6 +465,7 @@ __global__ __launch_bounds__(256) void cost_kernel(const float *__restrict__ X, 
                     const float pc = pcv[v];
                     if (lane == 0) n_eq += (cost == pc);
                     if (cost < pc) {                                          // strict improvement only (encode_icm.jl:183-186)
+                        accepted |= 1ull << (int)(ii[v] - base);
                         if (lane == 0) {
                             ++n_lt;
                             prev[ii[v]] = cost;
@@ -453,6 +477,13 @@ __global__ __launch_bounds__(256) void cost_kernel(const float *__restrict__ X, 
                     }
                 }
             }
+        }
+        if (pn.on && live) {
+            const bool acc = (accepted >> lane) & 1ull;
+            uint32_t fin[RW];
+#pragma unroll
+            for (int q = 0; q < RW; ++q) fin[q] = acc ? rn[q] : cw[q];
+            perturb_next_store<CS>(pn, il, fin, acc ? vn : vfin);
         }
     }
     if (mode == 1 && lane == 0 && (n_eq | n_lt)) {
@@ -472,7 +503,7 @@ template <int M>
 __global__ __launch_bounds__(256) void cost2_kernel(const float *__restrict__ X, const float *__restrict__ K,
                                                     const uint8_t *rec, uint8_t *cur, float *__restrict__ prev,
                                                     unsigned long long *__restrict__ counters, int64_t n, int d, int mode,
-                                                    const unsigned short *__restrict__ vnew, unsigned short *__restrict__ vcur) {
+                                                    const unsigned short *vnew, unsigned short *vcur, const lsq_perturb_next pn) {
     constexpr int CS = (M <= 8) ? 8 : 16;
     constexpr int RW = CS / 4;
     const int lane = threadIdx.x & 63;
@@ -486,18 +517,22 @@ __global__ __launch_bounds__(256) void cost2_kernel(const float *__restrict__ X,
         const int64_t il = base + lane;
         const bool livel = il < n;
         const int64_t ic = livel ? il : n - 1;
-        uint32_t rn[RW];
+        uint32_t rn[RW], cw[RW];
         bool same = (mode == 1);
 #pragma unroll
         for (int q = 0; q < RW; ++q) {
             rn[q] = reinterpret_cast<const uint32_t *>(rec + ic * CS)[q];
-            if (mode == 1) same = same && (rn[q] == reinterpret_cast<const uint32_t *>(cur + ic * CS)[q]);
+            cw[q] = (mode == 1) ? reinterpret_cast<const uint32_t *>(cur + ic * CS)[q] : rn[q];
+            same = same && (rn[q] == cw[q]);
         }
         const float pl = (mode == 1) ? prev[ic] : 0.0f;
         const bool skip = livel && same && (pl == pl);
         const unsigned nskip = (unsigned)__popcll(__ballot(skip));              // all lanes vote, lane 0 keeps the wave's counters
         if (lane == 0) n_eq += nskip;
-        if (same && livel && vcur) vcur[il] = (unsigned short)(vcur[il] | vnew[il]);     // same tuple: what the sweeps learnt about it is kept
+        unsigned short vfin = (livel && vcur) ? vcur[il] : (unsigned short)0;      // the vector's validity word after this kernel (for the fused perturbation)
+        const unsigned short vn = (livel && vcur && mode == 1) ? vnew[il] : (unsigned short)0;
+        if (same && livel && vcur) { vfin = (unsigned short)(vfin | vn); vcur[il] = vfin; }     // same tuple: what the sweeps learnt about it is kept
+        uint64_t accepted = 0;                                                      // bit l: the candidate of vector base + l replaced the current record
         uint64_t todo = __ballot(livel && !skip);
         while (todo) {
             const int sa = __builtin_ctzll(todo);
@@ -555,7 +590,9 @@ __global__ __launch_bounds__(256) void cost2_kernel(const float *__restrict__ X,
                 if (live && lp == 0) prev[i] = cost;
             } else {
                 const bool eq = live && (cost == pc), lt = live && (cost < pc);          // strict improvement only (encode_icm.jl:183-186)
-                const unsigned ne = (unsigned)__popcll(__ballot(eq && lp == 0)), nl = (unsigned)__popcll(__ballot(lt && lp == 0));
+                const uint64_t bl = __ballot(lt && lp == 0);                              // bit 0: first half's vector (sa), bit 32: second half's (sb)
+                const unsigned ne = (unsigned)__popcll(__ballot(eq && lp == 0)), nl = (unsigned)__popcll(bl);
+                accepted |= ((bl & 1ull) ? 1ull << sa : 0ull) | (((bl >> 32) & 1ull) ? 1ull << sb : 0ull);
                 if (lane == 0) { n_eq += ne; n_lt += nl; }
                 if (lt && lp == 0) {
                     prev[i] = cost;
@@ -565,6 +602,13 @@ __global__ __launch_bounds__(256) void cost2_kernel(const float *__restrict__ X,
                     if (vcur) vcur[i] = vnew[i];
                 }
             }
+        }
+        if (pn.on && livel) {
+            const bool acc = (accepted >> lane) & 1ull;
+            uint32_t fin[RW];
+#pragma unroll
+            for (int q = 0; q < RW; ++q) fin[q] = acc ? rn[q] : cw[q];
+            perturb_next_store<CS>(pn, il, fin, acc ? vn : vfin);
         }
     }
     if (mode == 1 && lane == 0 && (n_eq | n_lt)) {
@@ -792,14 +836,17 @@ int lsq_launch_perturb(hipStream_t s, const uint8_t *src, uint8_t *dst, int64_t 
 }
 
 int lsq_launch_cost(hipStream_t s, const float *X, const float *K, const uint8_t *rec, uint8_t *cur, float *prev,
-                    unsigned long long *counters, int64_t n, int d, int m, int mode, const unsigned short *vnew, unsigned short *vcur) {
+                    unsigned long long *counters, int64_t n, int d, int m, int mode, const unsigned short *vnew, unsigned short *vcur,
+                    const lsq_perturb_next *next) {
     if (n <= 0) return LSQ_OK;
+    lsq_perturb_next pn = {};
+    if (next) pn = *next;
     const int use_v2 = LSQ_KNOB("LSQ_COST_V2", 1);
     // half a wave per vector with 8-byte loads: measured 13 % faster at d = 128, 7 % slower at d = 960 (same box)
     if (use_v2 && d % 2 == 0 && d <= 256 && ((uintptr_t)X | (uintptr_t)K) % 8 == 0) {
-        LSQ_DISPATCH_M(m, hipLaunchKernelGGL(cost2_kernel<M_>, dim3(wave_grid((n + 1) / 2)), dim3(256), 0, s, X, K, rec, cur, prev, counters, n, d, mode, vnew, vcur));
+        LSQ_DISPATCH_M(m, hipLaunchKernelGGL(cost2_kernel<M_>, dim3(wave_grid((n + 1) / 2)), dim3(256), 0, s, X, K, rec, cur, prev, counters, n, d, mode, vnew, vcur, pn));
     } else {
-        LSQ_DISPATCH_M(m, hipLaunchKernelGGL(cost_kernel<M_>, dim3(wave_grid((n + 1) / 2)), dim3(256), 0, s, X, K, rec, cur, prev, counters, n, d, mode, vnew, vcur));
+        LSQ_DISPATCH_M(m, hipLaunchKernelGGL(cost_kernel<M_>, dim3(wave_grid((n + 1) / 2)), dim3(256), 0, s, X, K, rec, cur, prev, counters, n, d, mode, vnew, vcur, pn));
     }
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;

@@ -164,9 +164,13 @@ int lsq_launch_icm_walkq(hipStream_t s, const float *U, const uint16_t *Uq, cons
 // light: blocks with <= light active vectors gather table columns from L2 instead of staging slices (-1 = default 256)
 // cost of `rec`; mode 0: prev[i] = cost.  mode 1 (accept): if cost < prev[i] { cur[i] = rec[i]; prev[i] = cost }
 // and counters[0] += (#cost == prev), counters[1] += (#cost < prev)   (counters: 2 x uint64 on device)
+// perturbation for the NEXT ILS iteration fused into the cost kernel's exit (on = 0: none): dst / vdst receive the perturbed copy of every vector's
+// final record / validity word (dst may be the candidate array the kernel has just judged)
+struct lsq_perturb_next { int on; int m, npert; uint32_t it; uint64_t seed, goff; uint8_t *dst; unsigned short *vdst; };
 int lsq_launch_cost(hipStream_t s, const float *X, const float *K, const uint8_t *rec, uint8_t *cur, float *prev,
                     unsigned long long *counters, int64_t n, int d, int m, int mode,
-                    const unsigned short *vnew, unsigned short *vcur);      // accept also copies the validity mask
+                    const unsigned short *vnew, unsigned short *vcur,
+                    const lsq_perturb_next *next = nullptr);      // accept also copies the validity mask
 // *sum += SUM_i v[i]  (f64)
 int lsq_launch_sum_f64(hipStream_t s, const float *v, int64_t n, double *sum);
 
