@@ -793,11 +793,12 @@ int lsq_launch_q16_prepare(hipStream_t s, const float *X, int64_t n, int d, cons
         LSQ_HIP(hipMemsetAsync(bad, 0, sizeof(int), s));
         if (m > 1) hipLaunchKernelGGL(table_range_kernel, dim3((unsigned)(m * m)), dim3(256), 0, s, T, m, trange, bad);
     }
-    // sampled range of the unaries: about 16 384 vectors (every rts-th panel of 128 consecutive ones) through the range-only GEMM pass
+    // sampled range of the unaries: about 16 384 vectors at d <= 128 (every rts-th panel of 128 consecutive ones) through the range-only GEMM pass
     LSQ_HIP(hipMemsetAsync(qrange, 0, sizeof(unsigned) * (2 * LSQ_MAX_M + 1), s));
     for (int j = 0; j < m; ++j) LSQ_HIP(hipMemsetAsync(qrange + 2 * j, 0xff, sizeof(unsigned), s));      // min slots start at the largest key
     if (n > 0) {
-        const int rts = n > 16384 ? (int)(n / 16384) : 1;
+        const int64_t nsample = d <= 128 ? 16384 : (d <= 512 ? 8192 : 4096);      // the pass costs 2 d m h flops per sampled vector: fewer of them at large d
+        const int rts = n > nsample ? (int)(n / nsample) : 1;
         LSQ_TRY(lsq_launch_chain_gemm(s, X, K, sci, -2.0f, n, m * LSQ_H, d, LSQ_H, 0, 0, nullptr, 0, n, 0, nullptr, 0, nullptr, 0, nullptr, qrange, rts));
         LSQ_HIP(hipMemsetAsync(qflag, 0, sizeof(unsigned short) * (size_t)((n + 1) & ~(int64_t)1), s));
     }
