@@ -108,6 +108,9 @@ LSQ_API int lsq_set_stream(lsq_ctx *ctx, void *hip_stream);
  *   "light" (default 160 in the filtered walk, 256 in the f32 walk: the measured crossovers): a block with at most this many active vectors
  *        gathers f32 table columns straight from L2 (one wave per vector, two vectors in flight) instead of staging slices through LDS;
  *        0 = always stage.  Same codes.
+ *   "wave_max" (default 64): a chunk with at most this many vectors per block of the walk kernel (n <= 256 x 64) -- all of them light -- runs
+ *        icm_wave_kernel instead: a wave owns its two vectors through every node update of the launch (records and validity words in registers,
+ *        no compaction, no barriers); 0 = never.  Same codes.
  *   "fallback" (0/1, default 1): a candidate whose codes become equal to the vector's current codes inherits the current state's validity
  *        bits (validity depends on the code tuple only): exact, ~12 % fewer node updates.
  *   "skip" (0/1, default 1): a node whose conditioning codes did not change since it was last minimised is not recomputed (exact memoisation --

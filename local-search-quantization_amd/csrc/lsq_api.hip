@@ -67,6 +67,7 @@ struct lsq_ctx {
     int per_node = 0;        // schedule 6: one launch per node update instead of 64 per launch (profiling: per-sweep timings / counters)
     int ablation = 0;        // timing-only kernel ablations (results are garbage when != 0)
     int light = -1;          // schedules 3/4: light-block threshold (-1 = default)
+    int wave_max = 64;       // chunks with at most this many vectors per block of the walk kernel (and all-light blocks) run icm_wave_kernel
     int fallback = 1;        // schedules 3/4: a candidate equal to its current record inherits that record's validity bits (exact)
     int skip = 1;            // schedule 3: skip node updates whose inputs did not change (exact memoisation)
     // workspace
@@ -181,6 +182,7 @@ extern "C" int lsq_set_option(lsq_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "ablation")) c->ablation = (int)value;      // timing-only kernel variants: tuning build only
 #endif
     else if (!strcmp(key, "light")) c->light = (int)value;
+    else if (!strcmp(key, "wave_max")) c->wave_max = (int)value;
     else if (!strcmp(key, "fallback")) c->fallback = (int)value;
     else if (!strcmp(key, "q16_min")) c->q16_min = value;
     else if (!strcmp(key, "per_node")) c->per_node = value != 0;
@@ -384,6 +386,19 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t c
             return LSQ_OK;
         }
         (void)idle;
+        {
+            // a chunk so small that every block of the walk kernel would be light (at most `light` vectors each): a wave owns its vectors through
+            // the whole launch instead (icm_wave_kernel: no compaction, no barriers, records and validity words in registers)
+            int per_pass = 0, npass = 0;
+            lsq_walk_geometry(cn, m, &per_pass, &npass, nullptr);
+            const int light_max = c->light >= 0 ? c->light : 256;
+            if (c->ablation == 0 && per_pass <= light_max && per_pass <= c->wave_max) {
+                LSQ_TRY(lsq_launch_icm_wave(c->stream, c->U.as<float>(), c->T.as<float>(), rec, valid, cn, m, seq.data(), (int)seq.size(), 0, c->skip,
+                                            c->active.as<unsigned long long>(), c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr));
+                c->icm_launches += ((int64_t)seq.size() + 63) / 64;
+                return LSQ_OK;
+            }
+        }
         LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>(), c->Ts.as<float>(), c->T.as<float>(), rec, valid, cn, m, seq.data(), (int)seq.size(), 0, c->skip,
                                     c->active.as<unsigned long long>(), c->ablation, c->light, c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr));
         c->icm_launches += ((int64_t)seq.size() + 63) / 64;

@@ -325,6 +325,101 @@ __global__ __launch_bounds__(256) void tables_to_slices_kernel(const float *__re
         *reinterpret_cast<const f32x4 *>(T + (((int64_t)j * m + k) * LSQ_H + b) * LSQ_H + slice * SL + qq * 4);
 }
 
+// ---- small chunks: a WAVE owns its vectors through every node update of the launch ------------------------------------------------
+// When a chunk is so small that every block of the walk kernel would be "light" anyway (at most `light` vectors per block), the block
+// structure only costs: per node update a compaction (validity words from memory), barriers, and the bookkeeping round trips.  Here a wave keeps
+// the records and validity words of its LSQ_LIGHT_LB vectors in scalar registers for the whole launch; a node update is the light routine's
+// arithmetic (unary row from the slice-major planes, (m-1) table rows from L2, plain f32 adds in ascending k, first argmin) and nothing else;
+// records and validity words are written once, at the end.  Same codes, same memoisation rules (skip, fall-back) as icm_walk_kernel.
+template <int M>
+__global__ __launch_bounds__(256) void icm_wave_kernel(const float *__restrict__ U, const float *__restrict__ T, uint8_t *__restrict__ rec,
+                                                       unsigned short *__restrict__ valid, int64_t n, const WalkNodes nodes, int SL, int use_skip,
+                                                       unsigned long long *__restrict__ active_total, const uint8_t *__restrict__ ref_rec,
+                                                       const unsigned short *__restrict__ ref_valid, const int *__restrict__ idle_if_set) {
+    constexpr int CS = (M <= 8) ? 8 : 16;
+    constexpr int LB = LSQ_LIGHT_LB(M);
+    if (idle_if_set && *idle_if_set) return;
+    __shared__ unsigned stat_s[4 + LSQ_WALK_TRACE];
+    for (int e = threadIdx.x; e < 4 + LSQ_WALK_TRACE; e += 256) stat_s[e] = 0u;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t wv = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t i0 = wv * LB;
+    const int LPV = SL / 4;
+    const bool have_ref = ref_rec && ref_valid;
+    CodeRec cr[LB], rr[LB];
+    uint32_t vm[LB], rv[LB];
+    bool on[LB];
+#pragma unroll
+    for (int e = 0; e < LB; ++e) {
+        on[e] = i0 + e < n;
+        cr[e].lo = cr[e].hi = rr[e].lo = rr[e].hi = 0ull;
+        vm[e] = rv[e] = 0u;
+        if (on[e]) {
+            cr[e] = load_rec<CS>(rec, i0 + e);
+            if (use_skip) vm[e] = (uint32_t)__builtin_amdgcn_readfirstlane((int)valid[i0 + e]);
+            if (have_ref) {
+                rr[e] = load_rec<CS>(ref_rec, i0 + e);
+                rv[e] = (uint32_t)__builtin_amdgcn_readfirstlane((int)ref_valid[i0 + e]);
+            }
+        }
+    }
+    unsigned total = 0, wave_nodes = 0;
+    for (int nu = 0; nu < nodes.count; ++nu) {
+        const int j = nodes.j[nu];
+        bool need[LB];
+        unsigned cnt = 0;
+#pragma unroll
+        for (int e = 0; e < LB; ++e) {
+            need[e] = on[e] && (!use_skip || !((vm[e] >> j) & 1u));
+            cnt += need[e] ? 1u : 0u;
+        }
+        if (cnt == 0) continue;
+        const float *__restrict__ Usj = U + (int64_t)j * n * LSQ_H;
+        const float *__restrict__ Tj = T + (int64_t)j * M * LSQ_H * LSQ_H;
+        f32x4 s[LB], c[LB][M > 1 ? M - 1 : 1];
+#pragma unroll
+        for (int e = 0; e < LB; ++e) {
+            s[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (need[e]) s[e] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(Usj + ((int64_t)(lane / LPV) * n + (i0 + e)) * SL) + (lane % LPV));
+        }
+#pragma unroll
+        for (int e = 0; e < LB; ++e)
+            if (need[e]) {
+#pragma unroll
+                for (int kk = 0; kk < M - 1; ++kk) {
+                    const int k = kk + (kk >= j ? 1 : 0);
+                    c[e][kk] = reinterpret_cast<const f32x4 *>(Tj + ((int64_t)(k * LSQ_H) + cr[e].get(k)) * LSQ_H)[lane];
+                }
+            }
+#pragma unroll
+        for (int e = 0; e < LB; ++e)
+            if (need[e]) {
+#pragma unroll
+                for (int kk = 0; kk < M - 1; ++kk) s[e] = s[e] + c[e][kk];      // ascending k, plain f32 adds
+                const uint32_t code = (uint32_t)wave_first_argmin(s[e], lane);
+                if (code != cr[e].get(j)) { cr[e].set(j, code); vm[e] = 1u << j; }      // a changed code invalidates every other node
+                else vm[e] |= 1u << j;                                                  // an unchanged one confirms node j
+                if (have_ref && cr[e].lo == rr[e].lo && (CS == 8 || cr[e].hi == rr[e].hi)) vm[e] |= rv[e];      // known_valid()
+            }
+        total += cnt;
+        ++wave_nodes;
+        if (lane == 0) atomicAdd(&stat_s[4 + ((nodes.pos0 + nu) & (LSQ_WALK_TRACE - 1))], cnt);
+    }
+#pragma unroll
+    for (int e = 0; e < LB; ++e)
+        if (on[e] && lane == 0) {
+            *reinterpret_cast<uint64_t *>(rec + (i0 + e) * CS) = cr[e].lo;
+            if (CS == 16) *reinterpret_cast<uint64_t *>(rec + (i0 + e) * CS + 8) = cr[e].hi;
+            if (use_skip) valid[i0 + e] = (unsigned short)vm[e];
+        }
+    if (lane == 0) { atomicAdd(&stat_s[0], total); atomicAdd(&stat_s[2], wave_nodes); }      // [2]: light (wave, node) updates
+    __syncthreads();
+    if (active_total)
+        for (int e = threadIdx.x; e < 4 + LSQ_WALK_TRACE; e += 256)
+            if (stat_s[e]) atomicAdd(active_total + e, (unsigned long long)stat_s[e]);
+}
+
 // ---- perturbation (cudautils.cu:27-80 / encode_icm.jl:55-70) ------------------------------------
 // npert distinct positions (selection sampling, ascending) of the record w get uniform codes; Philox keyed by (seed, global index, ILS iteration)
 __device__ inline bool perturb_record(uint64_t (&w)[2], int m, int npert, uint64_t seed, uint32_t it, uint64_t gi) {
@@ -827,6 +922,32 @@ int lsq_launch_tables_to_slices(hipStream_t s, const float *T, float *Ts, int m,
         else hipLaunchKernelGGL(KERNEL<16>, dim3(GRID), dim3(256), 0, s, __VA_ARGS__);             \
         LSQ_HIP(hipGetLastError());                                                                \
     } while (0)
+
+// small chunks (at most `light` vectors per block of the walk kernel): every node update of the sequence in launches of <= 64, a wave per
+// LSQ_LIGHT_LB vectors
+int lsq_launch_icm_wave(hipStream_t s, const float *U, const float *T, uint8_t *rec, unsigned short *valid, int64_t n, int m, const int32_t *order,
+                        int nnodes, int pos0, int use_skip, unsigned long long *active_total, const uint8_t *ref_rec, const unsigned short *ref_valid,
+                        const int *idle_if_set) {
+    if (n <= 0 || nnodes <= 0) return LSQ_OK;
+    if (m < 1 || m > LSQ_MAX_M) { lsq_set_error("m = %d out of range 1..16", m); return LSQ_EINVAL; }
+    const int skip = (use_skip && valid) ? 1 : 0;
+    for (int done = 0; done < nnodes; done += LSQ_WALK_MAX_NODES) {
+        WalkNodes nodes;
+        nodes.count = (nnodes - done < LSQ_WALK_MAX_NODES) ? nnodes - done : LSQ_WALK_MAX_NODES;
+        nodes.pos0 = pos0 + done;
+        for (int t = 0; t < nodes.count; ++t) {
+            const int j = order[done + t];
+            if (j < 0 || j >= m) { lsq_set_error("node %d out of range 0..%d", j, m - 1); return LSQ_EINVAL; }
+            nodes.j[t] = (uint8_t)j;
+        }
+        const int lb = LSQ_LIGHT_LB(m);
+        const unsigned grid = (unsigned)((n + 4 * lb - 1) / (4 * lb));
+        LSQ_DISPATCH_M(m, hipLaunchKernelGGL(icm_wave_kernel<M_>, dim3(grid), dim3(256), 0, s, U, T, rec, valid, n, nodes, lsq_walk_slice_width(m), skip,
+                                             active_total, skip ? ref_rec : nullptr, skip ? ref_valid : nullptr, idle_if_set));
+    }
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}
 
 int lsq_launch_perturb(hipStream_t s, const uint8_t *src, uint8_t *dst, int64_t n, int m, int npert, uint64_t seed,
                        uint32_t it, uint64_t global_offset, const unsigned short *vsrc, unsigned short *vdst) {

@@ -145,6 +145,9 @@ int lsq_launch_tables_to_slices(hipStream_t s, const float *T, float *Ts, int m,
 // U is the slice-major unary buffer of ALL nodes; T (optional) the row-major tables for light blocks' L2 gathers; order[nnodes] = node updates run back to back inside the launch
 // (a block owns its vectors for the whole launch): 1 entry = one node update, icmiter*m entries = a whole ILS iteration.
 void lsq_walk_geometry(int64_t n, int m, int *per_pass, int *npass, int *pp_cap);      // segments of the walk kernel over n vectors
+int lsq_launch_icm_wave(hipStream_t s, const float *U, const float *T, uint8_t *rec, unsigned short *valid, int64_t n, int m, const int32_t *order,
+                        int nnodes, int pos0, int use_skip, unsigned long long *active_total, const uint8_t *ref_rec, const unsigned short *ref_valid,
+                        const int *idle_if_set = nullptr);      // chunks in which every block would be light: a wave owns its vectors through the launch
 int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const float *T, uint8_t *rec, unsigned short *valid, int64_t n, int m,
                         const int32_t *order, int nnodes, int pos0, int use_skip, unsigned long long *active_total, int ablation, int light,
                         const uint8_t *ref_rec, const unsigned short *ref_valid, const int *idle_if_set = nullptr);
