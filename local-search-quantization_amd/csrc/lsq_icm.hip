@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void icm_wave_kernel(const float *__restrict__
 #pragma unroll
         for (int e = 0; e < LB; ++e) {
             s[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (need[e]) s[e] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(Usj + ((int64_t)(lane / LPV) * n + (i0 + e)) * SL) + (lane % LPV));
+            if (need[e]) s[e] = (reinterpret_cast<const f32x4 *>(Usj + ((int64_t)(lane / LPV) * n + (i0 + e)) * SL))[lane % LPV];      // small chunks: the planes live in L2 / the Infinity Cache across sweeps
         }
 #pragma unroll
         for (int e = 0; e < LB; ++e)
