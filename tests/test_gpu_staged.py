@@ -304,3 +304,29 @@ def test_filter_mild_outliers_are_flagged_before_levels_can_wrap(lsq, oracle):
             Xa[rows] *= np.float32(scale)
             flagged += _filter_case(lsq, oracle, Xa, K, B0, m, [1], 2, 4, seed)["filter_f32"]
     assert flagged > 0
+
+
+@pytest.mark.parametrize("m", [1, 4, 8, 9, 13, 16])
+def test_small_chunk_wave_kernel_every_rule(lsq, oracle, m):
+    """Chunks of at most 256 x wave_max vectors run icm_wave_kernel (a wave owns its vectors through the launch).  It must give the oracle's
+    codes under the four skip x fallback combinations, for both schedules that can reach it, with a ragged last wave, and agree with the
+    block-structured light path (wave_max = 0) in codes AND in the number of node updates recomputed (same memoisation rules)."""
+    d, n, ils, J, npert, seed = 16, 2501, [1, 3], 3, min(4, m), 900 + m
+    X, K, B0 = make_problem(d, n, m, seed=seed, kind="gauss")
+    Bs_ref, objs_ref = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, True, seed)
+    for schedule in (6, 4):
+        for skip in (1, 0):
+            for fb in (1, 0):
+                got = {}
+                for wave_max in (64, 0):
+                    with lsq.Engine(0, schedule=schedule, skip=skip) as eng:
+                        eng.set_option("fallback", fb)
+                        eng.set_option("wave_max", wave_max)
+                        Bs, objs = eng.encode_icm(X, B0, K, m, ils, J, npert, True, seed=seed)
+                        t = eng.timings()
+                    tag = "m=%d schedule=%d skip=%d fallback=%d wave_max=%d" % (m, schedule, skip, fb, wave_max)
+                    assert np.array_equal(Bs, Bs_ref), "%s: %d of %d codes differ" % (tag, (Bs != Bs_ref).sum(), Bs.size)
+                    assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0), tag
+                    assert t["staged_blocks"] == 0 and t["filtered_blocks"] == 0 and t["light_blocks"] > 0, (tag, t)
+                    got[wave_max] = t["icm_node_updates"]
+                assert got[64] == got[0], (m, schedule, skip, fb, got)
