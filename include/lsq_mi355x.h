@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define LSQ_VERSION 200
+#define LSQ_VERSION 300
 
 #if defined(__GNUC__)
 #define LSQ_API __attribute__((visibility("default")))
@@ -115,6 +115,8 @@ LSQ_API int lsq_set_stream(lsq_ctx *ctx, void *hip_stream);
  *        bits (validity depends on the code tuple only): exact, ~12 % fewer node updates.
  *   "skip" (0/1, default 1): a node whose conditioning codes did not change since it was last minimised is not recomputed (exact memoisation --
  *        same codes, fewer bytes).
+ *   "ils_counter": the next iteration index used by lsq_encoding_icm / lsq_encode_icm_fully when called with it = LSQ_IT_AUTO
+ *        (starts at 0, advances by one per such call).
  *   (liblsq_mi355x_tuning.so only) "ablation": timing-only kernel variants whose results are garbage. */
 LSQ_API int lsq_set_option(lsq_ctx *ctx, const char *key, int64_t value);
 LSQ_API int lsq_get_timings(lsq_ctx *ctx, lsq_timings *out);
@@ -171,7 +173,14 @@ LSQ_API int lsq_encode_icm_dev(lsq_ctx *ctx, const float *dX, const uint8_t *dB0
 
 /* ---- (2) the CPU-path shaped entry points -------------------------------------------------
  * encoding_icm(X, oldB, C, niter, randord, npert, V) -> B     src/encodings/encode_icm.jl:131-189
- * ONE ILS iteration (`it` = its 0-based index, the RNG counter) with the accept rule. */
+ * ONE ILS iteration with the accept rule.  `it` = the iteration's 0-based index: it keys the perturbation and the node
+ * order (the reference draws them from Julia's global RNG, so every call differs).  The reference's callers keep no
+ * such count (demos/demo_lsq.jl:48-51: `for i = 1:ilsiter; B = encoding_icm(...); end`), so an unchanged caller passes
+ * it = LSQ_IT_AUTO: the CONTEXT then counts -- the k-th such call on a context uses it = k-1 (option "ils_counter" sets
+ * the next value; lsq_encode_icm_fully shares the counter) -- and `ilsiter` chained calls give exactly the codes of
+ * lsq_encode_icm(ilsiters = [ilsiter]) on a fresh context.  A fixed `it` on every call would re-draw the SAME
+ * perturbation each time and the ILS would silently stop exploring. */
+#define LSQ_IT_AUTO 0xFFFFFFFFu
 LSQ_API int lsq_encoding_icm(lsq_ctx *ctx, const float *X, const int16_t *oldB, const float *K,
                      int d, int64_t n, int m, int h, int niter, int randord, int npert,
                      uint64_t seed, uint32_t it, uint64_t global_offset, int16_t *outB);

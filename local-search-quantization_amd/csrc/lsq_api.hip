@@ -70,6 +70,7 @@ struct lsq_ctx {
     int wave_max = 64;       // chunks with at most this many vectors per block of the walk kernel (and all-light blocks) run icm_wave_kernel
     int fallback = 1;        // schedules 3/4: a candidate equal to its current record inherits that record's validity bits (exact)
     int skip = 1;            // schedule 3: skip node updates whose inputs did not change (exact memoisation)
+    uint32_t auto_it = 0;    // ILS-iteration counter of the CPU-shaped entry points called with it = LSQ_IT_AUTO: advances by one per call
     // workspace
     DevBuf sci, T, Ts, U, part, vCur, vNew, active, recCur, recNew, prev, counters, obj, bad;
     DevBuf Uq, Tq, qp, qscratch, qflag;                // 16-bit filtered walk: u16 unary planes, u16 slice tables, lsq_q16_params, bound scratch, per-vector out-of-range flags
@@ -186,6 +187,10 @@ extern "C" int lsq_set_option(lsq_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "fallback")) c->fallback = (int)value;
     else if (!strcmp(key, "q16_min")) c->q16_min = value;
     else if (!strcmp(key, "per_node")) c->per_node = value != 0;
+    else if (!strcmp(key, "ils_counter")) {
+        if (value < 0 || value >= (int64_t)LSQ_IT_AUTO) { lsq_set_error("ils_counter must lie in 0..2^32-2"); return LSQ_EINVAL; }
+        c->auto_it = (uint32_t)value;
+    }
     else if (!strcmp(key, "schedule")) {
 #ifdef LSQ_TUNING
         if (value < 0 || value > 6 || value == 5) { lsq_set_error("schedule must be 0..4 or 6"); return LSQ_EINVAL; }
@@ -367,7 +372,6 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t c
         std::vector<int32_t> seq((size_t)nsweeps * m);
         for (int sw = 0; sw < nsweeps; ++sw)
             for (int q = 0; q < m; ++q) seq[(size_t)sw * m + q] = order[q];
-        const int *idle = nullptr;
         if (use_q16(c, cn) && valid) {
             // 16-bit filtered walk; when the chunk's bounds were not usable (params.ok == 0: non-finite data) it idles and the f32 walk
             // below -- which idles when params.ok == 1 -- does the work.  64 node updates per launch, as below.
@@ -385,7 +389,6 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t c
             c->icm_launches += ((int64_t)seq.size() + (int64_t)per_launch - 1) / (int64_t)per_launch;
             return LSQ_OK;
         }
-        (void)idle;
         {
             // a chunk so small that every block of the walk kernel would be light (at most `light` vectors each): a wave owns its vectors through
             // the whole launch instead (icm_wave_kernel: no compaction, no barriers, records and validity words in registers)
@@ -547,13 +550,16 @@ static int encode_host(lsq_ctx *c, const char *fn, const float *X, const int16_t
     LSQ_TRY(validate_encode(fn, d, n, m, h, ilsiters, nr, icmiter, npert, &I));
     if (!K || (!objs && !place) || (n > 0 && (!X || !B || !Bs))) { lsq_set_error("%s: null pointer", fn); return LSQ_EINVAL; }
     const int64_t ntot = place ? place->ntot : n, row0 = place ? place->row0 : 0;
-    LSQ_TRY(check_codes_host(fn, B, n, m, h));      // before any device work: an invalid call costs nothing and never touches Bs
     LSQ_TRY(begin_call(c, I, nr));
     const size_t kbytes = sizeof(float) * (size_t)m * LSQ_H * d;
     LSQ_TRY(c->sK.ensure(kbytes));
     LSQ_HIP(hipMemcpyAsync(c->sK.p, K, kbytes, hipMemcpyHostToDevice, c->stream));
     const float *dK = c->sK.as<float>();
     LSQ_TRY(prepare_tables(c, dK, d, m));
+    // The ONE range check of the input codes (1..h): a host scan, hidden under the table kernels just enqueued and done before anything
+    // reads B or writes Bs -- an invalid call never touches the caller's output and the codes are not checked twice (ADVICE r2:
+    // the device flag of codes_from_i16_kernel is only consulted by the fine-grained entry points, which have no host scan).
+    LSQ_TRY(check_codes_host(fn, B, n, m, h));
     const EncodeParams P{d, m, ilsiters, nr, icmiter, npert, randord, seed, it0};
     const int cs = lsq_code_stride(m);
     // Chunk c+1's X is uploaded on a second stream under the ILS iterations of chunk c (double-buffered staging).  The first
@@ -594,10 +600,7 @@ static int encode_host(lsq_ctx *c, const char *fn, const float *X, const int16_t
     }
     std::vector<double> sums((size_t)nr, 0.0);
     std::vector<int64_t> stats(2 * (size_t)I, 0);
-    int bad = 0;
-    LSQ_HIP(hipMemcpyAsync(&bad, c->bad.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     LSQ_TRY(finish_call(c, I, nr, sums.data(), stats.data()));
-    if (bad) { lsq_set_error("%s: input codes must lie in 1..%d", fn, h); return LSQ_ECODE; }
     if (place) {
         for (int r = 0; r < nr; ++r) place->sums[r] = sums[(size_t)r];
         if (place->stats) for (size_t q = 0; q < stats.size(); ++q) place->stats[q] = stats[q];
@@ -699,7 +702,14 @@ extern "C" int lsq_encoding_icm(lsq_ctx *c, const float *X, const int16_t *oldB,
                                 int niter, int randord, int npert, uint64_t seed, uint32_t it, uint64_t global_offset, int16_t *outB) {
     const int64_t one = 1;
     float obj = 0.f;
-    return encode_host(c, "lsq_encoding_icm", X, oldB, K, d, n, m, h, &one, 1, niter, npert, randord, seed, it, global_offset, 0, outB, &obj);
+    if (!c) { lsq_set_error("null lsq_ctx"); return LSQ_EINVAL; }
+    // it = LSQ_IT_AUTO: the reference's caller keeps no iteration count (demos/demo_lsq.jl:48-51 just loops) -- the context does, so that
+    // successive calls draw different perturbations; it advances only when the call succeeded
+    const bool autoit = it == LSQ_IT_AUTO;
+    const int rc = encode_host(c, "lsq_encoding_icm", X, oldB, K, d, n, m, h, &one, 1, niter, npert, randord, seed, autoit ? c->auto_it : it,
+                               global_offset, 0, outB, &obj);
+    if (rc == LSQ_OK && autoit && c->auto_it < LSQ_IT_AUTO - 1u) ++c->auto_it;
+    return rc;
 }
 
 // upload helpers for the fine-grained entry points
@@ -735,6 +745,8 @@ extern "C" int lsq_encode_icm_fully(lsq_ctx *c, int16_t *B, const float *X, cons
     LSQ_TRY(use_device(c));
     LSQ_TRY(check_shape("lsq_encode_icm_fully", d, n, m, h));
     if (!K || niter < 0 || npert < 0 || idx_first < 1 || (n > 0 && (!B || !X))) { lsq_set_error("lsq_encode_icm_fully: bad arguments"); return LSQ_EINVAL; }
+    const bool autoit = it == LSQ_IT_AUTO;
+    if (autoit) { it = c->auto_it; if (c->auto_it < LSQ_IT_AUTO - 1u) ++c->auto_it; }
     if (n == 0) return LSQ_OK;
     if (n > c->chunk) { lsq_set_error("lsq_encode_icm_fully: n = %lld exceeds the resident chunk (%lld); raise option \"chunk\"", (long long)n, (long long)c->chunk); return LSQ_EINVAL; }
     LSQ_TRY(upload_xk(c, X, K, d, n, m));

@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void icm_wave_kernel(const float *__restrict__
         vm[e] = rv[e] = 0u;
         if (on[e]) {
             cr[e] = load_rec<CS>(rec, i0 + e);
-            if (use_skip) vm[e] = (uint32_t)__builtin_amdgcn_readfirstlane((int)valid[i0 + e]);
+            if (valid) vm[e] = (uint32_t)__builtin_amdgcn_readfirstlane((int)valid[i0 + e]);      // maintained whenever the pointer is given (lsq_internal.h), consulted only with use_skip
             if (have_ref) {
                 rr[e] = load_rec<CS>(ref_rec, i0 + e);
                 rv[e] = (uint32_t)__builtin_amdgcn_readfirstlane((int)ref_valid[i0 + e]);
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void icm_wave_kernel(const float *__restrict__
         if (on[e] && lane == 0) {
             *reinterpret_cast<uint64_t *>(rec + (i0 + e) * CS) = cr[e].lo;
             if (CS == 16) *reinterpret_cast<uint64_t *>(rec + (i0 + e) * CS + 8) = cr[e].hi;
-            if (use_skip) valid[i0 + e] = (unsigned short)vm[e];
+            if (valid) valid[i0 + e] = (unsigned short)vm[e];
         }
     if (lane == 0) { atomicAdd(&stat_s[0], total); atomicAdd(&stat_s[2], wave_nodes); }      // [2]: light (wave, node) updates
     __syncthreads();

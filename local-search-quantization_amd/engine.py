@@ -13,6 +13,7 @@ import numpy as np
 from . import _lib
 
 H = 256
+IT_AUTO = 0xFFFFFFFF      # LSQ_IT_AUTO: the context counts the ILS iterations of the CPU-shaped entry points
 
 
 def _np(a, dtype):
@@ -138,7 +139,9 @@ class Engine:
         return dBs, obj, stats
 
     # -- (2) CPU-path shaped ---------------------------------------------------------------
-    def encoding_icm(self, X, oldB, K, m, niter, randord, npert, seed=0, it=0, global_offset=0, h=H):
+    def encoding_icm(self, X, oldB, K, m, niter, randord, npert, seed=0, it=None, global_offset=0, h=H):
+        """ONE ILS iteration with the accept rule.  it=None (default): the context's own counter (LSQ_IT_AUTO) -- the k-th call uses it = k-1."""
+        it = IT_AUTO if it is None else it
         X, K, oldB = _np(X, np.float32), _np(K, np.float32), _np(oldB, np.int16)
         n, d = X.shape
         self._check_shapes(X, K, oldB, m, h)
@@ -148,8 +151,9 @@ class Engine:
                                             int(global_offset), out.ctypes.data))
         return out
 
-    def encode_icm_fully(self, B, X, K, m, niter, randord, npert, idx_first=1, seed=0, it=0, h=H):
-        """In place on B (n, m) int16 (must be C-contiguous int16)."""
+    def encode_icm_fully(self, B, X, K, m, niter, randord, npert, idx_first=1, seed=0, it=None, h=H):
+        """In place on B (n, m) int16 (must be C-contiguous int16).  it=None: the context's counter, as in encoding_icm."""
+        it = IT_AUTO if it is None else it
         X, K = _np(X, np.float32), _np(K, np.float32)
         if B.dtype != np.int16 or not B.flags["C_CONTIGUOUS"]:
             raise ValueError("B must be a C-contiguous int16 (n, m) array (it is updated in place)")

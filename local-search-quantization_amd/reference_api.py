@@ -56,13 +56,16 @@ def encode_icm_cuda(RX, B, C, ilsiters, icmiter, npert, randord, nsplits=2, V=Fa
     return [Bs[r].T for r in range(Bs.shape[0])], objs
 
 
-def encoding_icm(X, oldB, C, niter, randord, npert, V=False, *, seed=0, it=0, engine=None):
+def encoding_icm(X, oldB, C, niter, randord, npert, V=False, *, seed=0, it=None, engine=None):
+    """One ILS iteration (encode_icm.jl:131-189).  With the reference's own argument list (no `it`) the engine counts the calls, so the
+    demo loop `for i = 1:ilsiter; B = encoding_icm(...); end` (demos/demo_lsq.jl:48-51) perturbs differently every time -- and equals
+    encode_icm_cuda(..., [ilsiter], ...) on a fresh engine (or after engine.set_option("ils_counter", 0))."""
     eng = engine or default_engine()
     m, d, h = _dims(C)
     return eng.encoding_icm(_X_of(X), _B_of(oldB), _K_of(C), m, niter, randord, npert, seed=seed, it=it, h=h).T
 
 
-def encode_icm_fully(B, X, C, binaries, cbi, niter, randord, npert, IDX, V=False, *, seed=0, it=0, engine=None):
+def encode_icm_fully(B, X, C, binaries, cbi, niter, randord, npert, IDX, V=False, *, seed=0, it=None, engine=None):
     """In place on B (m, n) int16.  `binaries`/`cbi` are accepted for signature parity and ignored
     (rebuilt on the device from C).  IDX = (first, last) 1-based or a range."""
     eng = engine or default_engine()

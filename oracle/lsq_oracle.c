@@ -342,6 +342,54 @@ ORC_EXPORT int orc_encode_icm(const float *X, const int16_t *B, const float *K, 
     return 0;
 }
 
+/* ------------------------------------------------ the worker, per-vector ---- */
+
+/* `encode_icm_fully!` (encode_icm.jl:4-127): perturbation (:55-70), then `niter` sweeps over the node order (:72-125),
+ * IN PLACE on B and WITHOUT the accept test (that is encoding_icm's, :178-186).  Every node update goes through
+ * node_update() above -- the function all the other entry points of this file use.  With npert = 0 and randord = 0 the
+ * call draws no random number: that is the deterministic call tools/make_reference_fixture.jl records from the reference
+ * itself, and tests/test_reference_fixture.py replays it through THIS function to pin the oracle's encoder.
+ * margins (optional, n floats): per vector, the smallest (second-best - best) conditioned value met in any of its node
+ * updates (+inf when h == 1) -- lets a checker tell decisions that survive a different GEMM summation order from near-ties. */
+ORC_EXPORT int orc_encode_icm_fully(const float *X, int16_t *B, const float *K, int d, long n, int m, int h, int niter,
+                                    int randord, int npert, uint64_t seed, uint32_t it, uint64_t global_offset, float *margins) {
+    if (d < 1 || n < 0 || m < 1 || m > 16 || h < 1 || h > 256 || niter < 0 || npert < 0) return -1;
+    for (long q = 0; q < n * m; ++q) if (B[q] < 1 || B[q] > h) return -3;
+    float *Kt = make_Kt(K, m, h, d);
+    float *sci = (float *)malloc(sizeof(float) * (size_t)m * h);
+    float *T = (float *)malloc(sizeof(float) * (size_t)m * m * h * h);
+    orc_sqnorms(K, m * h, d, sci);
+    orc_tables(K, m, h, d, T);
+    int32_t order[16];
+    orc_perm(seed, it, m, randord, order);
+#pragma omp parallel
+    {
+        float *u = (float *)malloc(sizeof(float) * (size_t)m * h);
+        float *s = (float *)malloc(sizeof(float) * (size_t)h);
+#pragma omp for schedule(static)
+        for (long i = 0; i < n; ++i) {
+            uint8_t nw[16];
+            for (int j = 0; j < m; ++j) nw[j] = (uint8_t)(B[i * m + j] - 1);
+            unaries_one(X + (size_t)i * d, Kt, sci, d, m, h, u);
+            orc_perturb(seed, global_offset + (uint64_t)i, it, m, h, npert, nw);
+            float margin = INFINITY;
+            for (int sw = 0; sw < niter; ++sw)
+                for (int q = 0; q < m; ++q) {
+                    const int j = order[q];
+                    const int best = node_update(u + (size_t)j * h, T, nw, j, m, h, s);
+                    nw[j] = (uint8_t)best;
+                    for (int a = 0; a < h; ++a)
+                        if (a != best && !(s[a] - s[best] >= margin)) margin = s[a] - s[best];
+                }
+            for (int j = 0; j < m; ++j) B[i * m + j] = (int16_t)(nw[j] + 1);
+            if (margins) margins[i] = margin;
+        }
+        free(u); free(s);
+    }
+    free(T); free(sci); free(Kt);
+    return 0;
+}
+
 /* --------------------------------- one ILS iteration, structure-faithful ---- */
 
 /* `encoding_icm` (encode_icm.jl:131-189) with the reference's own loop nest kept:

@@ -12,21 +12,22 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "liblsq_oracle.so")
+_LIB_PATH = os.environ.get("LSQ_ORACLE_LIB") or os.path.join(_HERE, "liblsq_oracle.so")      # override: the sanitizer build (make asan)
 _lib = None
 
 __all__ = [
     "build", "lib", "philox4x32_10", "rng_word", "perm", "perturb", "randinit", "synth_data_u8",
-    "sqnorms", "tables", "unaries", "veccost", "icm_node", "encode_icm", "encoding_icm_faithful",
+    "sqnorms", "tables", "unaries", "veccost", "icm_node", "encode_icm", "encode_icm_fully", "encoding_icm_faithful",
     "qerror", "num_threads", "ref_linscan_path", "ref_linscan",
 ]
 
 
 def build(force=False):
     """Compile the C restatement (and, when /root/reference is present, oracle/_ref)."""
+    target = "asan" if os.environ.get("LSQ_ORACLE_LIB") else "liblsq_oracle.so"
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(
             os.path.join(_HERE, "lsq_oracle.c")):
-        subprocess.check_call(["make", "-C", _HERE, "liblsq_oracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, target], stdout=subprocess.DEVNULL)
     subprocess.call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 
@@ -65,6 +66,9 @@ def lib():
         L.orc_encoding_icm_faithful.argtypes = [f32p, i16p, f32p, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int,
                                                 C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, i16p]
         L.orc_encoding_icm_faithful.restype = C.c_int
+        L.orc_encode_icm_fully.argtypes = [f32p, i16p, f32p, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_uint64, C.c_uint32, C.c_uint64, f32p]
+        L.orc_encode_icm_fully.restype = C.c_int
         L.orc_qerror.argtypes = [f32p, i16p, f32p, C.c_int, C.c_long, C.c_int, C.c_int]
         L.orc_qerror.restype = C.c_double
         L.orc_num_threads.restype = C.c_int
@@ -187,6 +191,20 @@ def encoding_icm_faithful(X, oldB, K, m, h, niter, randord, npert, seed, it, nwo
     if rc != 0:
         raise ValueError("orc_encoding_icm_faithful failed with %d" % rc)
     return out
+
+
+def encode_icm_fully(X, B, K, m, h, niter, randord, npert, seed=0, it=0, global_offset=0, want_margins=False):
+    """The worker `encode_icm_fully!` (encode_icm.jl:4-127): perturb + niter sweeps, NO accept test.  -> B' (n, m) int16
+    [, margins (n,) f32: the smallest runner-up gap met in any node update of the vector]."""
+    X, K = _f32(X), _f32(K)
+    out = np.array(B, dtype=np.int16, order="C", copy=True)
+    n, d = X.shape
+    margins = np.zeros(max(n, 1), dtype=np.float32)
+    rc = lib().orc_encode_icm_fully(_p(X, C.c_float), _p(out, C.c_int16), _p(K, C.c_float), d, n, m, h, niter,
+                                    int(bool(randord)), npert, seed, it, global_offset, _p(margins, C.c_float))
+    if rc != 0:
+        raise ValueError("orc_encode_icm_fully failed with %d" % rc)
+    return (out, margins[:n]) if want_margins else out
 
 
 def qerror(X, B, K, m, h):

@@ -12,6 +12,45 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "tuning: cross-checks of the NON-SHIPPED schedules 0..2 (liblsq_mi355x_tuning.so only); they run only "
+                                       "with LSQ_TEST_TUNING=1 so that they never count toward the product's green total")
+
+
+def pytest_collection_modifyitems(config, items):
+    if os.environ.get("LSQ_TEST_TUNING") == "1":
+        return
+    skip = pytest.mark.skip(reason="tuning-build cross-check of a non-shipped schedule (set LSQ_TEST_TUNING=1 to run it)")
+    for item in items:
+        if "tuning" in item.keywords:
+            item.add_marker(skip)
+
+
+# How the encode is run in the parity tests.  The FIRST entries are the shipped library: its plain defaults (what a caller gets),
+# schedule 6 forced onto every chunk with every block staged (the 16-bit filtered walk is then the kernel that produces every code,
+# whatever n), the f32 walk in both launch shapes.  Schedules 0..2 exist in the tuning build only and are marked `tuning`.
+def _variant(name, marks=(), **options):
+    return pytest.param(options, id=name, marks=list(marks))
+
+
+ENCODE_VARIANTS = [
+    _variant("default"),
+    _variant("s6_forced", schedule=6, q16_min=0, light=0),
+    _variant("s6_light", schedule=6, q16_min=0),
+    _variant("s4", schedule=4),
+    _variant("s3", schedule=3),
+    _variant("legacy2", marks=[pytest.mark.tuning], schedule=2, tuning=1),
+    _variant("legacy0", marks=[pytest.mark.tuning], schedule=0, tuning=1),
+    _variant("legacy1", marks=[pytest.mark.tuning], schedule=1, tuning=1),
+]
+
+
+def open_engine(lsq, options, **kw):
+    """Engine(0) with a variant's options applied (`tuning` selects the tuning build)."""
+    opts = dict(options)
+    eng = lsq.Engine(0, tuning=bool(opts.pop("tuning", 0)), **kw)
+    for k, v in opts.items():
+        eng.set_option(k, v)
+    return eng
 
 
 @pytest.fixture(scope="session")

@@ -8,6 +8,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import ENCODE_VARIANTS, open_engine
+
 H = 256
 FIXTURES = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
 
@@ -38,12 +40,15 @@ def test_oracle_reproduces_golden(oracle, path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("schedule", [4, 3, 2, 0, 1])
+@pytest.mark.parametrize("variant", ENCODE_VARIANTS)
 @pytest.mark.parametrize("path", FIXTURES, ids=lambda p: os.path.basename(p)[:-4])
-def test_hip_reproduces_golden(lsq, path, schedule):
+def test_hip_reproduces_golden(lsq, path, variant):
     z, X, K, d, n, m, J, npert, randord, seed = _load(path)
-    with lsq.Engine(0, schedule=schedule, tuning=schedule < 3) as eng:
+    with open_engine(lsq, variant, profile=True) as eng:
         Bs, objs = eng.encode_icm(X, z["B0"], K, m, z["ilsiters"], J, npert, randord, seed=seed)
+        t = eng.timings()
+        if variant.get("q16_min") == 0 and variant.get("light") == 0:      # every code came out of the shipped 16-bit filtered walk
+            assert t["filtered_blocks"] > 0 and t["staged_blocks"] == 0 and t["light_blocks"] == 0, t
         assert np.array_equal(Bs, z["Bs"]), "%d codes differ" % (Bs != z["Bs"]).sum()
         assert np.allclose(objs, z["objs"], rtol=1e-5, atol=0)            # north_star tolerance for the MSE
         assert np.array_equal(eng.get_unaries(X, K, m)[:, :4, :], z["U_rows"])

@@ -6,7 +6,7 @@ reproduce the oracle's canonical fp32 operation order); objective within 1e-5 re
 import numpy as np
 import pytest
 
-from conftest import make_problem
+from conftest import ENCODE_VARIANTS, make_problem, open_engine
 
 pytestmark = pytest.mark.gpu
 
@@ -74,16 +74,19 @@ CONFIGS = [
 ]
 
 
-@pytest.mark.parametrize("schedule", [4, 3, 2, 0, 1])
+@pytest.mark.parametrize("variant", ENCODE_VARIANTS)
 @pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: "d%d_n%d_m%d" % (c[0], c[1], c[2]))
-def test_encode_icm_matches_oracle(lsq, oracle, cfg, schedule):
+def test_encode_icm_matches_oracle(lsq, oracle, cfg, variant):
     d, n, m, ils, J, npert, randord, seed, kind = cfg
     X, K, B0 = make_problem(d, n, m, seed=seed, kind=kind)
     Bs_ref, objs_ref, st_ref = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, randord, seed, want_stats=True)
-    with lsq.Engine(0, schedule=schedule, tuning=schedule < 3) as eng:
+    with open_engine(lsq, variant, profile=True) as eng:
         Bs, objs = eng.encode_icm(X, B0, K, m, ils, J, npert, randord, seed=seed)
+        t = eng.timings()
     assert np.array_equal(Bs, Bs_ref), "%d of %d codes differ" % ((Bs != Bs_ref).sum(), Bs.size)
     assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0)
+    if variant.get("q16_min") == 0 and variant.get("light") == 0:       # the shipped default kernel produced every code
+        assert t["filtered_blocks"] > 0 and t["staged_blocks"] == 0 and t["light_blocks"] == 0, t
 
 
 def test_skip_unchanged_is_exact(lsq, oracle):
@@ -205,6 +208,48 @@ def test_reference_shaped_api(lsq, oracle):
     assert abs(lsq.qerror(RX, Bs[1], C) - objs_ref[1]) <= 1e-5 * objs_ref[1]
 
 
+def test_chained_default_calls_equal_the_whole_call(lsq, oracle):
+    """The reference demo loop `for i = 1:ilsiter; B = encoding_icm(X, B, C, niter, randord, npert, V); end` (demos/demo_lsq.jl:48-51)
+    through the reference's own argument list -- no iteration index: the context counts (LSQ_IT_AUTO).  8 chained default-argument calls
+    == encode_icm_cuda(..., [8], ...) == the oracle.  A fixed index on every call would re-draw the same perturbation:
+    shown here to give different codes."""
+    d, n, m, seed, I = 64, 700, 8, 77, 8
+    X, K, B0 = make_problem(d, n, m, seed=seed)
+    C = [np.ascontiguousarray(K[j * H:(j + 1) * H].T) for j in range(m)]
+    RX, B = np.asfortranarray(X.T), np.asfortranarray(B0.T)
+    Bs_ref, _ = oracle.encode_icm(X, B0, K, m, H, [I], 4, 4, True, seed)
+    with lsq.Engine(0) as eng:
+        Bc = B.copy()
+        for _ in range(I):
+            Bc = lsq.encoding_icm(RX, Bc, C, 4, True, 4, False, seed=seed, engine=eng)          # the reference's positional arguments only
+        assert np.array_equal(Bc.T, Bs_ref[0])
+        Bs, _ = lsq.encode_icm_cuda(RX, B, C, [I], 4, 4, True, 2, False, seed=seed, engine=eng)
+        assert np.array_equal(Bs[0], Bc)
+        # the counter went on: the same chained loop now continues the sequence (iterations 8..15) ...
+        Bd = B.copy()
+        for _ in range(I):
+            Bd = lsq.encoding_icm(RX, Bd, C, 4, True, 4, False, seed=seed, engine=eng)
+        assert not np.array_equal(Bd, Bc)
+        # ... and "ils_counter" rewinds it
+        eng.set_option("ils_counter", 0)
+        Be = B.copy()
+        for _ in range(I):
+            Be = lsq.encoding_icm(RX, Be, C, 4, True, 4, False, seed=seed, engine=eng)
+        assert np.array_equal(Be, Bc)
+        # the trap this removes: the same explicit index on every call
+        Bf = B.copy()
+        for _ in range(I):
+            Bf = lsq.encoding_icm(RX, Bf, C, 4, True, 4, False, seed=seed, it=0, engine=eng)
+        assert not np.array_equal(Bf, Bc)
+        # the worker shares the counter: perturbation of iteration 0 after a rewind == explicit it = 0
+        eng.set_option("ils_counter", 0)
+        Bw0 = np.array(B, dtype=np.int16, order="F")
+        lsq.encode_icm_fully(Bw0, RX, C, None, None, 4, True, 4, (1, n), False, seed=seed, engine=eng)
+        Bw1 = np.array(B, dtype=np.int16, order="F")
+        lsq.encode_icm_fully(Bw1, RX, C, None, None, 4, True, 4, (1, n), False, seed=seed, it=0, engine=eng)
+        assert np.array_equal(Bw0, Bw1)
+
+
 def test_ties_pick_lowest_index(lsq, oracle):
     """Duplicate codewords create exact ties; the node update must return the LOWEST index (P3),
     which the reference CUDA tree reduction does not guarantee."""
@@ -240,10 +285,10 @@ def test_nonfinite_inputs_follow_the_reference_scan(lsq, oracle, n):
     K[300] = -0.0
     import torch
     Bs_ref, objs_ref, st_ref = oracle.encode_icm(X, B0, K, m, H, [1, 2, 4], 3, 4, True, seed, want_stats=True)
-    for schedule in (4, 3):
-        with lsq.Engine(0, schedule=schedule, tuning=schedule < 3) as eng:
+    for options in ({}, {"schedule": 6, "q16_min": 0}, {"schedule": 4}, {"schedule": 3}):      # {}: the shipped defaults
+        with open_engine(lsq, options) as eng:
             Bs, objs = eng.encode_icm(X, B0, K, m, [1, 2, 4], 3, 4, True, seed=seed)
-            assert np.array_equal(Bs, Bs_ref), "schedule %d: %d codes differ" % (schedule, (Bs != Bs_ref).sum())
+            assert np.array_equal(Bs, Bs_ref), "%r: %d codes differ" % (options, (Bs != Bs_ref).sum())
             assert np.array_equal(np.isnan(objs), np.isnan(objs_ref))
             # the "% equal / % better" counters too: a vector whose codes come back unchanged is "equal" without a cost
             # evaluation -- unless its cost is NaN, which the reference's `==` never counts
@@ -295,7 +340,7 @@ def test_full_size_properties(lsq):
     and invariance to sharding / chunking / schedule."""
     import torch
     n, d, m, ils, J, npert, seed = 1_000_000, 128, 8, [1, 3], 4, 4, 42
-    with lsq.Engine(0) as eng, lsq.Engine(0, chunk=300_000, schedule=2, tuning=True) as eng2, lsq.Engine(0, schedule=4) as eng4:
+    with lsq.Engine(0) as eng, lsq.Engine(0, chunk=300_000, schedule=3) as eng2, lsq.Engine(0, schedule=4) as eng4:
         dX = eng.synth_data_u8_dev(1234, n, d)
         dB0 = eng.randinit_dev(7, n, m)
         dK = eng.synth_codebooks_dev(4321, m, d)

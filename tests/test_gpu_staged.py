@@ -177,6 +177,52 @@ def test_cfg5_chunk_walk(lsq, oracle):
 
 
 
+def test_cfg4_per_gpu_share_runs_the_filtered_walk(lsq, oracle):
+    """BASELINE configs[3] as ONE GPU of the 8-GPU job runs it: 125 000 x 960 (GIST-like range), m = 8, 16-bit filtered walk by default
+    (n >= q16_min), Q16 GEMM epilogue with Kd = 960, the 4096-vector range sample (lsq_icmq.hip: d > 512), global offset of rank 3.
+    Default options.  >= 40 random rows + the first / last row + rows around block boundaries (489 vectors per block) vs the oracle run
+    on exactly those vectors (results depend on the global index only, P8); counters prove which path produced them."""
+    import torch
+    d, m, ils, J, npert, seed = 960, 8, [1, 2], 4, 4, 42
+    n, goff = 125_000, 375_000
+    with lsq.Engine(0, profile=True) as eng:
+        dX = eng.synth_data_u8_dev(1234, n, d, global_offset=goff)
+        dX.mul_(0.3 / 255.0)
+        dB0 = eng.randinit_dev(7, n, m, global_offset=goff)
+        dK = eng.synth_codebooks_dev(4321, m, d)
+        dK.mul_(0.3 / 255.0)
+        dBs, sums, stats = eng.encode_icm_dev(dX, dB0, dK, m, ils, J, npert, True, seed=seed, global_offset=goff)
+        torch.cuda.synchronize()
+        t = eng.timings()
+        assert t["filtered_blocks"] > 0 and t["staged_blocks"] == 0, t
+        assert t["filter_refined"] < 0.25 * t["icm_node_updates"], t
+        K = dK.cpu().numpy()
+        rng = np.random.default_rng(960)
+        per = -(-n // 256)
+        rows = [0, n - 1] + [b * per + o for b in (1, 2, 128, 255) for o in (-1, 0, 1)] + list(rng.choice(n, size=44, replace=False))
+        rows = np.array(sorted(set(int(r) for r in rows if 0 <= r < n)))
+        idx = torch.from_numpy(rows).to(dX.device)
+        Xs, B0s = dX[idx].cpu().numpy(), dB0[idx].cpu().numpy().astype(np.int16) + 1
+        for r, which in ((0, [1]), (1, [1, 2])):
+            gots = dBs[r][idx].cpu().numpy().astype(np.int16) + 1
+            for q, i in enumerate(rows):
+                ref, _ = oracle.encode_icm(Xs[q:q + 1], B0s[q:q + 1], K, m, H, which, J, npert, True, seed, global_offset=goff + int(i))
+                assert np.array_equal(ref[-1, 0], gots[q]), "snapshot %d, vector %d differs" % (r, i)
+        # objective = mean cost of the returned codes (P10) on the whole shard
+        c = eng.veccost(dX.cpu().numpy(), dBs[1].cpu().numpy().astype(np.int16) + 1, K, m)
+        assert abs(sums[1] / n - c.astype(np.float64).mean()) <= 1e-6 * sums[1] / n
+
+
+def test_filter_forced_at_d960_all_vectors(lsq, oracle):
+    """d = 960 through the forced filter (q16_min = 0, light = 0) on ALL vectors: the long chains (Kd = 960: 60 K chunks of the GEMM, odd row counts)
+    feeding the u16 epilogue, and the exact refinement with d > 257."""
+    d, n, m, ils, J, npert, seed = 960, 3001, 8, [2], 3, 4, 96
+    X, K, B0 = make_problem(d, n, m, seed=seed, kind="gauss")
+    X = (X * np.float32(0.1)).astype(np.float32)
+    t = _filter_case(lsq, oracle, X, K, B0, m, ils, J, npert, seed)
+    assert t["light_blocks"] == 0, t
+
+
 # ---- the 16-bit filter under adversarial value distributions -------------------------------------------------------------------
 def _filter_case(lsq, oracle, X, K, B0, m, ils, J, npert, seed, expect_filter=True):
     Bs_ref, objs_ref, st_ref = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, True, seed, want_stats=True)
