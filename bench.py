@@ -22,6 +22,10 @@ Prints ONE JSON line on rank 0 with the driver's contract fields plus
   `roofline`         dominant kernel (the ICM node update): algorithmic HBM bytes / HIP-event launch time vs 8 TB/s, the LDS-side
                      gather rate vs the guide's 150 TB/s, the M1 compulsory-bytes fraction, PMC traffic when the committed
                      profile was taken from THIS build (hash of the loaded .so), else null;
+  `workloads`        the SAME 10^6-vector encode on other inputs / options, because the GPU time is data-dependent (exact memoisation of
+                     unchanged node updates + the 16-bit filter): `trained` (codebooks trained by this package's own train_lsq on a 100 000-vector
+                     sample -- the reference encodes with trained codebooks, LSQ.jl:10-88 -> demo_lsq_gpu.jl:33-50), `floor` (memoisation off:
+                     every node update recomputed, filtered walk and f32 walk), `heavy_tailed` (Cauchy-scaled vectors: out-of-range unaries);
   `sample_parity`    two 256-vector blocks of the timed output re-computed with the CPU oracle after the timed region;
   `north_star_point` the same workload at north_star's own operating point (4 ILS iterations), with its CPU baseline;
   `end_to_end`       the host-buffer entry point lsq_encode_icm on pageable host memory (H2D of X, D2H of the codes included);
@@ -69,6 +73,8 @@ def parse():
     p.add_argument("--ablation", type=int, default=int(os.environ.get("LSQ_ABLATION", "0")), help="tuning build only; results invalid when != 0")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra-legs", action="store_true", help="skip sample_parity / north_star_point / end_to_end / the busy tail")
+    p.add_argument("--no-sample-parity", action="store_true", help="skip the oracle re-encode of 512 vectors of the timed output (profiling runs)")
+    p.add_argument("--no-workloads", action="store_true", help="skip the `workloads` leg (trained codebooks / no-memoisation floor / heavy tails)")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget for the cfg2 sample")
     p.add_argument("--min-gpu-seconds", type=float, default=6.0,
                    help="after the timed region keep running identical UNTIMED steps until the GPU legs have lasted this long "
@@ -86,7 +92,8 @@ def cpu_baseline(args):
     """Time the oracle's structure-faithful restatement of encoding_icm (reference src/encodings/encode_icm.jl:131-189 loop
     nest, one OpenMP thread per `julia -p` worker) on bounded samples.  Never part of the measured GPU path.
       * cfg2 sample: a 100 000-vector subset split over the workers, as many of the 16 ILS iterations as fit the
-        budget, scaled linearly (the control flow is data-independent);
+        budget, scaled linearly (the CPU restatement, like the reference, executes EVERY node update of every vector: its time does not depend
+        on the values -- unlike the GPU path, whose exact memoisation and 16-bit filter make the time data-dependent; see `workloads`);
       * cfg1 exactly: n = 10 000, d = 128, m = 8, one call = one ILS iteration with 4 sweeps (demo_lsq.jl:34);
       * the cache-blocked per-vector variant, so the ratio is not inflated by the reference's loop order alone."""
     import oracle as O
@@ -188,6 +195,82 @@ def pmc_traffic(lib_sha):
     return best
 
 
+def workloads_leg(lsq, eng, dX, dB0, dK, n, d, m, args, goff):
+    """The same n-vector encode under the conditions the headline number depends on.  Untimed w.r.t. `value`; every entry is
+    1 warm-up + 3 timed steps with the per-class timings of exactly those steps.  -> dict of sub-objects."""
+    import torch
+    h = 256
+    out = {}
+
+    def timed(X, K, options, note, steps=3):
+        saved = {"skip": args.skip, "fallback": 1, "schedule": args.schedule if args.schedule >= 0 else 6}
+        for k, v in options.items():
+            eng.set_option(k, v)
+        buf = torch.empty((1, n, m), dtype=torch.uint8, device=X.device)
+        run = lambda: eng.encode_icm_dev(X, dB0, K, m, [args.ils], args.icmiter, args.npert, True, seed=42, global_offset=goff, out=buf)
+        run()
+        torch.cuda.synchronize()
+        eng.reset_timings()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            _, sums, stats = run()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        tm = eng.timings()
+        for k in options:
+            eng.set_option(k, saved[k])
+        total_nu = n * args.ils * args.icmiter * m * steps
+        return {"value": n / dt, "unit": "vectors/s", "ms_per_step": dt * 1e3, "icm_ms": tm["icm_ms"] / steps, "unaries_ms": tm["unaries_ms"] / steps,
+                "cost_ms": tm["cost_ms"] / steps, "recomputed_fraction": tm["icm_node_updates"] / max(total_nu, 1),
+                "ambiguous_fraction": tm["filter_refined"] / max(tm["icm_node_updates"], 1),
+                "filter_f32": int(tm["filter_f32"] // steps), "filter_f32_fraction": tm["filter_f32"] / max(tm["icm_node_updates"], 1),
+                "blocks": {"staged_f32": int(tm["staged_blocks"] // steps), "light_f32": int(tm["light_blocks"] // steps),
+                           "filtered_u16": int(tm["filtered_blocks"] // steps)},
+                "objective": float(sums[0] / n), "last_ils_pct_better": float(100.0 * stats[-1, 1] / n), "options": options, "note": note}, buf
+
+    # ---- floor: no memoisation at all (every one of the I x J x m node updates of every vector is recomputed), filtered walk and f32 walk
+    out["floor"] = {}
+    out["floor"]["filtered_walk"], _ = timed(dX, dK, {"skip": 0, "fallback": 0},
+                                             "skip = 0, fallback = 0: what the step costs when the memoisation saves nothing (worst case of the data dependence)")
+    out["floor"]["f32_walk"], _ = timed(dX, dK, {"skip": 0, "fallback": 0, "schedule": 4}, "the same through schedule 4: no memoisation and no 16-bit filter")
+    out["f32_walk_with_memoisation"], _ = timed(dX, dK, {"schedule": 4}, "schedule 4 (f32 walk) with the default exact memoisation: what the 16-bit filter alone buys")
+
+    # ---- trained codebooks: this package's own train_lsq (host LSQR codebook update + GPU encode) on the first 100 000 vectors
+    ns = min(n, 100_000)
+    t0 = time.perf_counter()
+    Xs = dX[:ns].cpu().numpy()
+    Bs0 = dB0[:ns].cpu().numpy().astype(np.int16) + 1
+    with lsq.Engine(eng.device) as e2:
+        C, Btr, _, _, obj = lsq.train_lsq(np.ascontiguousarray(Xs.T), m, h, np.eye(d, dtype=np.float32), np.ascontiguousarray(Bs0.T), None,
+                                          8, 4, args.icmiter, True, args.npert, False, seed=42, engine=e2)
+    Ktr = np.ascontiguousarray(np.concatenate([np.asarray(Cj, dtype=np.float32).T for Cj in C], axis=0))
+    dKtr = torch.from_numpy(Ktr).to(dX.device)
+    train_s = time.perf_counter() - t0
+    out["trained"], btr = timed(dX, dKtr, {}, "codebooks = train_lsq(first %d vectors of the same data, random initial codes, 8 iterations x 4 ILS): "
+                                "trained in %.1f s (not timed); default options" % (ns, train_s))
+    out["trained"]["train_objective_first_last"] = [float(obj[0]), float(obj[-1])]
+    # parity on the trained workload too: 256 vectors of its output vs the oracle
+    import oracle as O
+    O.build()
+    a = n // 3
+    ref, _ = O.encode_icm(dX[a:a + 256].cpu().numpy(), dB0[a:a + 256].cpu().numpy().astype(np.int16) + 1, Ktr, m, h, [args.ils], args.icmiter,
+                          args.npert, True, 42, global_offset=goff + a)
+    out["trained"]["sample_parity"] = bool(np.array_equal(ref[0], btr[0][a:a + 256].cpu().numpy().astype(np.int16) + 1))
+
+    # ---- heavy tails: every vector scaled by a Cauchy variate (|x| spans orders of magnitude): the sampled level range misses outliers
+    g = torch.Generator(device=dX.device)
+    g.manual_seed(99)
+    scale = torch.empty((n, 1), dtype=torch.float32, device=dX.device).cauchy_(generator=g)
+    dXh = (dX * scale).contiguous()
+    out["heavy_tailed"], bh = timed(dXh, dK, {}, "x_i <- x_i * Cauchy(0,1): heavy-tailed norms; unaries outside the sampled 16-bit level range take the exact f32 path "
+                                    "(filter_f32); default options")
+    ref, _ = O.encode_icm(dXh[a:a + 256].cpu().numpy(), dB0[a:a + 256].cpu().numpy().astype(np.int16) + 1, dK.cpu().numpy(), m, h, [args.ils],
+                          args.icmiter, args.npert, True, 42, global_offset=goff + a)
+    out["heavy_tailed"]["sample_parity"] = bool(np.array_equal(ref[0], bh[0][a:a + 256].cpu().numpy().astype(np.int16) + 1))
+    del dXh, scale
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
@@ -206,6 +289,7 @@ def main():
     dev_index = local_rank % ndev                      # one rank per GPU in production; modulo only for 1-GPU smoke runs
     torch.cuda.set_device(dev_index)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -247,7 +331,7 @@ def main():
     if dX is None:
         dX = eng.synth_data_u8_dev(1234, n, d, global_offset=goff)
         if d == 960:
-            dX.mul_(0.3 / 255.0)                       # GIST-like range; the encode path is value-independent
+            dX.mul_(0.3 / 255.0)                       # GIST-like range
     dB0 = eng.randinit_dev(7, n, m, global_offset=goff)
     dK = eng.synth_codebooks_dev(4321, m, d) if rank == 0 else torch.zeros((m * h, d), dtype=torch.float32, device=dX.device)
     if d == 960 and rank == 0:
@@ -352,6 +436,8 @@ def main():
             "value": value, "unit": "vectors/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": data_tag,
+            "dtype_note": "every code is the exact f32 argmin of the reference's arithmetic (bit-exact vs the oracle); the dominant kernel FILTERS on 16-bit "
+                          "levels of the same sums (u16 planes written by the unary GEMM) and re-decides in exact f32 whatever the filter cannot prove",
             "config": {
                 "workload": "%s: %s base encode, %s, m=%d, h=%d, %d ILS iters x %d ICM sweeps, npert=%d, randord, seed=42; inputs resident "
                             "in HBM; lsq_encode_icm_dev" % (workload, "SIFT1M-shaped" if d == 128 else "GIST1M-shaped" if d == 960 else "synthetic",
@@ -362,7 +448,8 @@ def main():
                 "d": d, "m": m, "h": h, "ils_iters": args.ils, "icm_iters": args.icmiter, "npert": args.npert,
                 "skip_unchanged_nodes": bool(args.skip),
                 "parallelism": "%d x independent shards (one process per GPU), RCCL broadcast of codebooks, no collective in the sweep" % world,
-                "rccl_ranks": world, "library": os.path.basename(lib_path), "lib_sha16": lib_sha,
+                "collective_backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
+                "rccl_ranks": world if (world == 1 or backend == "nccl") else 0, "library": os.path.basename(lib_path), "lib_sha16": lib_sha,
             },
             "ranks": ranks,
             "objective": float(sums[0] / n), "last_ils_pct_better": float(100.0 * stats[-1, 1] / n),
@@ -373,10 +460,11 @@ def main():
             out["INVALID"] = "ablation %d: timing-only variant, results are garbage" % args.ablation
 
     # ---- extra legs: rank 0 of a single-GPU run only -----------------------------------------------------------------------
-    if rank == 0 and world == 1 and not args.no_extra_legs:
+    if rank == 0 and world == 1 and not args.no_sample_parity:      # copies two 256-row slices only: also on the 12.5 M-vector cfg5 share
         ok, detail = sample_parity(eng, dX, dB0, dK, dBs, n, m, args, goff)
         out["sample_parity"] = ok
         out["sample_parity_detail"] = detail
+    if rank == 0 and world == 1 and not args.no_extra_legs:
         # end to end through the host-buffer entry point (pageable numpy buffers): H2D of X / K / codes, encode, D2H of the codes
         if n * d * 4 <= 8 << 30:
             Xh, Kh = dX.cpu().numpy(), dK.cpu().numpy()
@@ -405,6 +493,8 @@ def main():
         ns_dt = (time.perf_counter() - t0) / args.steps
         out["north_star_point"] = {"ils_iters": ns_ils, "value": n / ns_dt, "unit": "vectors/s", "ms_per_step": ns_dt * 1e3,
                                    "note": "north_star quotes its >= 50x target at 4 ILS iterations; same workload otherwise"}
+        if not args.no_workloads and n * d * 4 <= 2 << 30:
+            out["workloads"] = workloads_leg(lsq, eng, dX, dB0, dK, n, d, m, args, goff)
         if args.multi_leg:
             devs = list(range(ndev)) if ndev > 1 else [0, 0]
             Xh, Kh = dX.cpu().numpy(), dK.cpu().numpy()
