@@ -77,6 +77,8 @@ typedef struct lsq_timings {
     int64_t filter_refined;  /* node updates the 16-bit filter could not decide: every candidate within the window evaluated exactly */
     int64_t filter_exact;    /* ... number of exact f32 candidate evaluations that took                               */
     int64_t filter_f32;      /* node updates sent to the f32 path because a unary fell outside the sampled level range  */
+    int64_t filter_fallback_chunks; /* resident chunks the filter handed to the f32 walk: non-finite / degenerate value ranges, or more than 1/64 of the
+                                * (vector, node) pairs outside the sampled level range (since v300)                     */
 } lsq_timings;
 
 LSQ_API const char *lsq_last_error(void);
@@ -115,6 +117,9 @@ LSQ_API int lsq_set_stream(lsq_ctx *ctx, void *hip_stream);
  *        bits (validity depends on the code tuple only): exact, ~12 % fewer node updates.
  *   "skip" (0/1, default 1): a node whose conditioning codes did not change since it was last minimised is not recomputed (exact memoisation --
  *        same codes, fewer bytes).
+ *   "filter_fallback_div" (default 64): schedule 6 hands a resident chunk to the f32 walk when more than 1 / div of its (vector, node) pairs
+ *        have a unary outside the sampled 16-bit level range (each such pair takes the one-wave-per-vector f32 routine, ~5x the cost of a filtered update);
+ *        0 = never.  Same codes.
  *   "ils_counter": the next iteration index used by lsq_encoding_icm / lsq_encode_icm_fully when called with it = LSQ_IT_AUTO
  *        (starts at 0, advances by one per such call).
  *   (liblsq_mi355x_tuning.so only) "ablation": timing-only kernel variants whose results are garbage. */
@@ -159,8 +164,8 @@ LSQ_API int lsq_encode_icm(lsq_ctx *ctx, const float *RX, const int16_t *B, cons
                    int nsplits, uint64_t seed, uint64_t global_offset, int verbose,
                    int16_t *Bs, float *objs);
 
-/* Same call on DEVICE-resident buffers, asynchronous on the context's stream except for the
- * final read-back of nr objective sums.  dB0 / dBs: uint8 0-based [n][m] (dBs: nr of them).
+/* Same call on DEVICE-resident buffers: launches go to the context's stream; the host waits once per resident chunk
+ * (schedule 6 reads the chunk's three-word verdict after the unary GEMM) and for the final read-back of nr objective sums.  dB0 / dBs: uint8 0-based [n][m] (dBs: nr of them).
  * obj_sums (host, nr doubles) receives SUM_i cost_i (not the mean) so that a multi-GPU caller
  * can add shards; objs = obj_sums / n_total.  stats (host, optional, 2*max(ilsiters) int64):
  * per ILS iteration the number of vectors whose new cost was == / < the previous one

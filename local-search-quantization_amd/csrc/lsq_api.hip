@@ -74,6 +74,9 @@ struct lsq_ctx {
     // workspace
     DevBuf sci, T, Ts, U, part, vCur, vNew, active, recCur, recNew, prev, counters, obj, bad;
     DevBuf Uq, Tq, qp, qscratch, qflag;                // 16-bit filtered walk: u16 unary planes, u16 slice tables, lsq_q16_params, bound scratch, per-vector out-of-range flags
+    bool chunk_q16 = false;                            // the resident chunk runs the filtered walk (set by build_unaries from the chunk's verdict)
+    int64_t fallback_div = 64;                         // option "filter_fallback_div": the chunk goes to the f32 walk when flagged pairs * div > all pairs (0 = never)
+    int64_t filter_fallback_chunks = 0;                // chunks the filter handed to the f32 walk (unusable bounds or too many out-of-range vectors)
     DevBuf sX, sX2, sK, sB16, sOut16, sTight, sF32;    // staging for the host-buffer entry points (sX/sX2: double-buffered X chunks)
     hipStream_t copy_stream = nullptr;               // H2D of X runs here, under the compute of the previous panel / chunk
     hipEvent_t copy_done = nullptr;
@@ -187,6 +190,10 @@ extern "C" int lsq_set_option(lsq_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "fallback")) c->fallback = (int)value;
     else if (!strcmp(key, "q16_min")) c->q16_min = value;
     else if (!strcmp(key, "per_node")) c->per_node = value != 0;
+    else if (!strcmp(key, "filter_fallback_div")) {
+        if (value < 0) { lsq_set_error("filter_fallback_div must be >= 0"); return LSQ_EINVAL; }
+        c->fallback_div = value;
+    }
     else if (!strcmp(key, "ils_counter")) {
         if (value < 0 || value >= (int64_t)LSQ_IT_AUTO) { lsq_set_error("ils_counter must lie in 0..2^32-2"); return LSQ_EINVAL; }
         c->auto_it = (uint32_t)value;
@@ -220,6 +227,7 @@ extern "C" int lsq_get_timings(lsq_ctx *c, lsq_timings *out) {
     out->filter_refined = c->filter_refined;
     out->filter_exact = c->filter_exact;
     out->filter_f32 = c->filter_f32;
+    out->filter_fallback_chunks = c->filter_fallback_chunks;
     return LSQ_OK;
 }
 
@@ -234,6 +242,7 @@ extern "C" int lsq_reset_timings(lsq_ctx *c) {
     LSQ_TRY(resolve_timings(c));
     for (double &v : c->cat_ms) v = 0.0;
     c->icm_launches = c->icm_node_updates = c->staged_blocks = c->light_blocks = c->filtered_blocks = c->filter_refined = c->filter_exact = c->filter_f32 = 0;
+    c->filter_fallback_chunks = 0;
     for (int64_t &v : c->trace) v = 0;
     return LSQ_OK;
 }
@@ -317,9 +326,10 @@ static int prepare_tables(lsq_ctx *c, const float *dK, int d, int m) {
 static bool use_q16(const lsq_ctx *c, int64_t cn) { return c->schedule == 6 && cn >= c->q16_min; }
 
 static int build_unaries(lsq_ctx *c, const float *dX, const float *dK, int d, int64_t cn, int m, int slice, int64_t r0, int64_t rows) {
-    uint16_t *dq = nullptr;
-    if (slice > 0 && r0 == 0 && rows == cn && use_q16(c, cn)) {
-        // 16-bit filtered walk: rigorous value bounds of this chunk -> parameters -> 16-bit slice tables; the GEMM below then also emits the u16 planes
+    c->chunk_q16 = false;
+    const bool q16 = slice > 0 && r0 == 0 && rows == cn && use_q16(c, cn);
+    if (q16) {
+        // 16-bit filtered walk: sampled value ranges of this chunk -> parameters -> 16-bit slice tables; the GEMM below then also emits the u16 planes
         Timer t(c, CAT_TABLES);
         LSQ_TRY(c->Uq.ensure(sizeof(uint16_t) * (size_t)m * (size_t)cn * LSQ_H));
         LSQ_TRY(c->Tq.ensure(sizeof(uint16_t) * (size_t)m * (size_t)(m > 1 ? m - 1 : 1) * LSQ_H * LSQ_H));
@@ -332,15 +342,30 @@ static int build_unaries(lsq_ctx *c, const float *dX, const float *dK, int d, in
                                        reinterpret_cast<int *>(sc + 16), reinterpret_cast<float *>(sc + 256), reinterpret_cast<unsigned *>(sc + 64),
                                        c->qflag.as<unsigned short>(), c->qp.as<lsq_q16_params>(), c->tables_changed));
         c->tables_changed = 0;
-        dq = c->Uq.as<uint16_t>();
     }
-    Timer t(c, CAT_UNARIES);
-    LSQ_TRY(c->U.ensure(sizeof(float) * (size_t)m * (size_t)cn * LSQ_H));
-    // row-major  (slice == 0): U[(j*cn + i)*h + a]                      = chain(x_i[t] * -2 K[j,a][t]) + sci[j,a]
-    // slice-major (slice = SL): U[j*cn*h + ((a/SL)*cn + i)*SL + a%SL]   (same values, LDS-slice schedule)
-    return lsq_launch_chain_gemm(c->stream, dX + r0 * d, dK, c->sci.as<float>(), -2.0f, rows, m * LSQ_H, d, LSQ_H, cn * (int64_t)LSQ_H, LSQ_H,
-                                 c->U.as<float>(), slice, cn, r0, dq, dq ? lsq_q16_slice_width(m) : 0, dq ? c->qp.as<lsq_q16_params>() : nullptr, 0,
-                                 dq ? c->qflag.as<unsigned short>() : nullptr, nullptr);
+    {
+        Timer t(c, CAT_UNARIES);
+        LSQ_TRY(c->U.ensure(sizeof(float) * (size_t)m * (size_t)cn * LSQ_H));
+        // row-major  (slice == 0): U[(j*cn + i)*h + a]                      = chain(x_i[t] * -2 K[j,a][t]) + sci[j,a]
+        // slice-major (slice = SL): U[j*cn*h + ((a/SL)*cn + i)*SL + a%SL]   (same values, LDS-slice schedule)
+        uint16_t *dq = q16 ? c->Uq.as<uint16_t>() : nullptr;
+        LSQ_TRY(lsq_launch_chain_gemm(c->stream, dX + r0 * d, dK, c->sci.as<float>(), -2.0f, rows, m * LSQ_H, d, LSQ_H, cn * (int64_t)LSQ_H, LSQ_H,
+                                      c->U.as<float>(), slice, cn, r0, dq, dq ? lsq_q16_slice_width(m) : 0, dq ? c->qp.as<lsq_q16_params>() : nullptr, 0,
+                                      dq ? c->qflag.as<unsigned short>() : nullptr, nullptr));
+    }
+    if (q16) {
+        // The chunk's verdict (three words, ONE host round trip per resident chunk -- 10^6 vectors, ~50 ms of work): usable bounds, and few enough
+        // (vector, node) pairs outside the sampled level range.  Such pairs take the one-wave-per-vector f32 routine inside the filtered walk (~5x the
+        // cost of a filtered update): above 1 / filter_fallback_div of the pairs -- heavy tails, a drifting or sorted chunk -- the f32 walk is the
+        // faster road for the whole chunk (measured: Cauchy-scaled vectors 2.2 -> 13 M vectors/s).  Exactness depends on neither road.
+        // The f32 unaries are there either way (the GEMM wrote both outputs), so the hand-over costs nothing but this read.
+        int verdict[3] = {0, 0, 0};      // lsq_q16_params: ok, oor, nflag
+        LSQ_HIP(hipMemcpyAsync(verdict, c->qp.p, sizeof(verdict), hipMemcpyDeviceToHost, c->stream));
+        LSQ_HIP(hipStreamSynchronize(c->stream));
+        if (verdict[0] == 1 && (int64_t)verdict[2] * c->fallback_div <= cn * (int64_t)m) c->chunk_q16 = true;
+        else c->filter_fallback_chunks += 1;
+    }
+    return LSQ_OK;
 }
 
 // ref_rec / ref_valid: the vectors' current records and validity masks (read-only during the sweeps), or nullptr
@@ -372,9 +397,8 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t c
         std::vector<int32_t> seq((size_t)nsweeps * m);
         for (int sw = 0; sw < nsweeps; ++sw)
             for (int q = 0; q < m; ++q) seq[(size_t)sw * m + q] = order[q];
-        if (use_q16(c, cn) && valid) {
-            // 16-bit filtered walk; when the chunk's bounds were not usable (params.ok == 0: non-finite data) it idles and the f32 walk
-            // below -- which idles when params.ok == 1 -- does the work.  64 node updates per launch, as below.
+        if (c->chunk_q16 && valid) {
+            // 16-bit filtered walk on the level planes of this chunk (build_unaries read the chunk's verdict); 64 node updates per launch
             const lsq_q16_params *P = c->qp.as<lsq_q16_params>();
             const size_t per_launch = c->per_node ? 1 : 64;
             for (size_t done = 0; done < seq.size(); done += per_launch) {
@@ -382,9 +406,6 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t c
                 LSQ_TRY(lsq_launch_icm_walkq(c->stream, c->U.as<float>(), c->Uq.as<uint16_t>(), c->Tq.as<uint16_t>(), c->T.as<float>(), rec, valid, cn, m,
                                              seq.data() + done, cntn, (int)done, c->skip, c->active.as<unsigned long long>(), c->light,
                                              c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr, P, c->qflag.as<unsigned short>()));
-                LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>(), c->Ts.as<float>(), c->T.as<float>(), rec, valid, cn, m, seq.data() + done, cntn, (int)done, c->skip,
-                                            c->active.as<unsigned long long>(), 0, c->light, c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr,
-                                            reinterpret_cast<const int *>(P)));
             }
             c->icm_launches += ((int64_t)seq.size() + (int64_t)per_launch - 1) / (int64_t)per_launch;
             return LSQ_OK;

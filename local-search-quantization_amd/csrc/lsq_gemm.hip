@@ -177,6 +177,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         float qlo = 0.f, qinv = 0.f, qhi = 0.f;
         int noor = 0;
         const bool q16 = Q16 == 1 && qp->ok != 0;          // unusable bounds (non-finite data): the f32 walk handles the chunk, nothing to emit
+        int npair = 0;                                       // (row, plane) pairs this lane flagged FIRST
         if (q16) {
             qlo = qp->node[c / h].loU;
             qinv = qp->node[c / h].invD;
@@ -195,7 +196,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     D[coff + (rbase + row) * rstride] = v;
                     if (q16) {
                         const float qf = rintf((v - qlo) * qinv);
-                        if (!(qf >= 0.0f && qf <= qhi)) { atomicOr(reinterpret_cast<unsigned *>(qflag + ((rbase + row) & ~(int64_t)1)), (1u << (c / h)) << (16 * (int)((rbase + row) & 1))); ++noor; }
+                        if (!(qf >= 0.0f && qf <= qhi)) {
+                            const unsigned bit = (1u << (c / h)) << (16 * (int)((rbase + row) & 1));
+                            const unsigned old = atomicOr(reinterpret_cast<unsigned *>(qflag + ((rbase + row) & ~(int64_t)1)), bit);
+                            npair += (old & bit) ? 0 : 1;
+                            ++noor;
+                        }
                         // levels go through an LDS tile so that they leave the chip as 16-byte stores (8 candidates of a row), not 2-byte ones
                         qtile[(wy * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * QLD + wx * 64 + tj * 32 + l31] = (uint16_t)fminf(fmaxf(qf, 0.0f), 65535.0f);
                     }
@@ -203,6 +209,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             }
         }
         if (q16 && noor) atomicAdd(&qp->oor, noor);
+        if (q16 && npair) atomicAdd(&qp->nflag, npair);
         if (Q16 == 2) { bmin = fminf(bmin, vmin); bmax = fmaxf(bmax, vmax); bnan = bnan || !(vmin == vmin && vmax == vmax); }
     }
     if (Q16 == 1) {

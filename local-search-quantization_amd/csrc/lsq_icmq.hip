@@ -17,8 +17,8 @@
 //            and all its exact ties -- is evaluated EXACTLY (the f32 unaries the GEMM also wrote, the f32 tables, canonical order)
 //            and the lexicographic (value, index) minimum is taken: the reference's strict-< scan.  Vectors with a unary outside
 //            the sampled level range are flagged by the GEMM and take the full-f32 routine (one wave per vector).
-// Non-finite inputs / degenerate ranges set params.ok = 0 and the launch leaves the chunk to icm_walk_kernel (both are enqueued;
-// exactly one of them works).  Parity: every test that compares icm_walk_kernel with the oracle also runs this kernel.
+// Non-finite inputs / degenerate ranges (params.ok = 0) or too many flagged vectors: the HOST reads the chunk's verdict after the unary GEMM
+// and gives the chunk to icm_walk_kernel instead (one round trip per resident chunk).  Parity: every test that compares icm_walk_kernel with the oracle also runs this kernel.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -137,6 +137,7 @@ __global__ __launch_bounds__(64) void q16_params_kernel(const float *__restrict_
         P->node[j] = nd;
     }
     P->ok = ok ? 1 : 0;          // P->oor accumulates over the chunks of a call (zeroed by the host at its start)
+    P->nflag = 0;                // per chunk: raised by the GEMM epilogue that follows
 }
 
 // Tq[j][slice][kk][b][SLQ] (u16)  <-  rint((T[j][k(kk)][b][slice*SLQ ..] - loT[j][k]) * invD_j)      (one thread per 8 levels = 16 B)
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
     constexpr int TAB = (M - 1) * LSQ_H * EPR;           // 16-byte entries of one slice table (global)
     constexpr int LTAB = TL::lds_entries(M);             // ... in LDS (planes, skew)
     constexpr int PP = TL::pp(M, BPC);                   // BPC = 1: the f32 walk's geometry (4096 up to m = 14); BPC = 2: two 512-thread blocks share a CU
-    if (P->ok == 0) return;                              // non-finite / degenerate bounds: icm_walk_kernel (enqueued next) does this launch's work
+    if (P->ok == 0) return;                              // never launched in that case (the host read the verdict after the GEMM); kept as a guard
 #ifdef LSQ_TUNING
     unsigned long long *dbgp = nullptr;
     if (g_walkq_dbg) {
@@ -837,7 +838,7 @@ static int launch_walkq_t(hipStream_t s, const float *U, const uint16_t *Uq, con
     return LSQ_OK;
 }
 
-// the filtered counterpart of lsq_launch_icm_walk; does nothing on the device when P->ok == 0 (the caller enqueues the f32 walk, guarded the other way)
+// the filtered counterpart of lsq_launch_icm_walk (the caller has read the chunk's verdict on the host)
 int lsq_launch_icm_walkq(hipStream_t s, const float *U, const uint16_t *Uq, const uint16_t *Tq, const float *T, uint8_t *rec, unsigned short *valid,
                          int64_t n, int m, const int32_t *order, int nnodes, int pos0, int use_skip, unsigned long long *active_total, int light,
                          const uint8_t *ref_rec, const unsigned short *ref_valid, const lsq_q16_params *P, const unsigned short *qflag) {

@@ -93,6 +93,7 @@ struct lsq_q16_node {
 struct lsq_q16_params {
     int ok;
     int oor;                   // values the GEMM epilogue found outside the sampled level range (their vectors are flagged and take the f32 path)
+    int nflag;                 // (vector, node) pairs flagged in this chunk: above 1 / filter_fallback_div of all pairs the host sends the whole chunk to the f32 walk
     lsq_q16_node node[LSQ_MAX_M];
 };
 
@@ -155,7 +156,7 @@ int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const fl
 // 16-bit filtered walk (lsq_icmq.hip).  lsq_launch_q16_prepare: per chunk, after the pair tables and before the unary GEMM -- bounds,
 // parameters P and the 16-bit slice tables Tq [m][256/SLQ][m-1][256][SLQ]; tables_changed = 1 on the first chunk of a call.
 // bad (1 int), trange (2 m m floats), qrange (2 * 16 + 1 u32): scratch.  lsq_launch_icm_walkq: same contract as lsq_launch_icm_walk plus
-// Uq (the GEMM's u16 planes), Tq and P; on the device it does nothing when P->ok == 0.
+// Uq (the GEMM's u16 planes), Tq and P; the caller launches it only after reading the chunk's verdict (P->ok, P->nflag) on the host.
 int lsq_q16_slice_width(int m);
 int lsq_launch_q16_prepare(hipStream_t s, const float *X, int64_t n, int d, const float *K, const float *sci, const float *T, int m, uint16_t *Tq,
                            int *bad, float *trange, unsigned *qrange, unsigned short *qflag, lsq_q16_params *P, int tables_changed);

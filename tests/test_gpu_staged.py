@@ -224,19 +224,21 @@ def test_filter_forced_at_d960_all_vectors(lsq, oracle):
 
 
 # ---- the 16-bit filter under adversarial value distributions -------------------------------------------------------------------
-def _filter_case(lsq, oracle, X, K, B0, m, ils, J, npert, seed, expect_filter=True):
+def _filter_case(lsq, oracle, X, K, B0, m, ils, J, npert, seed, expect_filter=True, **options):
     Bs_ref, objs_ref, st_ref = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, True, seed, want_stats=True)
     with lsq.Engine(0, schedule=6) as eng:
         eng.set_option("q16_min", 0)
         eng.set_option("light", 0)
+        for k, v in options.items():
+            eng.set_option(k, v)
         Bs, objs = eng.encode_icm(X, B0, K, m, ils, J, npert, True, seed=seed)
         t = eng.timings()
     assert np.array_equal(Bs, Bs_ref), "%d of %d codes differ (%r)" % ((Bs != Bs_ref).sum(), Bs.size, t)
     assert np.array_equal(np.isnan(objs), np.isnan(objs_ref)) and np.allclose(objs[~np.isnan(objs)], objs_ref[~np.isnan(objs)], rtol=1e-5, atol=0)
     if expect_filter:
-        assert t["filtered_blocks"] > 0 and t["staged_blocks"] == 0, t
+        assert t["filtered_blocks"] > 0 and t["staged_blocks"] == 0 and t["filter_fallback_chunks"] == 0, t
     else:
-        assert t["filtered_blocks"] == 0 and t["staged_blocks"] > 0, t      # unusable bounds: the f32 walk did the work
+        assert t["filtered_blocks"] == 0 and t["staged_blocks"] > 0 and t["filter_fallback_chunks"] > 0, t      # unusable bounds / too many flagged vectors: the f32 walk did the work
     return t
 
 
@@ -253,6 +255,45 @@ def test_filter_exact_ties_and_near_ties(lsq, oracle):
     K = K.reshape(m * H, d)
     t = _filter_case(lsq, oracle, X, K, B0, m, [1, 3], 3, 4, seed)
     assert t["filter_refined"] > 0 and t["filter_exact"] > 2 * t["filter_refined"], t      # some windows hold more than two candidates
+
+
+def test_filter_more_ambiguous_vectors_than_records(lsq, oracle):
+    """Every codeword duplicated: EVERY node update is an exact tie, so all ~1200 vectors of a block are ambiguous at once -- more than the 1024
+    refinement records a block holds: the overflow takes the one-wave-per-vector f32 routine.  All vectors vs the oracle."""
+    d, n, m, seed = 16, 300_000, 8, 56
+    X, K, B0 = make_problem(d, n, m, seed=seed, kind="gauss")
+    K = K.reshape(m, H, d).copy()
+    K[:, 1::2] = K[:, 0::2]
+    K = K.reshape(m * H, d)
+    t = _filter_case(lsq, oracle, X, K, B0, m, [1], 2, 4, seed)
+    assert t["filter_refined"] + t["filter_f32"] > 0.95 * t["icm_node_updates"], t
+    assert t["filter_refined"] > 0.5 * t["icm_node_updates"] and t["filter_f32"] > 0, t      # the records were full: some vectors overflowed
+
+
+def test_filter_light_blocks(lsq, oracle):
+    """Light blocks of the filtered walk (one wave per vector, f32 rows gathered from L2): default `light`, a chunk small enough that every block
+    is light, with ties, outliers beyond the sampled level range and the four skip x fallback rules."""
+    d, n, m, seed = 24, 40_000, 8, 57                      # 157 vectors per block: every block is light; the range sample takes every other 128-vector panel
+    X, K, B0 = make_problem(d, n, m, seed=seed, kind="gauss")
+    K = K.reshape(m, H, d).copy()
+    K[3, 1::2] = K[3, 0::2]                                # one codebook with duplicated codewords: ties at node 3 only
+    K = K.reshape(m * H, d)
+    X = X.copy()
+    hot = np.array([i for i in range(0, n, 53) if (i // 128) % 2 == 1])      # ~1 % of the vectors, in panels the sample does not see
+    X[hot] *= np.float32(6.0)                              # far outside the level range: flagged by the GEMM epilogue
+    Bs_ref, objs_ref = oracle.encode_icm(X, B0, K, m, H, [1, 3], 3, 4, True, seed)
+    for skip in (1, 0):
+        for fb in (1, 0):
+            with lsq.Engine(0, schedule=6, skip=skip, profile=True) as eng:
+                eng.set_option("q16_min", 0)
+                eng.set_option("fallback", fb)
+                eng.set_option("wave_max", 0)
+                eng.set_option("filter_fallback_div", 0)
+                Bs, objs = eng.encode_icm(X, B0, K, m, [1, 3], 3, 4, True, seed=seed)
+                t = eng.timings()
+            assert np.array_equal(Bs, Bs_ref), "skip=%d fallback=%d: %d codes differ (%r)" % (skip, fb, (Bs != Bs_ref).sum(), t)
+            assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0)
+            assert t["light_blocks"] > 0 and t["filtered_blocks"] == 0 and t["staged_blocks"] == 0, t
 
 
 def test_filter_offsets_scales_and_single_codebook(lsq, oracle):
@@ -307,11 +348,19 @@ def test_filter_outliers_beyond_the_sampled_range(lsq, oracle):
         t = _filter_case(lsq, oracle, Xa, K, B0, m, [2], 2, 4, seed)
         ta["filter_f32"] += t["filter_f32"]
     Xb = (X * rng.standard_cauchy((n, 1)).astype(np.float32)).astype(np.float32)
-    tb = _filter_case(lsq, oracle, Xb, K, B0, m, [2], 2, 4, seed)
+    tb = _filter_case(lsq, oracle, Xb, K, B0, m, [2], 2, 4, seed, filter_fallback_div=0)      # never hand the chunk over: every flagged vector takes the exact-256 routine
     Xc = X.copy()
     Xc[n // 2:] *= np.float32(1.7)
     tc = _filter_case(lsq, oracle, Xc, K, B0, m, [1], 2, 4, seed)
     assert ta["filter_f32"] + tb["filter_f32"] + tc["filter_f32"] > 0, (ta, tb, tc)      # at least one case exercised the per-vector flags
+    # the chunk-level decision: a third of the vectors scaled far outside the sampled range.  Above 1/64 of the pairs the whole chunk goes
+    # to the f32 walk; with the hand-over disabled the same chunk runs the exact-256 routine on every flagged pair.  Same codes both ways.
+    Xd = X.copy()
+    hot = np.array([i for i in range(n) if (i // 128) % 2 == 1 and i % 3 == 0])            # never in the sample (odd panels)
+    Xd[hot] *= np.float32(40.0)
+    td = _filter_case(lsq, oracle, Xd, K, B0, m, [1], 2, 4, seed, expect_filter=False)
+    te = _filter_case(lsq, oracle, Xd, K, B0, m, [1], 2, 4, seed, filter_fallback_div=0)
+    assert te["filter_f32"] > 1000, te
 
 
 def test_filter_degenerate_ranges(lsq, oracle):

@@ -6,6 +6,7 @@ sys.path.insert(0, '.')
 lsq = importlib.import_module("local-search-quantization_amd")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 per_node = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+m = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 L = lsq._lib.load(tuning=True)
 W = 24 + 2 * 65
 buf = torch.zeros((4096, W), dtype=torch.int64, device="cuda")
@@ -16,8 +17,8 @@ with lsq.Engine(0, schedule=6, tuning=True) as eng:
     eng.set_option("per_node", per_node)
     eng.set_option("q16_min", 0)
     eng.set_option("light", int(sys.argv[3]) if len(sys.argv) > 3 else 0)
-    dX = eng.synth_data_u8_dev(1234, n, 128); dB0 = eng.randinit_dev(7, n, 8); dK = eng.synth_codebooks_dev(4321, 8, 128)
-    eng.encode_icm_dev(dX, dB0, dK, 8, [2], 4, 4, True, seed=42)
+    dX = eng.synth_data_u8_dev(1234, n, 128); dB0 = eng.randinit_dev(7, n, m); dK = eng.synth_codebooks_dev(4321, m, 128)
+    eng.encode_icm_dev(dX, dB0, dK, m, [2], 4, 4, True, seed=42)
 torch.cuda.synchronize()
 t = buf.cpu().numpy()
 rows = t[(t[:, 0] != 0)]
