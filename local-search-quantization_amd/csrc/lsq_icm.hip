@@ -712,6 +712,135 @@ __global__ __launch_bounds__(256) void cost2_kernel(const float *__restrict__ X,
     }
 }
 
+// d % 4 == 0: a QUARTER wave (one 16-lane DPP row) per vector, 16-byte loads.  Lane l' (0..15) of a row owns dimensions t = 64 q + 4 l' .. + 3
+// for q = 0, 1, ..: the four residues 4 l' .. 4 l' + 3 (mod 64) of the canonical 64 strided partial sums, each accumulated in ascending t, so the
+// reduction order is exactly oracle cost_one()'s: levels 1 and 2 in-lane ((p0 + p1) + (p2 + p3)), levels 4 .. 32 across the 16 lanes of the row
+// (DPP).  A global load costs the texture-address unit 16 cycles per wave whatever its width, and the kernel is bound by what a CU can pull out
+// of L2 (m codeword rows per vector): four-dword loads move twice the bytes per instruction of cost2_kernel, four times those of cost_kernel.
+template <int M>
+__global__ __launch_bounds__(256) void cost4_kernel(const float *__restrict__ X, const float *__restrict__ K,
+                                                    const uint8_t *rec, uint8_t *cur, float *__restrict__ prev,
+                                                    unsigned long long *__restrict__ counters, int64_t n, int d, int mode,
+                                                    const unsigned short *vnew, unsigned short *vcur, const lsq_perturb_next pn) {
+    constexpr int CS = (M <= 8) ? 8 : 16;
+    constexpr int RW = CS / 4;
+    const int lane = threadIdx.x & 63;
+    const int qtr = lane >> 4, lp = lane & 15;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    unsigned n_eq = 0, n_lt = 0;
+    // 64 consecutive vectors per wave batch; vectors whose candidate record equals the current one keep their cost (see cost_kernel) and are
+    // skipped; the others are taken four at a time, one per row.
+    for (int64_t base = w * 64; base < n; base += nwaves * 64) {
+        const int64_t il = base + lane;
+        const bool livel = il < n;
+        const int64_t ic = livel ? il : n - 1;
+        uint32_t rn[RW], cw[RW];
+        bool same = (mode == 1);
+#pragma unroll
+        for (int q = 0; q < RW; ++q) {
+            rn[q] = reinterpret_cast<const uint32_t *>(rec + ic * CS)[q];
+            cw[q] = (mode == 1) ? reinterpret_cast<const uint32_t *>(cur + ic * CS)[q] : rn[q];
+            same = same && (rn[q] == cw[q]);
+        }
+        const float pl = (mode == 1) ? prev[ic] : 0.0f;
+        const bool skip = livel && same && (pl == pl);
+        const unsigned nskip = (unsigned)__popcll(__ballot(skip));
+        if (lane == 0) n_eq += nskip;
+        unsigned short vfin = (livel && vcur) ? vcur[il] : (unsigned short)0;      // the vector's validity word after this kernel (for the fused perturbation)
+        const unsigned short vn = (livel && vcur && mode == 1) ? vnew[il] : (unsigned short)0;
+        if (same && livel && vcur) { vfin = (unsigned short)(vfin | vn); vcur[il] = vfin; }     // same tuple: what the sweeps learnt about it is kept
+        uint64_t accepted = 0;                                                      // bit l: the candidate of vector base + l replaced the current record
+        uint64_t todo = __ballot(livel && !skip);
+        while (todo) {
+            int sidx[4];
+            bool hv[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {                                           // fewer than four left: the spare rows repeat the first, unwritten
+                hv[v] = todo != 0;
+                sidx[v] = hv[v] ? __builtin_ctzll(todo) : sidx[0];
+                if (hv[v]) todo &= todo - 1;
+            }
+            const bool live = qtr == 0 ? hv[0] : qtr == 1 ? hv[1] : qtr == 2 ? hv[2] : hv[3];
+            const int mys = qtr == 0 ? sidx[0] : qtr == 1 ? sidx[1] : qtr == 2 ? sidx[2] : sidx[3];
+            const int64_t i = base + mys;
+            uint32_t r[RW];
+            float pc;
+            {
+                uint32_t rv4[4][RW];
+                float pc4[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+#pragma unroll
+                    for (int q = 0; q < RW; ++q) rv4[v][q] = (uint32_t)__builtin_amdgcn_readlane((int)rn[q], sidx[v]);
+                    pc4[v] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pl), sidx[v]));
+                }
+#pragma unroll
+                for (int q = 0; q < RW; ++q) r[q] = qtr == 0 ? rv4[0][q] : qtr == 1 ? rv4[1][q] : qtr == 2 ? rv4[2][q] : rv4[3][q];
+                pc = qtr == 0 ? pc4[0] : qtr == 1 ? pc4[1] : qtr == 2 ? pc4[2] : pc4[3];
+            }
+            const float *x = X + i * (int64_t)d;
+            const float *kb[M];
+#pragma unroll
+            for (int k = 0; k < M; ++k) kb[k] = K + ((int64_t)(k * LSQ_H) + ((r[k >> 2] >> (8 * (k & 3))) & 0xffu)) * d;
+            f32x4 p = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int c0 = 0; c0 < d; c0 += 64) {
+                const int t = c0 + 4 * lp;
+                const bool ok = t < d;
+                const int u = ok ? t : 0;
+                const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + u);
+                f32x4 kv[M];
+#pragma unroll
+                for (int k = 0; k < M; ++k) kv[k] = *reinterpret_cast<const f32x4 *>(kb[k] + u);
+                f32x4 cb = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < M; ++k) cb = cb + kv[k];                            // k ascending from 0 (utils.jl:238-244)
+                const f32x4 rr = cb - xv;
+                const f32x4 sq = rr * rr;                                               // never fused (-ffp-contract=off)
+                p.x = p.x + (ok ? sq.x : 0.0f);                                         // residues 4 l' .. 4 l' + 3: t ascending
+                p.y = p.y + (ok ? sq.y : 0.0f);
+                p.z = p.z + (ok ? sq.z : 0.0f);
+                p.w = p.w + (ok ? sq.w : 0.0f);
+            }
+            float v = (p.x + p.y) + (p.z + p.w);                                        // tree levels 1 and 2
+            v = v + dpp_self<DPP_XOR1, 0xf>(v);                                         // levels 4, 8, 16, 32: within the row
+            v = v + dpp_self<DPP_XOR2, 0xf>(v);
+            v = v + dpp_self<DPP_HALF_MIRROR, 0xf>(v);
+            v = v + dpp_self<DPP_MIRROR, 0xf>(v);
+            const float cost = v;                                                       // every lane of the row holds its vector's cost
+            if (mode == 0) {
+                if (live && lp == 0) prev[i] = cost;
+            } else {
+                const bool eq = live && (cost == pc), lt = live && (cost < pc);          // strict improvement only (encode_icm.jl:183-186)
+                const uint64_t bl = __ballot(lt && lp == 0);                              // bits 0, 16, 32, 48: the four rows' vectors
+                const unsigned ne = (unsigned)__popcll(__ballot(eq && lp == 0)), nl = (unsigned)__popcll(bl);
+#pragma unroll
+                for (int v2 = 0; v2 < 4; ++v2)
+                    if ((bl >> (16 * v2)) & 1ull) accepted |= 1ull << sidx[v2];
+                if (lane == 0) { n_eq += ne; n_lt += nl; }
+                if (lt && lp == 0) {
+                    prev[i] = cost;
+                    uint32_t *qd = reinterpret_cast<uint32_t *>(cur + i * CS);
+#pragma unroll
+                    for (int q = 0; q < RW; ++q) qd[q] = r[q];
+                    if (vcur) vcur[i] = vnew[i];
+                }
+            }
+        }
+        if (pn.on && livel) {
+            const bool acc = (accepted >> lane) & 1ull;
+            uint32_t fin[RW];
+#pragma unroll
+            for (int q = 0; q < RW; ++q) fin[q] = acc ? rn[q] : cw[q];
+            perturb_next_store<CS>(pn, il, fin, acc ? vn : vfin);
+        }
+    }
+    if (mode == 1 && lane == 0 && (n_eq | n_lt)) {
+        if (n_eq) atomicAdd(&counters[0], (unsigned long long)n_eq);
+        if (n_lt) atomicAdd(&counters[1], (unsigned long long)n_lt);
+    }
+}
+
 __global__ __launch_bounds__(256) void sum_f64_kernel(const float *__restrict__ v, int64_t n, double *__restrict__ sum) {
     __shared__ double sh[4];
     double acc = 0.0;
@@ -962,9 +1091,12 @@ int lsq_launch_cost(hipStream_t s, const float *X, const float *K, const uint8_t
     if (n <= 0) return LSQ_OK;
     lsq_perturb_next pn = {};
     if (next) pn = *next;
-    const int use_v2 = LSQ_KNOB("LSQ_COST_V2", 1);
-    // half a wave per vector with 8-byte loads: measured 13 % faster at d = 128, 7 % slower at d = 960 (same box)
-    if (use_v2 && d % 2 == 0 && d <= 256 && ((uintptr_t)X | (uintptr_t)K) % 8 == 0) {
+    const int use_v2 = LSQ_KNOB("LSQ_COST_V2", 1), use_v4 = LSQ_KNOB("LSQ_COST_V4", 1);
+    // a quarter wave per vector with 16-byte loads (any d that is a multiple of 4); else half a wave per vector with 8-byte loads (measured 13 %
+    // faster than the scalar kernel at d = 128, 7 % slower at d = 960); else one wave per vector, 4-byte loads
+    if (use_v4 && d % 4 == 0 && ((uintptr_t)X | (uintptr_t)K) % 16 == 0) {
+        LSQ_DISPATCH_M(m, hipLaunchKernelGGL(cost4_kernel<M_>, dim3(wave_grid((n + 3) / 4)), dim3(256), 0, s, X, K, rec, cur, prev, counters, n, d, mode, vnew, vcur, pn));
+    } else if (use_v2 && d % 2 == 0 && d <= 256 && ((uintptr_t)X | (uintptr_t)K) % 8 == 0) {
         LSQ_DISPATCH_M(m, hipLaunchKernelGGL(cost2_kernel<M_>, dim3(wave_grid((n + 1) / 2)), dim3(256), 0, s, X, K, rec, cur, prev, counters, n, d, mode, vnew, vcur, pn));
     } else {
         LSQ_DISPATCH_M(m, hipLaunchKernelGGL(cost_kernel<M_>, dim3(wave_grid((n + 1) / 2)), dim3(256), 0, s, X, K, rec, cur, prev, counters, n, d, mode, vnew, vcur, pn));
