@@ -48,7 +48,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (~6.3 TB/s achievable)
 HBM_ACHIEVABLE_GBS = 6300.0
 LDS_PEAK_GBS = 150000.0        # same guide, section LDS: ds_read_b64/b128 aggregate with every CU streaming
-PMC_GLOB = "r02*_pmc_per_kernel.json"      # committed PMC passes; `traffic` is read from the newest one whose build hash matches
+PMC_GLOB = "r0[23]*_pmc_per_kernel.json"      # committed PMC passes; `traffic` is read from the newest one whose build hash matches
 
 
 def parse():
@@ -169,9 +169,22 @@ def sample_parity(eng, dX, dB0, dK, dBs, n, m, args, goff):
     return bad == 0, "%d vectors of the timed output re-encoded by oracle/lsq_oracle.c: %d differ" % (checked, bad)
 
 
+def workload_key(argv):
+    """the shape-defining flags of a bench.py command line, canonical: a PMC profile only speaks for the workload it was taken on"""
+    keep, shape = [], ("--vectors", "--scaling", "--total", "--dim", "--codebooks", "--ils", "--icmiter", "--npert", "--schedule", "--skip", "--option", "--chunk")
+    it = iter(argv)
+    for a in it:
+        if a in shape:
+            keep.append(a + "=" + next(it, ""))
+        elif any(a.startswith(k + "=") for k in shape):
+            keep.append(a)
+    return " ".join(sorted(keep))
+
+
 def pmc_traffic(lib_sha):
     """HBM traffic per ICM launch from the newest committed PMC profile taken from THIS build (its `_build.lib_sha16` must equal
-    the hash of the loaded .so); None when there is none -- a stale profile is never reported next to fresh timings."""
+    the hash of the loaded .so) ON THIS WORKLOAD (same shape flags); None when there is none -- a stale or foreign profile is never
+    reported next to fresh timings."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", PMC_GLOB))):
@@ -180,6 +193,8 @@ def pmc_traffic(lib_sha):
         except Exception:
             continue
         if pmc.get("_build", {}).get("lib_sha16") != lib_sha:
+            continue
+        if workload_key(pmc.get("_build", {}).get("bench_args", "").split()) != workload_key(sys.argv[1:]):
             continue
         wk = [k for k in pmc if k.startswith("icm_walk") and "FETCH_SIZE" in pmc[k] and "WRITE_SIZE" in pmc[k]]
         if not wk:

@@ -9,10 +9,16 @@ O=$R/gpurun_out/final_$TAG
 mkdir -p "$O"
 bash tools/profile_round.sh "$TAG" > "$O/profile_round.log" 2>&1
 cp gpurun_out/prof_$TAG/${TAG}_bench_kernel_stats.csv gpurun_out/prof_$TAG/${TAG}_pmc_per_kernel.json gpurun_out/prof_$TAG/${TAG}_bench_line.json "$O/" 2>/dev/null
-B="python bench.py --no-cpu-baseline --steps 5"
+# PMC passes for the other BASELINE shapes too: cfg3 (m = 16) and cfg4's per-GPU share
+bash tools/profile_round.sh "${TAG}cfg3" --codebooks 16 > "$O/profile_cfg3.log" 2>&1
+cp gpurun_out/prof_${TAG}cfg3/${TAG}cfg3_pmc_per_kernel.json gpurun_out/prof_${TAG}cfg3/${TAG}cfg3_bench_kernel_stats.csv "$O/" 2>/dev/null
+bash tools/profile_round.sh "${TAG}cfg4" --scaling strong --total 125000 --dim 960 > "$O/profile_cfg4.log" 2>&1
+cp gpurun_out/prof_${TAG}cfg4/${TAG}cfg4_pmc_per_kernel.json gpurun_out/prof_${TAG}cfg4/${TAG}cfg4_bench_kernel_stats.csv "$O/" 2>/dev/null
+python tools/scaling_shares.py "$O/${TAG}_scaling_shares.json" > "$O/scaling.log" 2>&1
+B="python bench.py --no-cpu-baseline --no-workloads --steps 5"
 $B --codebooks 16 > "$O/${TAG}_bench_cfg3.json" 2> "$O/cfg3.err"
 $B --scaling strong --total 125000 --dim 960 > "$O/${TAG}_bench_cfg4_share.json" 2> "$O/cfg4.err"
-$B --vectors 12500000 --steps 2 --no-extra-legs > "$O/${TAG}_bench_cfg5_share.json" 2> "$O/cfg5.err"
+$B --vectors 12500000 --steps 2 --no-extra-legs > "$O/${TAG}_bench_cfg5_share.json" 2> "$O/cfg5.err"      # sample_parity stays on (two 256-row slices)
 LSQ_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 \
     --scaling strong --total 250000 --dim 960 --steps 3 --no-cpu-baseline > "$O/${TAG}_bench_cfg4_2rank_1gpu_gloo.json" 2> "$O/gloo.err"
 python tools/sched_cmp.py > "$O/sched_cmp.log" 2>&1 && cp gpurun_out/r02g/sched_cmp.json "$O/${TAG}_schedule6_vs_4_shapes.json"
