@@ -77,8 +77,9 @@ typedef struct lsq_timings {
     int64_t filter_refined;  /* node updates the 16-bit filter could not decide: every candidate within the window evaluated exactly */
     int64_t filter_exact;    /* ... number of exact f32 candidate evaluations that took                               */
     int64_t filter_f32;      /* node updates sent to the f32 path because a unary fell outside the sampled level range  */
-    int64_t filter_fallback_chunks; /* resident chunks the filter handed to the f32 walk: non-finite / degenerate value ranges, or more than 1/64 of the
-                                * (vector, node) pairs outside the sampled level range (since v300)                     */
+    int64_t filter_fallback_chunks; /* resident chunks the filter handed to the f32 walk: non-finite / degenerate value ranges, more than 1/64 of the
+                                * (vector, node) pairs outside the sampled level range, or a first ILS iteration in which the filter decided too
+                                * little (since v300)                                                                   */
 } lsq_timings;
 
 LSQ_API const char *lsq_last_error(void);
@@ -120,6 +121,9 @@ LSQ_API int lsq_set_stream(lsq_ctx *ctx, void *hip_stream);
  *   "filter_fallback_div" (default 64): schedule 6 hands a resident chunk to the f32 walk when more than 1 / div of its (vector, node) pairs
  *        have a unary outside the sampled 16-bit level range (each such pair takes the one-wave-per-vector f32 routine, ~5x the cost of a filtered update);
  *        0 = never.  Same codes.
+ *   "filter_probe_div" (default 8): after the FIRST ILS iteration of a resident chunk schedule 6 reads that iteration's counters and runs the
+ *        remaining iterations as schedule 4 when more than 1 / div of the recomputed node updates needed the exact refinement or the f32 routine
+ *        (a level step blown up by a few extreme values: scale-mixture / heavy-tailed data); 0 = never.  Same codes.
  *   "ils_counter": the next iteration index used by lsq_encoding_icm / lsq_encode_icm_fully when called with it = LSQ_IT_AUTO
  *        (starts at 0, advances by one per such call).
  *   (liblsq_mi355x_tuning.so only) "ablation": timing-only kernel variants whose results are garbage. */

@@ -73,6 +73,10 @@ struct lsq_ctx {
     uint32_t auto_it = 0;    // ILS-iteration counter of the CPU-shaped entry points called with it = LSQ_IT_AUTO: advances by one per call
     // workspace
     DevBuf sci, T, Ts, U, part, vCur, vNew, active, recCur, recNew, prev, counters, obj, bad;
+    DevBuf probe;                                      // walk counters of a chunk's FIRST ILS iteration on the filtered path (read back: is the filter paying off?)
+    unsigned long long *walk_counters = nullptr;       // where the walk launches accumulate their statistics (c->active, or c->probe during that first iteration)
+    int64_t probe_div = 8;                             // option "filter_probe_div": after the first iteration the chunk goes to the f32 walk when
+                                                       // (refined + f32-routed) * div > recomputed node updates (0 = never)
     DevBuf Uq, Tq, qp, qscratch, qflag;                // 16-bit filtered walk: u16 unary planes, u16 slice tables, lsq_q16_params, bound scratch, per-vector out-of-range flags
     bool chunk_q16 = false;                            // the resident chunk runs the filtered walk (set by build_unaries from the chunk's verdict)
     int64_t fallback_div = 64;                         // option "filter_fallback_div": the chunk goes to the f32 walk when flagged pairs * div > all pairs (0 = never)
@@ -158,7 +162,7 @@ extern "C" int lsq_destroy(lsq_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : c->pool) (void)hipEventDestroy(e);
-    DevBuf *bufs[] = {&c->Uq, &c->Tq, &c->qp, &c->qscratch, &c->qflag, &c->sci, &c->T, &c->Ts, &c->U, &c->part, &c->vCur, &c->vNew, &c->active, &c->recCur, &c->recNew, &c->prev, &c->counters, &c->obj, &c->bad,
+    DevBuf *bufs[] = {&c->probe, &c->Uq, &c->Tq, &c->qp, &c->qscratch, &c->qflag, &c->sci, &c->T, &c->Ts, &c->U, &c->part, &c->vCur, &c->vNew, &c->active, &c->recCur, &c->recNew, &c->prev, &c->counters, &c->obj, &c->bad,
                       &c->sX, &c->sX2, &c->sK, &c->sB16, &c->sOut16, &c->sTight, &c->sF32};
     for (DevBuf *b : bufs) b->release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -190,6 +194,10 @@ extern "C" int lsq_set_option(lsq_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "fallback")) c->fallback = (int)value;
     else if (!strcmp(key, "q16_min")) c->q16_min = value;
     else if (!strcmp(key, "per_node")) c->per_node = value != 0;
+    else if (!strcmp(key, "filter_probe_div")) {
+        if (value < 0) { lsq_set_error("filter_probe_div must be >= 0"); return LSQ_EINVAL; }
+        c->probe_div = value;
+    }
     else if (!strcmp(key, "filter_fallback_div")) {
         if (value < 0) { lsq_set_error("filter_fallback_div must be >= 0"); return LSQ_EINVAL; }
         c->fallback_div = value;
@@ -404,7 +412,7 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t c
             for (size_t done = 0; done < seq.size(); done += per_launch) {
                 const int cntn = (int)std::min<size_t>(per_launch, seq.size() - done);
                 LSQ_TRY(lsq_launch_icm_walkq(c->stream, c->U.as<float>(), c->Uq.as<uint16_t>(), c->Tq.as<uint16_t>(), c->T.as<float>(), rec, valid, cn, m,
-                                             seq.data() + done, cntn, (int)done, c->skip, c->active.as<unsigned long long>(), c->light,
+                                             seq.data() + done, cntn, (int)done, c->skip, c->walk_counters, c->light,
                                              c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr, P, c->qflag.as<unsigned short>()));
             }
             c->icm_launches += ((int64_t)seq.size() + (int64_t)per_launch - 1) / (int64_t)per_launch;
@@ -418,23 +426,25 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t c
             const int light_max = c->light >= 0 ? c->light : 256;
             if (c->ablation == 0 && per_pass <= light_max && per_pass <= c->wave_max) {
                 LSQ_TRY(lsq_launch_icm_wave(c->stream, c->U.as<float>(), c->T.as<float>(), rec, valid, cn, m, seq.data(), (int)seq.size(), 0, c->skip,
-                                            c->active.as<unsigned long long>(), c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr));
+                                            c->walk_counters, c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr));
                 c->icm_launches += ((int64_t)seq.size() + 63) / 64;
                 return LSQ_OK;
             }
         }
         LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>(), c->Ts.as<float>(), c->T.as<float>(), rec, valid, cn, m, seq.data(), (int)seq.size(), 0, c->skip,
-                                    c->active.as<unsigned long long>(), c->ablation, c->light, c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr));
+                                    c->walk_counters, c->ablation, c->light, c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr));
         c->icm_launches += ((int64_t)seq.size() + 63) / 64;
     } else {
         for (int sw = 0; sw < nsweeps; ++sw)
             for (int q = 0; q < m; ++q)
                 LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>(), c->Ts.as<float>(), c->T.as<float>(), rec, valid, cn, m, &order[q], 1, sw * m + q, c->skip,
-                                            c->active.as<unsigned long long>(), c->ablation, c->light, c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr));
+                                            c->walk_counters, c->ablation, c->light, c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr));
         c->icm_launches += (int64_t)nsweeps * m;
     }
     return LSQ_OK;
 }
+
+static void fold_walk_counters(lsq_ctx *c, const unsigned long long *act);
 
 struct EncodeParams {
     int d, m;
@@ -471,7 +481,29 @@ static int encode_chunk(lsq_ctx *c, const float *dXc, const float *dK, int64_t c
     for (int64_t it = 0; it < I; ++it) {
         int32_t order[LSQ_MAX_M];
         LSQ_TRY(lsq_node_order(P.seed, P.it0 + (uint32_t)it, P.m, P.randord, order));
+        const bool probing = it == 0 && c->chunk_q16 && c->probe_div > 0 && I > 1;
+        if (probing) {
+            LSQ_TRY(c->probe.ensure(sizeof(unsigned long long) * LSQ_WALK_COUNTERS));
+            LSQ_HIP(hipMemsetAsync(c->probe.p, 0, sizeof(unsigned long long) * LSQ_WALK_COUNTERS, c->stream));
+            c->walk_counters = c->probe.as<unsigned long long>();
+        }
         LSQ_TRY(run_sweeps(c, nw, vnew, cn, P.m, order, P.icmiter, cur, vcur));
+        if (probing) {
+            // Is the filter paying off on THIS chunk?  A level step blown up by a few extreme values (scale-mixture / heavy-tailed data) leaves most
+            // node updates ambiguous: each then costs an exact refinement (or, past the block's 1024 records, the one-wave f32 routine) on top of the
+            // level walk, and the f32 walk is several times faster (measured: Cauchy-scaled vectors 2.2 M vectors/s filtered, 13 M on the f32 walk).
+            // The first ILS iteration's counters tell; the f32 unaries are resident either way, so the remaining iterations just change road.
+            c->walk_counters = c->active.as<unsigned long long>();
+            unsigned long long act[LSQ_WALK_COUNTERS] = {0};
+            LSQ_HIP(hipMemcpyAsync(act, c->probe.p, sizeof(act), hipMemcpyDeviceToHost, c->stream));
+            LSQ_HIP(hipStreamSynchronize(c->stream));
+            fold_walk_counters(c, act);
+            const unsigned long long hard = act[4 + LSQ_WALK_TRACE] + act[4 + LSQ_WALK_TRACE + 2];
+            if ((long double)hard * (long double)c->probe_div > (long double)act[0]) {
+                c->chunk_q16 = false;
+                c->filter_fallback_chunks += 1;
+            }
+        }
         {
             Timer t(c, CAT_COST);
             pn.it = P.it0 + (uint32_t)it + 1u;
@@ -505,10 +537,23 @@ static int begin_call(lsq_ctx *c, int64_t I, int nr) {
     LSQ_TRY(c->bad.ensure(sizeof(int)));
     LSQ_TRY(c->active.ensure(sizeof(unsigned long long) * LSQ_WALK_COUNTERS));
     LSQ_HIP(hipMemsetAsync(c->active.p, 0, sizeof(unsigned long long) * LSQ_WALK_COUNTERS, c->stream));
+    c->walk_counters = c->active.as<unsigned long long>();
     LSQ_HIP(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long) * 2 * (size_t)std::max<int64_t>(I, 1), c->stream));
     LSQ_HIP(hipMemsetAsync(c->obj.p, 0, sizeof(double) * (size_t)std::max(nr, 1), c->stream));
     LSQ_HIP(hipMemsetAsync(c->bad.p, 0, sizeof(int), c->stream));
     return LSQ_OK;
+}
+
+static void fold_walk_counters(lsq_ctx *c, const unsigned long long *act) {
+    if (c->schedule < 3) return;
+    c->icm_node_updates += (int64_t)act[0];
+    c->staged_blocks += (int64_t)act[1];
+    c->light_blocks += (int64_t)act[2];
+    c->filtered_blocks += (int64_t)act[3];
+    c->filter_refined += (int64_t)act[4 + LSQ_WALK_TRACE];
+    c->filter_exact += (int64_t)act[4 + LSQ_WALK_TRACE + 1];
+    c->filter_f32 += (int64_t)act[4 + LSQ_WALK_TRACE + 2];
+    for (int q = 0; q < LSQ_WALK_TRACE; ++q) c->trace[q] += (int64_t)act[4 + q];
 }
 
 static int finish_call(lsq_ctx *c, int64_t I, int nr, double *obj_sums, int64_t *stats) {
@@ -518,16 +563,7 @@ static int finish_call(lsq_ctx *c, int64_t I, int nr, double *obj_sums, int64_t 
     unsigned long long act[LSQ_WALK_COUNTERS] = {0};
     LSQ_HIP(hipMemcpyAsync(act, c->active.p, sizeof(act), hipMemcpyDeviceToHost, c->stream));
     LSQ_HIP(hipStreamSynchronize(c->stream));
-    if (c->schedule >= 3) {
-        c->icm_node_updates += (int64_t)act[0];
-        c->staged_blocks += (int64_t)act[1];
-        c->light_blocks += (int64_t)act[2];
-        c->filtered_blocks += (int64_t)act[3];
-        c->filter_refined += (int64_t)act[4 + LSQ_WALK_TRACE];
-        c->filter_exact += (int64_t)act[4 + LSQ_WALK_TRACE + 1];
-        c->filter_f32 += (int64_t)act[4 + LSQ_WALK_TRACE + 2];
-        for (int q = 0; q < LSQ_WALK_TRACE; ++q) c->trace[q] += (int64_t)act[4 + q];
-    }
+    fold_walk_counters(c, act);
     if (stats) for (int64_t q = 0; q < 2 * I; ++q) stats[q] = (int64_t)cnt[(size_t)q];
     return LSQ_OK;
 }

@@ -26,15 +26,15 @@ def pytest_collection_modifyitems(config, items):
 
 
 # How the encode is run in the parity tests.  The FIRST entries are the shipped library: its plain defaults (what a caller gets),
-# schedule 6 forced onto every chunk with every block staged (the 16-bit filtered walk is then the kernel that produces every code,
-# whatever n), the f32 walk in both launch shapes.  Schedules 0..2 exist in the tuning build only and are marked `tuning`.
+# schedule 6 forced onto every chunk with every block staged and both hand-overs to the f32 walk switched off (the 16-bit filtered walk
+# is then the kernel that produces every code, whatever n and whatever the data), the f32 walk in both launch shapes.  Schedules 0..2 exist in the tuning build only and are marked `tuning`.
 def _variant(name, marks=(), **options):
     return pytest.param(options, id=name, marks=list(marks))
 
 
 ENCODE_VARIANTS = [
     _variant("default"),
-    _variant("s6_forced", schedule=6, q16_min=0, light=0),
+    _variant("s6_forced", schedule=6, q16_min=0, light=0, filter_probe_div=0, filter_fallback_div=0),
     _variant("s6_light", schedule=6, q16_min=0),
     _variant("s4", schedule=4),
     _variant("s3", schedule=3),

@@ -57,7 +57,9 @@ def test_random_shape_matches_oracle(lsq, oracle, case):
     assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0)
     staged, light = tm["staged_blocks"] + tm["filtered_blocks"], tm["light_blocks"]
     if J > 0 and mode != "default":
-        assert (tm["staged_blocks"] > 0) == (t % 4 == 3) and (tm["filtered_blocks"] > 0) == (t % 4 != 3), tm
+        # schedule 4 stages f32 slices; schedule 6 runs the filtered walk -- and hands a chunk over to the f32 walk when its first ILS iteration
+        # came out mostly ambiguous (tiny d: the probe of option filter_probe_div), which then shows up in filter_fallback_chunks
+        assert (tm["staged_blocks"] > 0) == (t % 4 == 3 or tm["filter_fallback_chunks"] > 0) and (tm["filtered_blocks"] > 0) == (t % 4 != 3), tm
     if J == 0:
         assert staged == 0 and light == 0                  # no sweeps: perturbation + accept only
     elif mode == "forced":

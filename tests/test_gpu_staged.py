@@ -41,6 +41,7 @@ def test_forced_staging_every_m(lsq, oracle, m):
                     eng.set_option("light", 0)
                     eng.set_option("fallback", fb)
                     eng.set_option("q16_min", 0)             # schedule 6: the 16-bit filtered walk even at this size
+                    eng.set_option("filter_probe_div", 0)    # ... for every ILS iteration, whatever the first one's ambiguity
                     Bs, objs = eng.encode_icm(X, B0, K, m, ils, J, npert, True, seed=seed)
                     staged, light, filt = _paths(eng)
                 tag = "m=%d schedule=%d skip=%d fallback=%d" % (m, schedule, skip, fb)
@@ -229,6 +230,7 @@ def _filter_case(lsq, oracle, X, K, B0, m, ils, J, npert, seed, expect_filter=Tr
     with lsq.Engine(0, schedule=6) as eng:
         eng.set_option("q16_min", 0)
         eng.set_option("light", 0)
+        eng.set_option("filter_probe_div", 0)          # the first-iteration probe is tested on its own
         for k, v in options.items():
             eng.set_option(k, v)
         Bs, objs = eng.encode_icm(X, B0, K, m, ils, J, npert, True, seed=seed)
@@ -286,6 +288,7 @@ def test_filter_light_blocks(lsq, oracle):
         for fb in (1, 0):
             with lsq.Engine(0, schedule=6, skip=skip, profile=True) as eng:
                 eng.set_option("q16_min", 0)
+                eng.set_option("filter_probe_div", 0)
                 eng.set_option("fallback", fb)
                 eng.set_option("wave_max", 0)
                 eng.set_option("filter_fallback_div", 0)
@@ -348,7 +351,7 @@ def test_filter_outliers_beyond_the_sampled_range(lsq, oracle):
         t = _filter_case(lsq, oracle, Xa, K, B0, m, [2], 2, 4, seed)
         ta["filter_f32"] += t["filter_f32"]
     Xb = (X * rng.standard_cauchy((n, 1)).astype(np.float32)).astype(np.float32)
-    tb = _filter_case(lsq, oracle, Xb, K, B0, m, [2], 2, 4, seed, filter_fallback_div=0)      # never hand the chunk over: every flagged vector takes the exact-256 routine
+    tb = _filter_case(lsq, oracle, Xb, K, B0, m, [2], 2, 4, seed, filter_fallback_div=0, filter_probe_div=0)      # never hand the chunk over
     Xc = X.copy()
     Xc[n // 2:] *= np.float32(1.7)
     tc = _filter_case(lsq, oracle, Xc, K, B0, m, [1], 2, 4, seed)
@@ -359,8 +362,35 @@ def test_filter_outliers_beyond_the_sampled_range(lsq, oracle):
     hot = np.array([i for i in range(n) if (i // 128) % 2 == 1 and i % 3 == 0])            # never in the sample (odd panels)
     Xd[hot] *= np.float32(40.0)
     td = _filter_case(lsq, oracle, Xd, K, B0, m, [1], 2, 4, seed, expect_filter=False)
-    te = _filter_case(lsq, oracle, Xd, K, B0, m, [1], 2, 4, seed, filter_fallback_div=0)
+    te = _filter_case(lsq, oracle, Xd, K, B0, m, [1], 2, 4, seed, filter_fallback_div=0, filter_probe_div=0)
     assert te["filter_f32"] > 1000, te
+
+
+def test_filter_probe_hands_scale_mixture_chunks_to_the_f32_walk(lsq, oracle):
+    """Cauchy-scaled vectors: the sampled level range is blown up by a few extreme vectors, the level step is too coarse for the bulk and most node
+    updates come out ambiguous.  The first ILS iteration runs filtered, its counters are read back, and the remaining iterations run as the f32 walk
+    (option filter_probe_div, default 8): both kernels serve the same call.  Codes == the oracle on all vectors either way; with the probe off the
+    whole call stays on the filtered walk."""
+    d, n, m, seed = 16, 40_000, 8, 79
+    rng = np.random.default_rng(seed)
+    X, K, B0 = make_problem(d, n, m, seed=seed, kind="gauss")
+    X = (X * rng.standard_cauchy((n, 1)).astype(np.float32)).astype(np.float32)
+    Bs_ref, objs_ref = oracle.encode_icm(X, B0, K, m, H, [1, 3], 3, 4, True, seed)
+    seen = {}
+    for probe in (8, 0):
+        with lsq.Engine(0, schedule=6, profile=True) as eng:
+            eng.set_option("q16_min", 0)
+            eng.set_option("light", 0)
+            eng.set_option("filter_fallback_div", 0)
+            eng.set_option("filter_probe_div", probe)
+            Bs, objs = eng.encode_icm(X, B0, K, m, [1, 3], 3, 4, True, seed=seed)
+            t = eng.timings()
+        assert np.array_equal(Bs, Bs_ref), "probe=%d: %d codes differ (%r)" % (probe, (Bs != Bs_ref).sum(), t)
+        assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0)
+        seen[probe] = t
+    assert seen[8]["filter_fallback_chunks"] == 1 and seen[8]["filtered_blocks"] > 0 and seen[8]["staged_blocks"] > 0, seen[8]
+    assert seen[0]["filter_fallback_chunks"] == 0 and seen[0]["staged_blocks"] == 0, seen[0]
+    assert seen[8]["icm_node_updates"] == seen[0]["icm_node_updates"]          # same memoisation on both roads
 
 
 def test_filter_degenerate_ranges(lsq, oracle):
