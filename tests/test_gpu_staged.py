@@ -391,6 +391,19 @@ def test_filter_probe_hands_scale_mixture_chunks_to_the_f32_walk(lsq, oracle):
     assert seen[8]["filter_fallback_chunks"] == 1 and seen[8]["filtered_blocks"] > 0 and seen[8]["staged_blocks"] > 0, seen[8]
     assert seen[0]["filter_fallback_chunks"] == 0 and seen[0]["staged_blocks"] == 0, seen[0]
     assert seen[8]["icm_node_updates"] == seen[0]["icm_node_updates"]          # same memoisation on both roads
+    # several resident chunks, only the SECOND half of the data heavy-tailed: each chunk decides for itself (the well-conditioned chunks stay filtered)
+    Xm = X.copy()
+    Xg, _, _ = make_problem(d, n, m, seed=seed, kind="gauss")
+    Xm[: n // 2] = Xg[: n // 2]
+    ref, _ = oracle.encode_icm(Xm, B0, K, m, H, [3], 3, 4, True, seed)
+    with lsq.Engine(0, schedule=6, profile=True, chunk=n // 4) as eng:
+        eng.set_option("q16_min", 0)
+        eng.set_option("light", 0)
+        eng.set_option("filter_fallback_div", 0)
+        Bs, _ = eng.encode_icm(Xm, B0, K, m, [3], 3, 4, True, seed=seed)
+        t = eng.timings()
+    assert np.array_equal(Bs, ref), "%d codes differ (%r)" % ((Bs != ref).sum(), t)
+    assert t["filter_fallback_chunks"] == 2, t
 
 
 def test_filter_degenerate_ranges(lsq, oracle):
