@@ -123,7 +123,9 @@ LSQ_API int lsq_set_stream(lsq_ctx *ctx, void *hip_stream);
  *        0 = never.  Same codes.
  *   "filter_probe_div" (default 8): after the FIRST ILS iteration of a resident chunk schedule 6 reads that iteration's counters and runs the
  *        remaining iterations as schedule 4 when more than 1 / div of the recomputed node updates needed the exact refinement or the f32 routine
- *        (a level step blown up by a few extreme values: scale-mixture / heavy-tailed data); 0 = never.  Same codes.
+ *        (a level step blown up by a few extreme values: scale-mixture / heavy-tailed data); 0 = never.  Same codes.  A call of ONE ILS iteration
+ *        (lsq_encoding_icm chained by a trainer) is its own probe: the next single-iteration call of the same shape on this context starts on the
+ *        f32 walk when this one came out badly (re-probed every 16th call).
  *   "ils_counter": the next iteration index used by lsq_encoding_icm / lsq_encode_icm_fully when called with it = LSQ_IT_AUTO
  *        (starts at 0, advances by one per such call).
  *   (liblsq_mi355x_tuning.so only) "ablation": timing-only kernel variants whose results are garbage. */

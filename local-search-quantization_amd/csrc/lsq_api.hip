@@ -81,6 +81,10 @@ struct lsq_ctx {
     bool chunk_q16 = false;                            // the resident chunk runs the filtered walk (set by build_unaries from the chunk's verdict)
     int64_t fallback_div = 64;                         // option "filter_fallback_div": the chunk goes to the f32 walk when flagged pairs * div > all pairs (0 = never)
     int64_t filter_fallback_chunks = 0;                // chunks the filter handed to the f32 walk (unusable bounds or too many out-of-range vectors)
+    // single-iteration calls (the trainer's chained encoding_icm) cannot probe and switch within the call: the verdict of the previous such call on
+    // the same shape is remembered instead (re-probed every 16th call)
+    int64_t call_I = 0, call_q16_chunks = 0;
+    int64_t sticky_n = -1; int sticky_d = 0, sticky_m = 0, sticky_bad = 0, sticky_count = 0;
     DevBuf sX, sX2, sK, sB16, sOut16, sTight, sF32;    // staging for the host-buffer entry points (sX/sX2: double-buffered X chunks)
     hipStream_t copy_stream = nullptr;               // H2D of X runs here, under the compute of the previous panel / chunk
     hipEvent_t copy_done = nullptr;
@@ -335,7 +339,11 @@ static bool use_q16(const lsq_ctx *c, int64_t cn) { return c->schedule == 6 && c
 
 static int build_unaries(lsq_ctx *c, const float *dX, const float *dK, int d, int64_t cn, int m, int slice, int64_t r0, int64_t rows) {
     c->chunk_q16 = false;
-    const bool q16 = slice > 0 && r0 == 0 && rows == cn && use_q16(c, cn);
+    bool q16 = slice > 0 && r0 == 0 && rows == cn && use_q16(c, cn);
+    if (q16 && c->call_I == 1 && c->sticky_bad && c->sticky_n == cn && c->sticky_d == d && c->sticky_m == m && c->probe_div > 0) {
+        if (++c->sticky_count % 16 != 0) { q16 = false; c->filter_fallback_chunks += 1; }      // the last probe of this shape said: f32 walk
+    }
+    if (q16) c->call_q16_chunks += 1;
     if (q16) {
         // 16-bit filtered walk: sampled value ranges of this chunk -> parameters -> 16-bit slice tables; the GEMM below then also emits the u16 planes
         Timer t(c, CAT_TABLES);
@@ -458,7 +466,9 @@ template <class Snap>
 static int encode_chunk(lsq_ctx *c, const float *dXc, const float *dK, int64_t cn, uint64_t goff, const EncodeParams &P, int64_t I, Snap snap,
                         bool unaries_ready = false) {
     const int cs = lsq_code_stride(P.m);
+    c->call_I = I;
     if (!unaries_ready) LSQ_TRY(build_unaries(c, dXc, dK, P.d, cn, P.m, u_slice_width(c, P.m), 0, cn));
+    if (I == 1) { c->sticky_n = cn; c->sticky_d = P.d; c->sticky_m = P.m; }
     LSQ_TRY(c->recNew.ensure((size_t)cn * cs));
     LSQ_TRY(c->prev.ensure(sizeof(float) * (size_t)cn));
     LSQ_TRY(c->vCur.ensure(sizeof(unsigned short) * (size_t)cn));
@@ -538,6 +548,7 @@ static int begin_call(lsq_ctx *c, int64_t I, int nr) {
     LSQ_TRY(c->active.ensure(sizeof(unsigned long long) * LSQ_WALK_COUNTERS));
     LSQ_HIP(hipMemsetAsync(c->active.p, 0, sizeof(unsigned long long) * LSQ_WALK_COUNTERS, c->stream));
     c->walk_counters = c->active.as<unsigned long long>();
+    c->call_q16_chunks = 0;
     LSQ_HIP(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long) * 2 * (size_t)std::max<int64_t>(I, 1), c->stream));
     LSQ_HIP(hipMemsetAsync(c->obj.p, 0, sizeof(double) * (size_t)std::max(nr, 1), c->stream));
     LSQ_HIP(hipMemsetAsync(c->bad.p, 0, sizeof(int), c->stream));
@@ -564,6 +575,10 @@ static int finish_call(lsq_ctx *c, int64_t I, int nr, double *obj_sums, int64_t 
     LSQ_HIP(hipMemcpyAsync(act, c->active.p, sizeof(act), hipMemcpyDeviceToHost, c->stream));
     LSQ_HIP(hipStreamSynchronize(c->stream));
     fold_walk_counters(c, act);
+    if (I == 1 && c->call_q16_chunks > 0 && c->probe_div > 0) {      // the whole call was its own probe: remember the answer for the next call of this shape
+        const unsigned long long hard = act[4 + LSQ_WALK_TRACE] + act[4 + LSQ_WALK_TRACE + 2];
+        c->sticky_bad = ((long double)hard * (long double)c->probe_div > (long double)act[0]) ? 1 : 0;
+    }
     if (stats) for (int64_t q = 0; q < 2 * I; ++q) stats[q] = (int64_t)cnt[(size_t)q];
     return LSQ_OK;
 }
@@ -809,6 +824,8 @@ extern "C" int lsq_encode_icm_fully(lsq_ctx *c, int16_t *B, const float *X, cons
     LSQ_TRY(upload_xk(c, X, K, d, n, m));
     LSQ_TRY(upload_codes(c, B, n, m, h, c->recCur));
     LSQ_TRY(prepare_tables(c, c->sK.as<float>(), d, m));
+    c->call_I = 0;                                     // the worker has no accept step and no probe memory: always the configured road
+    c->walk_counters = nullptr;
     LSQ_TRY(build_unaries(c, c->sX.as<float>(), c->sK.as<float>(), d, n, m, u_slice_width(c, m), 0, n));
     LSQ_TRY(c->recNew.ensure((size_t)n * lsq_code_stride(m)));
     int32_t order[LSQ_MAX_M];

@@ -102,3 +102,19 @@ def test_bad_arguments_rejected_on_host(lsq):
     s, ln = C.c_int64(), C.c_int64()
     assert L.lsq_splitarray(10, 0, 0, C.byref(s), C.byref(ln)) == lsq._lib.LSQ_EINVAL
     assert b"splitarray" in L.lsq_last_error()
+
+
+def test_bench_matches_pmc_profiles_by_workload():
+    """bench.py reports `roofline.traffic` only from a committed PMC profile of the SAME build and the SAME workload flags: the key ignores
+    measurement flags (steps, warmup, legs) and keeps every shape-defining one."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    k = b.workload_key
+    assert k([]) == k("--steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs --no-sample-parity".split()) == ""
+    assert k("--codebooks 16 --steps 1".split()) == "--codebooks=16" != k([])
+    assert k("--scaling strong --total 125000 --dim 960".split()) == k("--dim 960 --total=125000 --scaling strong --warmup 0".split())
+    assert k("--vectors 12500000".split()) != k("--vectors 1000000".split())

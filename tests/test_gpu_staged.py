@@ -406,6 +406,29 @@ def test_filter_probe_hands_scale_mixture_chunks_to_the_f32_walk(lsq, oracle):
     assert t["filter_fallback_chunks"] == 2, t
 
 
+def test_single_iteration_calls_remember_the_probe(lsq, oracle):
+    """The trainer's pattern -- chained encoding_icm calls, ONE ILS iteration each -- cannot probe and switch inside a call: the call's own counters are
+    the probe and the NEXT call of the same shape starts on the f32 walk (re-probed every 16th call).  Scale-mixture data, 4 chained calls ==
+    the oracle's chained calls; calls 2..4 must have taken the f32 road; a well-conditioned data set never leaves the filtered walk."""
+    d, n, m, seed = 16, 40_000, 8, 80
+    rng = np.random.default_rng(seed)
+    Xg, K, B0 = make_problem(d, n, m, seed=seed, kind="gauss")
+    Xc = (Xg * rng.standard_cauchy((n, 1)).astype(np.float32)).astype(np.float32)
+    for X, expect_fallbacks in ((Xc, 3), (Xg, 0)):
+        with lsq.Engine(0, schedule=6, profile=True) as eng:
+            eng.set_option("q16_min", 0)
+            eng.set_option("light", 0)
+            eng.set_option("filter_fallback_div", 0)
+            Bg, Bo = B0.copy(), B0.copy()
+            for it in range(4):
+                Bg = eng.encoding_icm(X, Bg, K, m, 3, True, 4, seed=seed)                   # the context counts the iterations
+                Bo = oracle.encoding_icm_faithful(X, Bo, K, m, H, 3, True, 4, seed, it, nworkers=oracle.num_threads())
+                assert np.array_equal(Bg, Bo), "call %d: %d codes differ" % (it, (Bg != Bo).sum())
+            t = eng.timings()
+        assert t["filter_fallback_chunks"] == expect_fallbacks, t
+        assert t["filtered_blocks"] > 0 and (t["staged_blocks"] > 0) == (expect_fallbacks > 0), t
+
+
 def test_filter_degenerate_ranges(lsq, oracle):
     """All-zero codebooks (every conditioned sum is 0: step 0 -> unusable bounds -> the f32 walk; index 0 wins every argmin), constant
     data, and a single distinct codeword per codebook."""
