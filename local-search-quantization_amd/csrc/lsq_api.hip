@@ -77,7 +77,7 @@ struct lsq_ctx {
     unsigned long long *walk_counters = nullptr;       // where the walk launches accumulate their statistics (c->active, or c->probe during that first iteration)
     int64_t probe_div = 8;                             // option "filter_probe_div": after the first iteration the chunk goes to the f32 walk when
                                                        // (refined + f32-routed) * div > recomputed node updates (0 = never)
-    DevBuf Uq, Tq, qp, qscratch, qflag;                // 16-bit filtered walk: u16 unary planes, u16 slice tables, lsq_q16_params, bound scratch, per-vector out-of-range flags
+    DevBuf Uq, Tq, qp, qscratch, qflag, qsigma;                // 16-bit filtered walk: u16 unary planes, u16 slice tables, lsq_q16_params, bound scratch, per-vector out-of-range flags
     bool chunk_q16 = false;                            // the resident chunk runs the filtered walk (set by build_unaries from the chunk's verdict)
     int64_t fallback_div = 64;                         // option "filter_fallback_div": the chunk goes to the f32 walk when flagged pairs * div > all pairs (0 = never)
     int64_t filter_fallback_chunks = 0;                // chunks the filter handed to the f32 walk (unusable bounds or too many out-of-range vectors)
@@ -166,7 +166,7 @@ extern "C" int lsq_destroy(lsq_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : c->pool) (void)hipEventDestroy(e);
-    DevBuf *bufs[] = {&c->probe, &c->Uq, &c->Tq, &c->qp, &c->qscratch, &c->qflag, &c->sci, &c->T, &c->Ts, &c->U, &c->part, &c->vCur, &c->vNew, &c->active, &c->recCur, &c->recNew, &c->prev, &c->counters, &c->obj, &c->bad,
+    DevBuf *bufs[] = {&c->probe, &c->Uq, &c->Tq, &c->qp, &c->qscratch, &c->qflag, &c->qsigma, &c->sci, &c->T, &c->Ts, &c->U, &c->part, &c->vCur, &c->vNew, &c->active, &c->recCur, &c->recNew, &c->prev, &c->counters, &c->obj, &c->bad,
                       &c->sX, &c->sX2, &c->sK, &c->sB16, &c->sOut16, &c->sTight, &c->sF32};
     for (DevBuf *b : bufs) b->release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -349,14 +349,19 @@ static int build_unaries(lsq_ctx *c, const float *dX, const float *dK, int d, in
         Timer t(c, CAT_TABLES);
         LSQ_TRY(c->Uq.ensure(sizeof(uint16_t) * (size_t)m * (size_t)cn * LSQ_H));
         LSQ_TRY(c->Tq.ensure(sizeof(uint16_t) * (size_t)m * (size_t)(m > 1 ? m - 1 : 1) * LSQ_H * LSQ_H));
-        LSQ_TRY(c->qscratch.ensure(256 + sizeof(float) * 2 * (size_t)m * m));
+        // scratch: [16] bad, [64..200) range keys, [256..) table ranges (2 m m floats), row minima (m m h floats), codebook means (m d floats)
+        const size_t off_rowmin = (256 + sizeof(float) * 2 * (size_t)m * m + 255) & ~(size_t)255;
+        const size_t off_means = off_rowmin + sizeof(float) * (size_t)m * m * LSQ_H;
+        LSQ_TRY(c->qscratch.ensure(off_means + sizeof(float) * (size_t)m * d));
+        LSQ_TRY(c->qsigma.ensure(sizeof(float) * (size_t)cn * m));      // per-(vector, node) unary shift: levels only (lsq_icmq.hip)
         LSQ_TRY(c->qflag.ensure(sizeof(unsigned short) * (size_t)(cn + 2)));
         LSQ_TRY(c->qp.ensure(sizeof(lsq_q16_params)));
         if (c->tables_changed) LSQ_HIP(hipMemsetAsync(c->qp.p, 0, sizeof(lsq_q16_params), c->stream));      // first chunk of a call: ok = 0, oor = 0
         char *sc = c->qscratch.as<char>();
         LSQ_TRY(lsq_launch_q16_prepare(c->stream, dX, cn, d, dK, c->sci.as<float>(), c->T.as<float>(), m, c->Tq.as<uint16_t>(),
                                        reinterpret_cast<int *>(sc + 16), reinterpret_cast<float *>(sc + 256), reinterpret_cast<unsigned *>(sc + 64),
-                                       c->qflag.as<unsigned short>(), c->qp.as<lsq_q16_params>(), c->tables_changed));
+                                       c->qflag.as<unsigned short>(), c->qp.as<lsq_q16_params>(), c->tables_changed,
+                                       reinterpret_cast<float *>(sc + off_rowmin), reinterpret_cast<float *>(sc + off_means), c->qsigma.as<float>()));
         c->tables_changed = 0;
     }
     {
@@ -367,7 +372,7 @@ static int build_unaries(lsq_ctx *c, const float *dX, const float *dK, int d, in
         uint16_t *dq = q16 ? c->Uq.as<uint16_t>() : nullptr;
         LSQ_TRY(lsq_launch_chain_gemm(c->stream, dX + r0 * d, dK, c->sci.as<float>(), -2.0f, rows, m * LSQ_H, d, LSQ_H, cn * (int64_t)LSQ_H, LSQ_H,
                                       c->U.as<float>(), slice, cn, r0, dq, dq ? lsq_q16_slice_width(m) : 0, dq ? c->qp.as<lsq_q16_params>() : nullptr, 0,
-                                      dq ? c->qflag.as<unsigned short>() : nullptr, nullptr));
+                                      dq ? c->qflag.as<unsigned short>() : nullptr, nullptr, 1, dq ? c->qsigma.as<float>() : nullptr));
     }
     if (q16) {
         // The chunk's verdict (three words, ONE host round trip per resident chunk -- 10^6 vectors, ~50 ms of work): usable bounds, and few enough

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                          float *__restrict__ D, int64_t row_tiles, int col_tiles, int slice,
                                                          int64_t Mtot, int64_t rbase, uint16_t *__restrict__ Dq, int slice_q,
                                                          lsq_q16_params *__restrict__ qp, int64_t lda, unsigned short *__restrict__ qflag,
-                                                         unsigned *__restrict__ qrange, int rts) {
+                                                         unsigned *__restrict__ qrange, int rts, const float *__restrict__ sigma) {
     constexpr int LD = BK + LSQ_GEMM_PAD;
     __shared__ float smem[2 * BM * LD + 2 * BN * LD];      // A and B panels, double-buffered; reused by the u16 epilogue as a 128 x 128 level tile
     float (*As)[BM * LD] = reinterpret_cast<float (*)[BM * LD]>(smem);
@@ -116,6 +116,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wy = wave >> 1, wx = wave & 1;
     const int l31 = lane & 31, lhi = lane >> 5;
+
+    // per-(row, plane) shift of the value a LEVEL is taken of (argmin-neutral: lsq_icmq.hip); the f32 output stays unshifted.  The block's 128 shifts
+    // (one column plane per block) wait in LDS: a global load in the epilogue would queue behind the epilogue's own stores (one vmcnt for both).
+    // Q16 = 1 keeps them as lo_row = loU - sigma (one rounding, inside the bound's f32 term): the level is rint((v - lo_row) * invD), no extra add.
+    __shared__ __attribute__((aligned(16))) float sgs[BM];
+    if (Q16 != 0 && tid < BM) {
+        const int64_t row = row0 + tid;
+        const float sg = (sigma != nullptr && row < M) ? sigma[(rbase + row) * (N / h) + col0 / h] : 0.0f;
+        sgs[tid] = (Q16 == 1) ? ((qp->ok != 0 ? qp->node[col0 / h].loU : 0.0f) - sg) : sg;
+    }
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -174,12 +184,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const int64_t coff = slice ? (int64_t)(c / h) * plane_stride + (int64_t)(a / slice) * (Mtot * slice) + (a % slice)
                                    : (int64_t)(c / h) * plane_stride + a;
         const int64_t rstride = slice ? (int64_t)slice : row_stride;
-        float qlo = 0.f, qinv = 0.f, qhi = 0.f;
+        float qinv = 0.f, qhi = 0.f;
         int noor = 0;
         const bool q16 = Q16 == 1 && qp->ok != 0;          // unusable bounds (non-finite data): the f32 walk handles the chunk, nothing to emit
         int npair = 0;                                       // (row, plane) pairs this lane flagged FIRST
         if (q16) {
-            qlo = qp->node[c / h].loU;
             qinv = qp->node[c / h].invD;
             qhi = qp->node[c / h].hiq;
         }
@@ -191,6 +200,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const int64_t lrow = row0 + wy * 64 + 4 * lhi;                      // the lane's first row; element (ti, r) sits (ti*32 + (r&3) + 8*(r>>2)) rows further
         float *__restrict__ Dl = (Q16 == 2) ? nullptr : D + coff + (rbase + lrow) * rstride;
         uint16_t *__restrict__ ql = qtile + (wy * 64 + 4 * lhi) * QLD + wx * 64 + tj * 32 + l31;
+        const float *__restrict__ sgl = sgs + wy * 64 + 4 * lhi;
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
 #pragma unroll
@@ -199,10 +209,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 if (full || lrow + ro < M) {
                     float v = acc[ti][tj][r];
                     if (addv) v = v + add;           // one rounded add (utils.jl:112-118)
-                    if (Q16 == 2) { vmin = fminf(vmin, v); vmax = fmaxf(vmax, v); continue; }
+                    if (Q16 == 2) {
+                        const float w = v + sgl[ro];
+                        vmin = fminf(vmin, w); vmax = fmaxf(vmax, w);
+                        continue;
+                    }
                     Dl[(int64_t)ro * rstride] = v;
                     if (q16) {
-                        const float qf = rintf((v - qlo) * qinv);
+                        const float qf = rintf((v - sgl[ro]) * qinv);
                         const float qc = __builtin_amdgcn_fmed3f(qf, 0.0f, qhi);       // clamp to the level range (NaN -> 0)
                         if (!(qf == qc)) {                                               // outside [0, hiq] or NaN: flag the (vector, node) pair
                             const int64_t row = lrow + ro;
@@ -270,7 +284,7 @@ __global__ __launch_bounds__(256) void sqnorms_kernel(const float *__restrict__ 
 
 int lsq_launch_chain_gemm(hipStream_t s, const float *A, const float *Bm, const float *addv, float alpha, int64_t M,
                           int N, int Kd, int h, int64_t plane_stride, int64_t row_stride, float *D, int slice, int64_t Mtot, int64_t rbase,
-                          uint16_t *Dq, int slice_q, lsq_q16_params *qp, int64_t lda, unsigned short *qflag, unsigned *qrange, int rts) {
+                          uint16_t *Dq, int slice_q, lsq_q16_params *qp, int64_t lda, unsigned short *qflag, unsigned *qrange, int rts, const float *sigma) {
     if (lda <= 0) lda = Kd;
     if (rts < 1) rts = 1;
     if (M <= 0 || N <= 0) return LSQ_OK;
@@ -284,10 +298,10 @@ int lsq_launch_chain_gemm(hipStream_t s, const float *A, const float *Bm, const 
     if (qrange) {          // range-only pass
         if (vec4 && lda % 4 == 0)
             hipLaunchKernelGGL((chain_gemm_kernel<true, 16, 2>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                               plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, qrange, rts);
+                               plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, qrange, rts, sigma);
         else
             hipLaunchKernelGGL((chain_gemm_kernel<false, 16, 2>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                               plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, qrange, rts);
+                               plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, qrange, rts, sigma);
         LSQ_HIP(hipGetLastError());
         return LSQ_OK;
     }
@@ -295,22 +309,22 @@ int lsq_launch_chain_gemm(hipStream_t s, const float *A, const float *Bm, const 
         if (!qp || !qflag || slice_q < 1) { lsq_set_error("chain_gemm: quantised output needs parameters"); return LSQ_EINVAL; }
         if (vec4)
             hipLaunchKernelGGL((chain_gemm_kernel<true, 16, 1>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                               plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, Dq, slice_q, qp, lda, qflag, nullptr, 1);
+                               plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, Dq, slice_q, qp, lda, qflag, nullptr, 1, sigma);
         else
             hipLaunchKernelGGL((chain_gemm_kernel<false, 16, 1>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                               plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, Dq, slice_q, qp, lda, qflag, nullptr, 1);
+                               plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, Dq, slice_q, qp, lda, qflag, nullptr, 1, sigma);
         LSQ_HIP(hipGetLastError());
         return LSQ_OK;
     }
     if (vec4 && bk == 8)
         hipLaunchKernelGGL((chain_gemm_kernel<true, 8>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, nullptr, 1);
+                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, nullptr, 1, nullptr);
     else if (vec4)
         hipLaunchKernelGGL((chain_gemm_kernel<true, 16>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, nullptr, 1);
+                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, nullptr, 1, nullptr);
     else
         hipLaunchKernelGGL((chain_gemm_kernel<false, 16>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, nullptr, 1);
+                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, nullptr, 1, nullptr);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }

@@ -10,8 +10,12 @@
 //            (Uq, slice-major u16), the pair tables by tables_to_q16_slices_kernel (Tq).  The levels of a candidate are summed as
 //            packed pairs, Q[a] = qU[a] + SUM_k qT_k[a] < 65536 by construction (lsq_q16_node::hiq), so plain 32-bit three-operand
 //            adds are exact: 512 B of unaries and (m-1) x 512 B of table rows per vector and node.  A wave tracks the two smallest keys.
-//   BOUND    |lo_sum + D Q[a] - s_f32[a]| <= slack := m (0.5 + 2^-5) D + eps_f32  for every candidate (rounding of each level,
-//            rounding of the f32 chain).  Hence the exact argmin a* obeys  Q[a*] <= Qmin + window,  window = floor(2 slack / D) + 1.
+//   SHIFTS   a term that is the same for all 256 candidates of a node update cannot change its argmin, so it needs no level range: the levels
+//            are taken of U_j[a] + sigma_ij (sigma_ij = 2 <x_i, mean codeword of codebook j>: unary_shift_kernel) and of T_jk[b][a] - min_a
+//            T_jk[b][:] (table_range_kernel).  The ranges the common step must cover shrink by a third on SIFT-like data (D 11.3 -> 7.4 at
+//            m = 8), and the ambiguous node updates with them (1.7 % -> 1.2 %; m = 16: 3.2 % -> 2.1 %).
+//   BOUND    |C_i + D Q[a] - s_f32[a]| <= slack := m (0.5 + 2^-5) D + eps_f32  for every candidate, C_i the same for all of them (rounding of
+//            each level, of the shifts, of the f32 chain).  Hence the exact argmin a* obeys  Q[a*] <= Qmin + window,  window = floor(2 slack / D) + 1.
 //   REFINE   second - best > window: the best key IS the exact argmin (>= 98 % of the node updates).  Otherwise (q16_refine) every
 //            candidate whose level sum lies within the window of the best -- the SURVIVORS: they provably contain the exact argmin
 //            and all its exact ties -- is evaluated EXACTLY (the f32 unaries the GEMM also wrote, the f32 tables, canonical order)
@@ -63,29 +67,93 @@ __device__ inline uint32_t dpp_u32(uint32_t v) {
 }
 
 // ---- parameters -----------------------------------------------------------------------------------------------------------------
-// exact min / max of every off-diagonal pair table T[j][k] (65536 floats): range[(j*m + k)*2 + {0,1}]
-__global__ __launch_bounds__(256) void table_range_kernel(const float *__restrict__ T, int m, float *__restrict__ range, int *__restrict__ bad) {
+// Shifts that are the same for every candidate of a node update cannot change its argmin, so they need no level range.  A table row T[j][k][b][:]
+// enters a conditioned sum as a whole (the row of the code b that codebook k holds): its minimum is such a shift.  Per off-diagonal pair table (65536
+// floats): rowmin[(j*m + k)*256 + b] = min_a T[j][k][b][a];  range[(j*m + k)*2] = max_b (max_a - min_a) -- the range the CENTRED rows need, 13 %
+// less than the table's own range on SIFT-like data --;  range[(j*m + k)*2 + 1] = max |T| (for the f32 rounding term of the bound).
+__global__ __launch_bounds__(256) void table_range_kernel(const float *__restrict__ T, int m, float *__restrict__ range, float *__restrict__ rowmin,
+                                                          int *__restrict__ bad) {
     const int jk = blockIdx.x, j = jk / m, k = jk % m;
     if (j == k) return;
     const float *p = T + (int64_t)jk * LSQ_H * LSQ_H;
-    float lo = __builtin_inff(), hi = -__builtin_inff();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float rng = 0.0f, mag = 0.0f;
     bool nonfinite = false;
-    for (int e = threadIdx.x; e < LSQ_H * LSQ_H; e += 256) {
-        const float v = p[e];
-        nonfinite = nonfinite || !(fabsf(v) <= 3.0e38f);
-        lo = fminf(lo, v);
-        hi = fmaxf(hi, v);
-    }
-    __shared__ float slo[4], shi[4];
+    for (int b = wave; b < LSQ_H; b += 4) {                       // one wave per row: 64 lanes x 16 B = the row's 1 KiB in one load
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(p + (int64_t)b * LSQ_H + 4 * lane);
+        nonfinite = nonfinite || !(fabsf(v.x) <= 3.0e38f) || !(fabsf(v.y) <= 3.0e38f) || !(fabsf(v.z) <= 3.0e38f) || !(fabsf(v.w) <= 3.0e38f);
+        float lo = fminf(fminf(v.x, v.y), fminf(v.z, v.w)), hi = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off, 64)); hi = fmaxf(hi, __shfl_xor(hi, off, 64)); }
-    if (__ballot(nonfinite) != 0ull && (threadIdx.x & 63) == 0) atomicExch(bad, 1);
-    if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+        for (int off = 32; off > 0; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off, 64)); hi = fmaxf(hi, __shfl_xor(hi, off, 64)); }
+        if (lane == 0) rowmin[(int64_t)jk * LSQ_H + b] = lo;
+        rng = fmaxf(rng, hi - lo);                                // rounded up below (the params kernel works in double and adds its own margin)
+        mag = fmaxf(mag, fmaxf(fabsf(lo), fabsf(hi)));
+    }
+    __shared__ float srng[4], smag[4];
+    if (__ballot(nonfinite) != 0ull && lane == 0) atomicExch(bad, 1);
+    if (lane == 0) { srng[wave] = rng; smag[wave] = mag; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        range[jk * 2 + 0] = fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3]));
-        range[jk * 2 + 1] = fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3]));
+        range[jk * 2 + 0] = fmaxf(fmaxf(srng[0], srng[1]), fmaxf(srng[2], srng[3]));
+        range[jk * 2 + 1] = fmaxf(fmaxf(smag[0], smag[1]), fmaxf(smag[2], smag[3]));
     }
+}
+
+// The same holds for the unaries: adding sigma_ij to every candidate of (vector i, node j) leaves the argmin alone.  With sigma_ij = 2 <x_i, r_j>,
+// r_j = the mean codeword of codebook j, the shifted unary ||c||^2 - 2 <x, c - r_j> no longer carries the component every candidate shares (large on
+// SIFT-like non-negative data: it scales with ||x||), and the range the levels must cover shrinks: together with the centred table rows the common
+// step D falls by a third (11.3 -> 7.4 at cfg2), and so does the number of ambiguous node updates.  sigma only has to be THE SAME number wherever it
+// is used (range pass and level epilogue read it from memory); its own arithmetic is free.
+__global__ __launch_bounds__(256) void codebook_means_kernel(const float *__restrict__ K, int m, int d, float *__restrict__ R) {
+    // block (j, 64 dimensions): wave w sums codewords w, w + 4, ... (coalesced 256-byte reads), the four partial sums meet in LDS
+    const int j = blockIdx.y, t = blockIdx.x * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6;
+    __shared__ float part[4][64];
+    float acc = 0.0f;
+    if (t < d)
+        for (int a = wave; a < LSQ_H; a += 4) acc += K[((int64_t)j * LSQ_H + a) * d + t];
+    part[wave][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (wave == 0 && t < d) R[(int64_t)j * d + t] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x])) * (1.0f / LSQ_H);
+}
+
+// sigma[i][j] = 2 <x_i, r_j>  (one 16-lane DPP row per vector, grid-stride);  sigmax[0] = bits of max |sigma| over the chunk (non-negative floats
+// order like uints).  One atomic per wave at most, and only when the wave's maximum beats the word as L2 holds it (an L1-cached read would stay at
+// the initial 0 and send every wave's atomic to the same word: 2.5 ms of serialisation per 10^6 vectors, measured).
+__global__ __launch_bounds__(256) void unary_shift_kernel(const float *__restrict__ X, const float *__restrict__ R, int64_t n, int d, int m,
+                                                          float *__restrict__ sigma, unsigned *__restrict__ sigmax) {
+    const int lane = threadIdx.x & 63, lp = lane & 15;
+    const int64_t nrows = (int64_t)gridDim.x * 16;
+    const bool vec = (d & 3) == 0 && ((((uintptr_t)X | (uintptr_t)R) & 15) == 0);
+    float amax = 0.0f;
+    // whole waves stay together (the DPP row sums read neighbour lanes): the loop bound is wave-uniform, dead rows are masked
+    const int64_t first = ((int64_t)blockIdx.x * 256 + (threadIdx.x & ~63)) >> 4;      // the wave's first row
+    for (int64_t base = first; base < n; base += nrows) {
+        const int64_t i = base + (lane >> 4);
+        const bool live = i < n;
+        const float *x = X + (live ? i : 0) * (int64_t)d;
+        for (int j = 0; j < m; ++j) {
+            const float *r = R + (int64_t)j * d;
+            float acc = 0.0f;
+            if (vec) {
+                for (int t = 4 * lp; t < d; t += 64) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + t), rv = *reinterpret_cast<const f32x4 *>(r + t);
+                    acc += xv.x * rv.x + xv.y * rv.y + xv.z * rv.z + xv.w * rv.w;
+                }
+            } else {
+                for (int t = lp; t < d; t += 16) acc += x[t] * r[t];
+            }
+            acc = acc + dpp_self<DPP_XOR1, 0xf>(acc);
+            acc = acc + dpp_self<DPP_XOR2, 0xf>(acc);
+            acc = acc + dpp_self<DPP_HALF_MIRROR, 0xf>(acc);
+            acc = acc + dpp_self<DPP_MIRROR, 0xf>(acc);
+            const float sg = 2.0f * acc;
+            if (live && lp == 0) sigma[i * m + j] = sg;
+            if (live) amax = fmaxf(amax, fabsf(sg));                // NaN-ignoring: a non-finite sigma shows up in the range pass
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+    if (lane == 0 && __float_as_uint(amax) > __hip_atomic_load(sigmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(sigmax, __float_as_uint(amax));
 }
 
 // One block: value ranges -> lsq_q16_params (in double).
@@ -95,14 +163,14 @@ __global__ __launch_bounds__(256) void table_range_kernel(const float *__restric
 //   T_jk: exact range (table_range_kernel).
 // ok = 0 -- the whole chunk goes to the f32 walk -- when a pair table or the sample holds a non-finite value, or a range degenerates.
 __global__ __launch_bounds__(64) void q16_params_kernel(const float *__restrict__ trange, const int *__restrict__ bad, const unsigned *__restrict__ qrange,
-                                                        int m, lsq_q16_params *__restrict__ P) {
+                                                        int m, lsq_q16_params *__restrict__ P, const unsigned *__restrict__ sigrange) {
     if (threadIdx.x != 0) return;
+    const double sigmax = sigrange ? (double)__uint_as_float(sigrange[0]) : 0.0;      // max |sigma| of the chunk (bit pattern of a non-negative float)
     bool ok = (bad[0] == 0) && (qrange[2 * LSQ_MAX_M] == 0);
     for (int j = 0; j < m; ++j) {
         const unsigned kl = qrange[2 * j], kh = qrange[2 * j + 1];
         lsq_q16_node nd;
-        for (int k = 0; k < LSQ_MAX_M; ++k) nd.loT[k] = 0.0f;
-        nd.loU = 0.0f; nd.invD = 0.0f; nd.D = 0.0f; nd.hiq = 0.0f; nd.window = 65535; nd.lo_sum = 0.0; nd.slack = 0.0;
+        nd.loU = 0.0f; nd.invD = 0.0f; nd.D = 0.0f; nd.hiq = 0.0f; nd.window = 65535; nd.slack = 0.0;
         if (kl > kh) { ok = false; P->node[j] = nd; continue; }      // empty sample
         const double sl = (double)__uint_as_float((kl & 0x80000000u) ? (kl ^ 0x80000000u) : ~kl);
         const double sh = (double)__uint_as_float((kh & 0x80000000u) ? (kh ^ 0x80000000u) : ~kh);
@@ -112,23 +180,23 @@ __global__ __launch_bounds__(64) void q16_params_kernel(const float *__restrict_
         nd.loU = (float)loU;
         if ((double)nd.loU > loU) nd.loU = nextafterf(nd.loU, -__builtin_inff());
         loU = (double)nd.loU;
-        double rsum = hiU - loU, smax = fmax(fabs(loU), fabs(hiU)), lo_sum = loU;
+        double rsum = hiU - loU, smax = fmax(fabs(loU), fabs(hiU)) + sigmax, sub = fmax(fabs(loU), fabs(hiU));
         for (int k = 0; k < m; ++k) {
             if (k == j) continue;
-            const double tl = (double)trange[(j * m + k) * 2], th = (double)trange[(j * m + k) * 2 + 1];
-            nd.loT[k] = (float)tl;
-            rsum += th - tl;
-            smax += fmax(fabs(tl), fabs(th));
-            lo_sum += tl;
+            const double tr = (double)trange[(j * m + k) * 2] * (1.0 + 1e-6), tm = (double)trange[(j * m + k) * 2 + 1];      // centred-row range, magnitude
+            rsum += tr;
+            smax += tm;
+            sub += 2.0 * tm;                               // |t - rowmin| <= 2 max|t|: the f32 subtraction that centres a table entry
         }
         const double D = rsum / 65500.0;
-        const double eps = (double)(m + 1) * smax * 5.9604644775390625e-8 * 2.0;      // f32 chain vs real sum: <= m roundings of <= 2^-24 smax (x2 margin)
+        // f32 chain vs real sum: <= m roundings of <= 2^-24 smax (x2 margin);  + one f32 rounding each for the shifted unary (v + sigma) and the centred
+        // table entries (t - rowmin), <= 2^-24 of their magnitudes (x2 margin)
+        const double eps = (double)(m + 1) * smax * 5.9604644775390625e-8 * 2.0 + (sub + sigmax) * 5.9604644775390625e-8 * 2.0;
         const double slack = (double)m * (0.5 + 1.0 / 32.0) * D + eps + 65535.0 * D * 2.384185791015625e-7;      // + the f32 rounding of D and 1/D over 65535 levels
         nd.D = (float)D;
         nd.invD = (float)(1.0 / D);
         // levels of one sum: U <= hiq, table k <= R_k / D + 1/2  =>  sum <= 65500 + m / 2 + rounding < 65535: packed (and plain 32-bit) adds never carry
         nd.hiq = (float)fmin(floor((hiU - loU) / D), 65535.0);
-        nd.lo_sum = lo_sum;
         nd.slack = slack;
         const double w = 2.0 * slack / D;
         nd.window = (w < 30000.0) ? (int)w + 1 : 65535;
@@ -140,10 +208,10 @@ __global__ __launch_bounds__(64) void q16_params_kernel(const float *__restrict_
     P->nflag = 0;                // per chunk: raised by the GEMM epilogue that follows
 }
 
-// Tq[j][slice][kk][b][SLQ] (u16)  <-  rint((T[j][k(kk)][b][slice*SLQ ..] - loT[j][k]) * invD_j)      (one thread per 8 levels = 16 B)
+// Tq[j][slice][kk][b][SLQ] (u16)  <-  rint((T[j][k(kk)][b][slice*SLQ ..] - rowmin[j][k][b]) * invD_j)      (one thread per 8 levels = 16 B)
 template <int SLQ>
 __global__ __launch_bounds__(256) void tables_to_q16_slices_kernel(const float *__restrict__ T, uint16_t *__restrict__ Tq, int m,
-                                                                   const lsq_q16_params *__restrict__ P) {
+                                                                   const lsq_q16_params *__restrict__ P, const float *__restrict__ rowmin) {
     constexpr int NS = LSQ_H / SLQ, LPV = SLQ / 8;
     const int64_t total = (int64_t)m * NS * (m - 1) * LSQ_H * LPV;
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -155,7 +223,7 @@ __global__ __launch_bounds__(256) void tables_to_q16_slices_kernel(const float *
     const int slice = (int)(r % NS);
     const int j = (int)(r / NS);
     const int k = kk + (kk >= j ? 1 : 0);
-    const float lo = P->node[j].loT[k], inv = P->node[j].invD;
+    const float lo = rowmin[((int64_t)j * m + k) * LSQ_H + b], inv = P->node[j].invD;      // the row's own minimum: a shift common to all candidates
     const float *src = T + (((int64_t)j * m + k) * LSQ_H + b) * LSQ_H + slice * SLQ + qq * 8;
     uint32_t w[4];
 #pragma unroll
@@ -788,28 +856,33 @@ int lsq_q16_slice_width(int m) {
 }      // candidates per 16-bit slice: the same bytes per piece as the f32 walk
 
 int lsq_launch_q16_prepare(hipStream_t s, const float *X, int64_t n, int d, const float *K, const float *sci, const float *T, int m, uint16_t *Tq,
-                           int *bad, float *trange, unsigned *qrange, unsigned short *qflag, lsq_q16_params *P, int tables_changed) {
-    // bad[0]: a non-finite pair table (per call)
+                           int *bad, float *trange, unsigned *qrange, unsigned short *qflag, lsq_q16_params *P, int tables_changed,
+                           float *rowmin, float *means, float *sigma) {
+    // bad[0]: a non-finite pair table (per call); rowmin [m*m*256], means [m*d]: per call; sigma [n*m]: per chunk; qrange[2*16 + 1]: sample flag, [2*16 + 2]: max |sigma|
     if (tables_changed) {
         LSQ_HIP(hipMemsetAsync(bad, 0, sizeof(int), s));
-        if (m > 1) hipLaunchKernelGGL(table_range_kernel, dim3((unsigned)(m * m)), dim3(256), 0, s, T, m, trange, bad);
+        if (m > 1) hipLaunchKernelGGL(table_range_kernel, dim3((unsigned)(m * m)), dim3(256), 0, s, T, m, trange, rowmin, bad);
+        hipLaunchKernelGGL(codebook_means_kernel, dim3((unsigned)((d + 63) / 64), (unsigned)m), dim3(256), 0, s, K, m, d, means);
     }
-    // sampled range of the unaries: about 16 384 vectors at d <= 128 (every rts-th panel of 128 consecutive ones) through the range-only GEMM pass
-    LSQ_HIP(hipMemsetAsync(qrange, 0, sizeof(unsigned) * (2 * LSQ_MAX_M + 1), s));
+    // sampled range of the SHIFTED unaries: about 16 384 vectors at d <= 128 (every rts-th panel of 128 consecutive ones) through the range-only GEMM pass
+    LSQ_HIP(hipMemsetAsync(qrange, 0, sizeof(unsigned) * (2 * LSQ_MAX_M + 2), s));
     for (int j = 0; j < m; ++j) LSQ_HIP(hipMemsetAsync(qrange + 2 * j, 0xff, sizeof(unsigned), s));      // min slots start at the largest key
     if (n > 0) {
+        const int64_t shift_blocks = (n * 16 + 255) / 256;           // 16 vectors per block per pass, at most 8 blocks per CU in flight
+        hipLaunchKernelGGL(unary_shift_kernel, dim3((unsigned)(shift_blocks < 2048 ? shift_blocks : 2048)), dim3(256), 0, s, X, means, n, d, m, sigma,
+                           qrange + 2 * LSQ_MAX_M + 1);
         const int64_t nsample = d <= 128 ? 16384 : (d <= 512 ? 8192 : 4096);      // the pass costs 2 d m h flops per sampled vector: fewer of them at large d
         const int rts = n > nsample ? (int)(n / nsample) : 1;
-        LSQ_TRY(lsq_launch_chain_gemm(s, X, K, sci, -2.0f, n, m * LSQ_H, d, LSQ_H, 0, 0, nullptr, 0, n, 0, nullptr, 0, nullptr, 0, nullptr, qrange, rts));
+        LSQ_TRY(lsq_launch_chain_gemm(s, X, K, sci, -2.0f, n, m * LSQ_H, d, LSQ_H, 0, 0, nullptr, 0, n, 0, nullptr, 0, nullptr, 0, nullptr, qrange, rts, sigma));
         LSQ_HIP(hipMemsetAsync(qflag, 0, sizeof(unsigned short) * (size_t)((n + 1) & ~(int64_t)1), s));
     }
-    hipLaunchKernelGGL(q16_params_kernel, dim3(1), dim3(64), 0, s, trange, bad, qrange, m, P);
+    hipLaunchKernelGGL(q16_params_kernel, dim3(1), dim3(64), 0, s, trange, bad, qrange, m, P, qrange + 2 * LSQ_MAX_M + 1);
     if (m > 1) {
         const int slq = lsq_q16_slice_width(m);
         const int64_t total = (int64_t)m * (LSQ_H / slq) * (m - 1) * LSQ_H * (slq / 8);
         const unsigned grid = (unsigned)((total + 255) / 256);
-        if (slq == 32) hipLaunchKernelGGL(tables_to_q16_slices_kernel<32>, dim3(grid), dim3(256), 0, s, T, Tq, m, P);
-        else hipLaunchKernelGGL(tables_to_q16_slices_kernel<16>, dim3(grid), dim3(256), 0, s, T, Tq, m, P);
+        if (slq == 32) hipLaunchKernelGGL(tables_to_q16_slices_kernel<32>, dim3(grid), dim3(256), 0, s, T, Tq, m, P, rowmin);
+        else hipLaunchKernelGGL(tables_to_q16_slices_kernel<16>, dim3(grid), dim3(256), 0, s, T, Tq, m, P, rowmin);
     }
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;

@@ -259,6 +259,22 @@ def test_filter_exact_ties_and_near_ties(lsq, oracle):
     assert t["filter_refined"] > 0 and t["filter_exact"] > 2 * t["filter_refined"], t      # some windows hold more than two candidates
 
 
+@pytest.mark.parametrize("d,m,offset", [(32, 8, 50.0), (30, 8, 1000.0), (33, 16, 5.0), (7, 3, 2.0e4)])
+def test_filter_shift_invariant_levels(lsq, oracle, d, m, offset):
+    """The levels are taken of U + sigma_i (sigma_i = 2 <x_i, mean codeword>) and of table rows minus their own minimum -- shifts every candidate of
+    a node update shares.  Data and codebooks with a LARGE common component (every vector and every codeword moved by `offset` along one direction)
+    make those shifts orders of magnitude larger than the differences that decide the argmin: the f32 rounding of the shifts must be inside the
+    filter's bound, or codes would differ from the oracle's.  d not a multiple of 4: the scalar path of the shift kernel."""
+    n, seed = 20_000, 77
+    X, K, B0 = make_problem(d, n, m, seed=seed, kind="gauss")
+    u = np.random.default_rng(5).standard_normal(d).astype(np.float32)
+    u /= np.linalg.norm(u)
+    X = np.ascontiguousarray(X + np.float32(offset) * u)
+    K = np.ascontiguousarray(K + np.float32(offset / m) * u)
+    t = _filter_case(lsq, oracle, X, K, B0, m, [2], 2, 4, seed)
+    assert t["filter_f32"] < 0.05 * t["icm_node_updates"], t      # the shifted range was sampled well: few vectors fall outside it
+
+
 def test_filter_more_ambiguous_vectors_than_records(lsq, oracle):
     """Every codeword duplicated: EVERY node update is an exact tie, so all ~1200 vectors of a block are ambiguous at once -- more than the 1024
     refinement records a block holds: the overflow takes the one-wave-per-vector f32 routine.  All vectors vs the oracle."""
