@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define LSQ_VERSION 300
+#define LSQ_VERSION 310
 
 #if defined(__GNUC__)
 #define LSQ_API __attribute__((visibility("default")))
@@ -237,6 +237,27 @@ LSQ_API int lsq_splitarray(int64_t n, int nparts, int part, int64_t *start, int6
 LSQ_API int lsq_linscan_aqd_query_extra_byte(float *dists, int *idx, const unsigned char *codes, const float *queries,
                                      const float *codebooks, const float *dbnorms, int nqueries, int ncodes,
                                      int m, int h, int d, int nn, int nthreads);
+
+/* The same scan ON THE DEVICE (SURVEY 8(f)-1 "HIP scan later"; csrc/lsq_adc.hip).  Same argument list behind a context; same results bit for
+ * bit -- distances, 1-based ids, order including ties -- as the host function above and as the reference build.  Requires h == 256,
+ * 1 <= m <= 16, 1 <= nn <= ncodes.  NaN distances (undefined order in the reference's partial_sort) sort last.
+ *   lsq_linscan      host buffers (uploaded, searched, downloaded);
+ *   lsq_linscan_dev  device buffers: codes [ncodes][m] uint8 0-based, queries [nq][d], codebooks [m*h][d], dbnorms [ncodes]; outputs [nq][nn]. */
+LSQ_API int lsq_linscan(lsq_ctx *ctx, float *dists, int *idx, const unsigned char *codes, const float *queries, const float *codebooks,
+                        const float *dbnorms, int nqueries, int ncodes, int m, int h, int d, int nn);
+LSQ_API int lsq_linscan_dev(lsq_ctx *ctx, float *d_dists, int *d_idx, const uint8_t *d_codes, const float *d_queries, const float *d_codebooks,
+                            const float *d_dbnorms, int nqueries, int ncodes, int m, int h, int d, int nn);
+/* What the device scan did since the last lsq_reset_timings (times only with option "profile" = 1). */
+typedef struct lsq_linscan_stats {
+    int64_t queries, codes;          /* queries searched (accumulated); database size of the last call */
+    int64_t candidates;              /* (dist, id) pairs written to memory: the lists the selection sorted */
+    int64_t fallback_queries;        /* queries redone by the exhaustive road (candidate list short or overflowing) */
+    int64_t batches;
+    int64_t exhaustive;              /* last call: 1 = every distance written and sorted (small database / large nn / option) */
+    int64_t threshold_rank, list_capacity;      /* last call: sample rank of the threshold, entries per candidate list */
+    double lut_ms, sample_ms, scan_ms, select_ms;
+} lsq_linscan_stats;
+LSQ_API int lsq_get_linscan_stats(lsq_ctx *ctx, lsq_linscan_stats *out);
 
 /* update_codebooks(X, B, h) -> C      src/codebook_update.jl:52-86 (host code; north_star keeps it on the host).
  * K[t, :] = lsqr(sparsify_codes(B, h), X[t, :]) for every dimension t (LSQR of Paige & Saunders, Float32,

@@ -34,6 +34,15 @@ class Timings(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class LinscanStats(C.Structure):
+    _fields_ = [("queries", C.c_int64), ("codes", C.c_int64), ("candidates", C.c_int64), ("fallback_queries", C.c_int64),
+                ("batches", C.c_int64), ("exhaustive", C.c_int64), ("threshold_rank", C.c_int64), ("list_capacity", C.c_int64),
+                ("lut_ms", C.c_double), ("sample_ms", C.c_double), ("scan_ms", C.c_double), ("select_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 _vp, _i, _i64, _u64, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_uint32
 
 # name -> (restype, argtypes).  Pointers are passed as raw addresses (host or device).
@@ -66,6 +75,9 @@ SIGNATURES = {
     "lsq_node_order": (_i, [_u64, _u32, _i, _i, _vp]),
     "lsq_splitarray": (_i, [_i64, _i, _i, C.POINTER(_i64), C.POINTER(_i64)]),
     "lsq_linscan_aqd_query_extra_byte": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
+    "lsq_linscan": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
+    "lsq_linscan_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
+    "lsq_get_linscan_stats": (_i, [_vp, C.POINTER(LinscanStats)]),
     "lsq_update_codebooks": (_i, [_vp, _vp, _i, _i64, _i, _i, _i, _vp]),
     "lsq_synth_data_u8_dev": (_i, [_vp, _u64, _u64, _i64, _i, _vp]),
     "lsq_randinit_dev": (_i, [_vp, _u64, _u64, _i64, _i, _i, _vp]),

@@ -85,6 +85,9 @@ struct lsq_ctx {
     // the same shape is remembered instead (re-probed every 16th call)
     int64_t call_I = 0, call_q16_chunks = 0;
     int64_t sticky_n = -1; int sticky_d = 0, sticky_m = 0, sticky_bad = 0, sticky_count = 0;
+    lsq_adc_state *adc = nullptr;                      // device ADC scan (lsq_adc.hip): buffers, created on first use
+    lsq_linscan_stats adc_stats{};
+    int adc_exhaustive = 0, adc_rank = 0;              // options "linscan_exhaustive", "linscan_rank": test hooks of the scan's selection
     DevBuf sX, sX2, sK, sB16, sOut16, sTight, sF32;    // staging for the host-buffer entry points (sX/sX2: double-buffered X chunks)
     hipStream_t copy_stream = nullptr;               // H2D of X runs here, under the compute of the previous panel / chunk
     hipEvent_t copy_done = nullptr;
@@ -169,6 +172,7 @@ extern "C" int lsq_destroy(lsq_ctx *c) {
     DevBuf *bufs[] = {&c->probe, &c->Uq, &c->Tq, &c->qp, &c->qscratch, &c->qflag, &c->qsigma, &c->sci, &c->T, &c->Ts, &c->U, &c->part, &c->vCur, &c->vNew, &c->active, &c->recCur, &c->recNew, &c->prev, &c->counters, &c->obj, &c->bad,
                       &c->sX, &c->sX2, &c->sK, &c->sB16, &c->sOut16, &c->sTight, &c->sF32};
     for (DevBuf *b : bufs) b->release();
+    lsq_adc_free(c->adc);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
@@ -205,6 +209,11 @@ extern "C" int lsq_set_option(lsq_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "filter_fallback_div")) {
         if (value < 0) { lsq_set_error("filter_fallback_div must be >= 0"); return LSQ_EINVAL; }
         c->fallback_div = value;
+    }
+    else if (!strcmp(key, "linscan_exhaustive")) c->adc_exhaustive = value != 0;
+    else if (!strcmp(key, "linscan_rank")) {
+        if (value < 0) { lsq_set_error("linscan_rank must be >= 0"); return LSQ_EINVAL; }
+        c->adc_rank = (int)value;
     }
     else if (!strcmp(key, "ils_counter")) {
         if (value < 0 || value >= (int64_t)LSQ_IT_AUTO) { lsq_set_error("ils_counter must lie in 0..2^32-2"); return LSQ_EINVAL; }
@@ -256,6 +265,43 @@ extern "C" int lsq_reset_timings(lsq_ctx *c) {
     c->icm_launches = c->icm_node_updates = c->staged_blocks = c->light_blocks = c->filtered_blocks = c->filter_refined = c->filter_exact = c->filter_f32 = 0;
     c->filter_fallback_chunks = 0;
     for (int64_t &v : c->trace) v = 0;
+    c->adc_stats = lsq_linscan_stats{};
+    return LSQ_OK;
+}
+
+// ---- device ADC scan (lsq_adc.hip) -------------------------------------------------------------------------------------------------------
+static int linscan_check(const char *fn, const void *a, const void *b, const void *c0, const void *d0, const void *e, const void *f, int nq, int n,
+                         int m, int h, int d, int nn) {
+    if (nq < 0 || n < 0 || d < 1 || nn < 1) { lsq_set_error("%s: bad shape nq=%d n=%d d=%d nn=%d", fn, nq, n, d, nn); return LSQ_EINVAL; }
+    if (h != LSQ_H || m < 1 || m > LSQ_MAX_M) { lsq_set_error("%s: needs h == 256 and 1 <= m <= 16 (got h=%d m=%d)", fn, h, m); return LSQ_EINVAL; }
+    if (nn > n) { lsq_set_error("%s: nn=%d exceeds the database size %d", fn, nn, n); return LSQ_EINVAL; }
+    if (nq > 0 && (!a || !b || !c0 || !d0 || !e || !f)) { lsq_set_error("%s: null pointer", fn); return LSQ_EINVAL; }
+    return LSQ_OK;
+}
+
+extern "C" int lsq_linscan_dev(lsq_ctx *c, float *d_dists, int *d_idx, const uint8_t *d_codes, const float *d_queries, const float *d_codebooks,
+                               const float *d_dbnorms, int nqueries, int ncodes, int m, int h, int d, int nn) {
+    if (!c) { lsq_set_error("lsq_linscan_dev: null context"); return LSQ_EINVAL; }
+    LSQ_TRY(linscan_check("lsq_linscan_dev", d_dists, d_idx, d_codes, d_queries, d_codebooks, d_dbnorms, nqueries, ncodes, m, h, d, nn));
+    if (nqueries == 0) return LSQ_OK;
+    LSQ_TRY(use_device(c));
+    return lsq_adc_search(c->stream, &c->adc, d_dists, d_idx, d_codes, d_queries, d_codebooks, d_dbnorms, nqueries, ncodes, m, d, nn, c->adc_exhaustive,
+                          c->adc_rank, &c->adc_stats, c->profile);
+}
+
+extern "C" int lsq_linscan(lsq_ctx *c, float *dists, int *idx, const unsigned char *codes, const float *queries, const float *codebooks,
+                           const float *dbnorms, int nqueries, int ncodes, int m, int h, int d, int nn) {
+    if (!c) { lsq_set_error("lsq_linscan: null context"); return LSQ_EINVAL; }
+    LSQ_TRY(linscan_check("lsq_linscan", dists, idx, codes, queries, codebooks, dbnorms, nqueries, ncodes, m, h, d, nn));
+    if (nqueries == 0) return LSQ_OK;
+    LSQ_TRY(use_device(c));
+    return lsq_adc_search_host(c->stream, &c->adc, dists, idx, codes, queries, codebooks, dbnorms, nqueries, ncodes, m, d, nn, c->adc_exhaustive,
+                               c->adc_rank, &c->adc_stats, c->profile);
+}
+
+extern "C" int lsq_get_linscan_stats(lsq_ctx *c, lsq_linscan_stats *out) {
+    if (!c || !out) { lsq_set_error("lsq_get_linscan_stats: null argument"); return LSQ_EINVAL; }
+    *out = c->adc_stats;
     return LSQ_OK;
 }
 

@@ -183,3 +183,13 @@ int lsq_launch_sum_f64(hipStream_t s, const float *v, int64_t n, double *sum);
 int lsq_launch_synth_data_u8(hipStream_t s, uint64_t seed, uint64_t global_offset, int64_t n, int d, float *X);
 int lsq_launch_randinit(hipStream_t s, uint64_t seed, uint64_t global_offset, int64_t n, int m, int h, uint8_t *tight);
 int lsq_launch_synth_codebooks(hipStream_t s, uint64_t seed, int m, int h, int d, float *K);
+
+// ---- device ADC scan (lsq_adc.hip) ----------------------------------------------------------------------------------------------------
+struct lsq_adc_state;      // buffers of the scan, owned by the context
+void lsq_adc_free(lsq_adc_state *st);
+// device pointers; force_exhaustive / rank_override: test hooks (options "linscan_exhaustive", "linscan_rank")
+int lsq_adc_search(hipStream_t s, lsq_adc_state **st, float *dists, int *idx, const uint8_t *codes, const float *Q, const float *K, const float *dbnorms,
+                   int nq, int n, int m, int d, int nn, int force_exhaustive, int rank_override, lsq_linscan_stats *stats, int timed);
+int lsq_adc_search_host(hipStream_t s, lsq_adc_state **st, float *dists, int *idx, const unsigned char *codes, const float *Q, const float *K,
+                        const float *dbnorms, int nq, int n, int m, int d, int nn, int force_exhaustive, int rank_override, lsq_linscan_stats *stats,
+                        int timed);

@@ -138,6 +138,41 @@ class Engine:
                                                    stats.ctypes.data))
         return dBs, obj, stats
 
+    # -- (1c) the search step after the path: ADC linear scan on the device ------------------
+    def linscan(self, codes, Q, K, dbnorms, m, k, h=H):
+        """codes (n,m) uint8 0-based, Q (nq,d), K (m*h,d), dbnorms (n,): host arrays.
+        -> dists (nq,k) float32 ascending, ids (nq,k) int32 1-BASED   [lsq_linscan]"""
+        codes, Q, K, dbn = _np(codes, np.uint8), _np(Q, np.float32), _np(K, np.float32), _np(dbnorms, np.float32)
+        n, nq, d = codes.shape[0], Q.shape[0], Q.shape[1]
+        if codes.shape != (n, m) or K.shape != (m * h, d) or dbn.shape != (n,):
+            raise ValueError("shape mismatch: codes %s Q %s K %s dbnorms %s m=%d h=%d" % (codes.shape, Q.shape, K.shape, dbn.shape, m, h))
+        dists = np.zeros((nq, k), dtype=np.float32)
+        ids = np.zeros((nq, k), dtype=np.int32)
+        self._check(self._L.lsq_linscan(self._h, dists.ctypes.data, ids.ctypes.data, codes.ctypes.data, Q.ctypes.data, K.ctypes.data,
+                                        dbn.ctypes.data, nq, n, m, h, d, int(k)))
+        return dists, ids
+
+    def linscan_dev(self, dcodes, dQ, dK, dnorms, m, k, h=H):
+        """The same on device-resident torch tensors -> (dists (nq,k) f32, ids (nq,k) int32 1-based) tensors   [lsq_linscan_dev]"""
+        import torch
+        assert dcodes.is_cuda and dQ.is_cuda and dK.is_cuda and dnorms.is_cuda, "device tensors required"
+        assert dcodes.dtype == torch.uint8 and dQ.dtype == torch.float32 and dK.dtype == torch.float32 and dnorms.dtype == torch.float32
+        assert dcodes.is_contiguous() and dQ.is_contiguous() and dK.is_contiguous() and dnorms.is_contiguous()
+        n, (nq, d) = dcodes.shape[0], dQ.shape
+        if dcodes.shape != (n, m) or dK.shape != (m * h, d) or dnorms.shape != (n,):
+            raise ValueError("shape mismatch")
+        dists = torch.empty((nq, k), dtype=torch.float32, device=dQ.device)
+        ids = torch.empty((nq, k), dtype=torch.int32, device=dQ.device)
+        with self._on_torch_stream():
+            self._check(self._L.lsq_linscan_dev(self._h, dists.data_ptr(), ids.data_ptr(), dcodes.data_ptr(), dQ.data_ptr(), dK.data_ptr(),
+                                                dnorms.data_ptr(), nq, n, m, h, d, int(k)))
+        return dists, ids
+
+    def linscan_stats(self):
+        t = _lib.LinscanStats()
+        self._check(self._L.lsq_get_linscan_stats(self._h, C.byref(t)))
+        return t.as_dict()
+
     # -- (2) CPU-path shaped ---------------------------------------------------------------
     def encoding_icm(self, X, oldB, K, m, niter, randord, npert, seed=0, it=None, global_offset=0, h=H):
         """ONE ILS iteration with the accept rule.  it=None (default): the context's own counter (LSQ_IT_AUTO) -- the k-th call uses it = k-1."""

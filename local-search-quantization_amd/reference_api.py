@@ -110,10 +110,12 @@ def qerror(X, B, C, *, engine=None):
     return eng.qerror(_X_of(X), _B_of(B), _K_of(C), m, h=h)
 
 
-def linscan_lsq(B, X, C, dbnorms, R, k=10000, *, nthreads=0):
+def linscan_lsq(B, X, C, dbnorms, R, k=10000, *, nthreads=0, engine=None):
     """Linear scan with LSQ codes + separately stored norms  (src/linscan/Linscan.jl:46-73).
     B (m, n) uint8 0-based; X (d, nq) queries; C list of (d, h); dbnorms (n,); R (d, d) rotation.
-    -> dists (k, nq) float32 ascending, res (k, nq) int32 1-based ids."""
+    -> dists (k, nq) float32 ascending, res (k, nq) int32 1-based ids.
+    engine=None: the host scan (lsq_linscan_aqd_query_extra_byte, the reference's own division of labour);
+    engine=<Engine>: the device scan (lsq_linscan) -- same results bit for bit."""
     from . import _lib
     B = np.ascontiguousarray(np.asarray(B, dtype=np.uint8).T)                   # (n, m)
     RX = np.ascontiguousarray((np.asarray(R, dtype=np.float32).T @ np.asarray(X, dtype=np.float32)).T)   # (nq, d)
@@ -122,6 +124,9 @@ def linscan_lsq(B, X, C, dbnorms, R, k=10000, *, nthreads=0):
     n, m = B.shape
     nq, d = RX.shape
     h = np.asarray(C[0]).shape[1]
+    if engine is not None:
+        dists, res = engine.linscan(B, RX, K, dbn, m, k, h=h)
+        return dists.T, res.T
     dists = np.zeros((nq, k), dtype=np.float32)
     res = np.zeros((nq, k), dtype=np.int32)
     _lib.check(_lib.load().lsq_linscan_aqd_query_extra_byte(dists.ctypes.data, res.ctypes.data, B.ctypes.data, RX.ctypes.data,

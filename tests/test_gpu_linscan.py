@@ -1,0 +1,135 @@
+"""Row 8(f)-1 on the device: lsq_linscan / lsq_linscan_dev (csrc/lsq_adc.hip) must return what the reference's own
+linscan_aqd_query_extra_byte returns (oracle/_ref: src/linscan/cpp/linscan_aqd_pairwise_byte.cpp compiled as it stands) -- distances bit
+for bit, 1-based ids, order including ties -- on every road of the selection: exhaustive (small databases), thresholded candidate lists
+(large ones), and the fallback for queries whose list came out short or overflowed."""
+import numpy as np
+import pytest
+
+from test_linscan import _case, _ours
+
+pytestmark = pytest.mark.gpu
+H = 256
+
+
+def _reference(lsq, oracle, codes, Q, K, dbnorms, m, knn):
+    """the reference build where it travelled (oracle/_ref), else this library's host scan (itself pinned to the reference in test_linscan.py)"""
+    if oracle.ref_linscan_path() is not None:
+        return oracle.ref_linscan(codes, Q, K, dbnorms, m, H, knn)
+    return _ours(lsq, codes, Q, K, dbnorms, m, knn)
+
+
+def _check(lsq, oracle, codes, Q, K, dbnorms, m, knn, expect=None, **options):
+    dref, iref = _reference(lsq, oracle, codes, Q, K, dbnorms, m, knn)
+    with lsq.Engine(0) as eng:
+        for k, v in options.items():
+            eng.set_option(k, v)
+        dists, ids = eng.linscan(codes, Q, K, dbnorms, m, knn)
+        st = eng.linscan_stats()
+    assert np.array_equal(ids, iref), "%d of %d ids differ (%r)" % ((ids != iref).sum(), ids.size, st)
+    assert np.array_equal(dists.view(np.uint32), dref.view(np.uint32)), "max |diff| %g" % np.abs(dists - dref).max()
+    assert ids.min() >= 1 and ids.max() <= codes.shape[0]
+    if expect is not None:
+        for k, v in expect.items():
+            assert (st[k] == v) if not callable(v) else v(st[k]), (k, st)
+    return st
+
+
+@pytest.mark.parametrize("n,nq,d,m,knn,ties", [(5000, 37, 32, 7, 100, False), (3000, 16, 128, 8, 1000, False), (2000, 20, 16, 4, 50, True),
+                                              (64, 5, 8, 2, 64, True), (1000, 3, 24, 16, 10, False), (17, 1, 5, 1, 1, False),
+                                              (4096, 33, 960, 8, 7, False), (300, 2, 1030, 3, 300, False)])
+def test_small_databases_take_the_exhaustive_road(lsq, oracle, n, nq, d, m, knn, ties):
+    rng = np.random.default_rng(n + d)
+    codes, Q, K, dbnorms = _case(rng, n, nq, d, m, ties)
+    _check(lsq, oracle, codes, Q, K, dbnorms, m, knn, expect={"exhaustive": 1, "fallback_queries": 0, "queries": nq})
+
+
+@pytest.mark.parametrize("n,nq,d,m,knn,ties", [(200_000, 40, 32, 8, 100, False), (150_001, 19, 16, 16, 10, False), (120_000, 16, 24, 7, 1000, False),
+                                              (100_000, 50, 8, 4, 1, False), (131_072, 33, 20, 12, 64, True), (90_000, 5, 12, 5, 2000, True)])
+def test_thresholded_candidate_lists(lsq, oracle, n, nq, d, m, knn, ties):
+    """the production road: a sampled threshold per query, (dist, id) pairs at or below it appended by the scan, lists sorted"""
+    rng = np.random.default_rng(n + m)
+    codes, Q, K, dbnorms = _case(rng, n, nq, d, m, ties)
+    st = _check(lsq, oracle, codes, Q, K, dbnorms, m, knn, expect={"exhaustive": 0, "queries": nq})
+    assert st["fallback_queries"] == 0, st                                  # exchangeable data: the estimate holds for every query
+    assert st["candidates"] < 0.25 * n * nq and st["candidates"] >= knn * nq, st      # a small part of the distances was ever written
+
+
+def test_short_lists_fall_back(lsq, oracle):
+    """threshold = the sample's MINIMUM (option linscan_rank = 1): every list is far too short -> every query is redone exhaustively"""
+    rng = np.random.default_rng(11)
+    n, nq, d, m, knn = 100_000, 21, 16, 8, 50
+    codes, Q, K, dbnorms = _case(rng, n, nq, d, m)
+    _check(lsq, oracle, codes, Q, K, dbnorms, m, knn, expect={"exhaustive": 0, "fallback_queries": nq}, linscan_rank=1)
+
+
+def test_overflowing_lists_fall_back(lsq, oracle):
+    """a database of identical entries: every distance ties with the threshold, the lists overflow, the fallback orders the ties by id"""
+    rng = np.random.default_rng(12)
+    n, nq, d, m, knn = 80_000, 9, 16, 8, 30
+    codes, Q, K, dbnorms = _case(rng, n, nq, d, m)
+    codes[:] = codes[0]
+    dbnorms[:] = dbnorms[0]
+    st = _check(lsq, oracle, codes, Q, K, dbnorms, m, knn, expect={"fallback_queries": nq})
+    with lsq.Engine(0) as eng:
+        _, ids = eng.linscan(codes, Q, K, dbnorms, m, knn)
+    assert np.array_equal(ids, np.tile(np.arange(1, knn + 1, dtype=np.int32), (nq, 1))), st
+
+
+def test_sorted_database_is_still_exact(lsq, oracle):
+    """the near neighbours of every query sit where the strided sample does not look (and the sampled entries are all far):
+    the threshold is useless, the answer must not be"""
+    rng = np.random.default_rng(13)
+    n, nq, d, m, knn = 160_000, 12, 16, 8, 200
+    codes, Q, K, dbnorms = _case(rng, n, nq, d, m)
+    stride = n // 16384
+    dbnorms[::stride] += np.float32(1.0e6)                                   # every sampled entry is pushed far away
+    st = _check(lsq, oracle, codes, Q, K, dbnorms, m, knn)
+    assert st["fallback_queries"] == nq, st                                 # the lists overflowed (threshold above everything unsampled)
+
+
+def test_forced_exhaustive_equals_thresholded(lsq, oracle):
+    rng = np.random.default_rng(14)
+    n, nq, d, m, knn = 70_000, 18, 32, 8, 500
+    codes, Q, K, dbnorms = _case(rng, n, nq, d, m, ties=True)
+    _check(lsq, oracle, codes, Q, K, dbnorms, m, knn, expect={"exhaustive": 1}, linscan_exhaustive=1)
+    _check(lsq, oracle, codes, Q, K, dbnorms, m, knn, expect={"exhaustive": 0})
+
+
+def test_device_tensors_and_reference_shaped_call(lsq, oracle):
+    import torch
+    rng = np.random.default_rng(15)
+    n, nq, d, m, knn = 100_000, 70, 32, 8, 100
+    codes, Q, K, dbnorms = _case(rng, n, nq, d, m)
+    dref, iref = _reference(lsq, oracle, codes, Q, K, dbnorms, m, knn)
+    dev = torch.device("cuda:0")
+    with lsq.Engine(0, profile=True) as eng:
+        dd, di = eng.linscan_dev(torch.from_numpy(codes).to(dev), torch.from_numpy(Q).to(dev), torch.from_numpy(K).to(dev),
+                                 torch.from_numpy(dbnorms).to(dev), m, knn)
+        torch.cuda.synchronize()
+        st = eng.linscan_stats()
+        assert np.array_equal(di.cpu().numpy(), iref) and np.array_equal(dd.cpu().numpy(), dref)
+        assert st["scan_ms"] > 0 and st["lut_ms"] > 0 and st["select_ms"] > 0, st
+        # Julia shapes: B (m,n), X (d,nq), C list of (d,h); identity rotation
+        C = [np.ascontiguousarray(K[j * H:(j + 1) * H].T) for j in range(m)]
+        dists, res = lsq.linscan_lsq(codes.T, Q.T, C, dbnorms, np.eye(d, dtype=np.float32), knn, engine=eng)
+    assert np.array_equal(res.T, iref) and np.array_equal(dists.T, dref)
+
+
+def test_sift1m_shape_sample_of_queries(lsq, oracle):
+    """BASELINE configs[1]'s search shape (10^6 codes, m = 8, d = 128, knn = 1000): 48 queries against the host scan"""
+    rng = np.random.default_rng(16)
+    n, nq, d, m, knn = 1_000_000, 48, 128, 8, 1000
+    codes, Q, K, dbnorms = _case(rng, n, nq, d, m)
+    st = _check(lsq, oracle, codes, Q, K, dbnorms, m, knn, expect={"exhaustive": 0})
+    assert st["fallback_queries"] == 0 and st["candidates"] < 0.02 * n * nq, st
+
+
+def test_bad_arguments(lsq):
+    z = np.zeros((4, 2), np.uint8)
+    with lsq.Engine(0) as eng:
+        with pytest.raises(lsq._lib.LsqError):
+            eng.linscan(z, np.zeros((1, 3), np.float32), np.zeros((2 * H, 3), np.float32), np.zeros(4, np.float32), 2, 5)      # nn > n
+        with pytest.raises(lsq._lib.LsqError):
+            eng.linscan(z, np.zeros((1, 3), np.float32), np.zeros((2 * 16, 3), np.float32), np.zeros(4, np.float32), 2, 1, h=16)   # h != 256
+        d, i = eng.linscan(z, np.zeros((0, 3), np.float32), np.zeros((2 * H, 3), np.float32), np.zeros(4, np.float32), 2, 1)   # no queries
+        assert d.shape == (0, 1) and i.shape == (0, 1)
