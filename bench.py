@@ -26,6 +26,8 @@ Prints ONE JSON line on rank 0 with the driver's contract fields plus
                      unchanged node updates + the 16-bit filter): `trained` (codebooks trained by this package's own train_lsq on a 100 000-vector
                      sample -- the reference encodes with trained codebooks, LSQ.jl:10-88 -> demo_lsq_gpu.jl:33-50), `floor` (memoisation off:
                      every node update recomputed, filtered walk and f32 walk), `heavy_tailed` (Cauchy-scaled vectors: out-of-range unaries);
+  `search`           the step after the path on the codes just produced: the device ADC scan (10^4 queries, 1000 neighbours) with its LDS-gather
+                     roofline, the host scan and the reference's own build as CPU figures and checkers (SURVEY 8(f)-1);
   `sample_parity`    two 256-vector blocks of the timed output re-computed with the CPU oracle after the timed region;
   `north_star_point` the same workload at north_star's own operating point (4 ILS iterations), with its CPU baseline;
   `end_to_end`       the host-buffer entry point lsq_encode_icm on pageable host memory (H2D of X, D2H of the codes included);
@@ -286,6 +288,66 @@ def workloads_leg(lsq, eng, dX, dB0, dK, n, d, m, args, goff):
     return out
 
 
+def search_leg(lsq, eng, dK, dcodes, n, d, m, nq=10000, knn=1000):
+    """The step after the path (BASELINE's other metric, recall@1, is computed from it): the ADC linear scan over the codes the timed
+    loop produced, on the device (lsq_linscan_dev), with the host scan and -- where it travelled -- the reference's own build as CPU figures and
+    checkers.  Synthetic queries from the data distribution; dbnorms = ||sum of codewords||^2 (f64 -> f32)."""
+    import torch
+    H = 256
+    dQ = eng.synth_data_u8_dev(777, nq, d)
+    recon = torch.zeros((n, d), dtype=torch.float32, device=dK.device)
+    for j in range(m):
+        recon += dK[j * H + dcodes[:, j].long()]
+    dN = (recon.double() ** 2).sum(1).float().contiguous()
+    del recon
+    eng.linscan_dev(dcodes, dQ[:64].contiguous(), dK, dN, m, knn)
+    torch.cuda.synchronize()
+    eng.reset_timings()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dd, di = eng.linscan_dev(dcodes, dQ, dK, dN, m, knn)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    st = eng.linscan_stats()
+    lookups = float(n) * nq * m
+    res = {"value": nq / dt, "unit": "queries/s", "ms_per_call": dt * 1e3, "queries": nq, "codes": n, "knn": knn,
+           "breakdown_ms": {k: st[k] / reps for k in ("lut_ms", "sample_ms", "scan_ms", "select_ms")},
+           "table_lookups_per_s": lookups / dt,
+           "roofline": {"kernel": "adc_scan_kernel", "bound": "lds", "achieved": lookups * 16 / 4 * reps / (st["scan_ms"] * 1e-3) / 1e12 if st["scan_ms"] > 0 else None,
+                        "peak": 64.0, "unit": "TB/s",
+                        "note": "16-byte LDS reads of random 64-byte table rows (one code x four queries each) during the scan kernel alone; peak = what "
+                                "tools/ubench_lds measures for exactly this access pattern on this part (profiles/ubench_lds_*.txt: 63.9 TB/s; linear "
+                                "conflict-free reads 76.7 TB/s)"},
+           "candidates_per_query": st["candidates"] / max(st["queries"], 1), "fallback_queries": int(st["fallback_queries"]),
+           "threshold_rank": int(st["threshold_rank"]), "list_capacity": int(st["list_capacity"]),
+           "note": "lsq_linscan_dev on the codes of the timed encode, inputs resident in HBM; distances, ids and tie order identical to the reference's "
+                   "linscan_aqd_query_extra_byte (checked below on a sample of the queries)"}
+    if res["roofline"]["achieved"]:
+        res["roofline"]["frac"] = res["roofline"]["achieved"] / res["roofline"]["peak"]
+    # CPU figures + checks on a bounded sample of the queries
+    nh = min(nq, 512)
+    codes_h, Q_h, K_h, N_h = dcodes.cpu().numpy(), dQ[:nh].cpu().numpy(), dK.cpu().numpy(), dN.cpu().numpy()
+    L = lsq._lib.load()
+    hd = np.zeros((nh, knn), np.float32)
+    hi = np.zeros((nh, knn), np.int32)
+    t0 = time.perf_counter()
+    lsq._lib.check(L.lsq_linscan_aqd_query_extra_byte(hd.ctypes.data, hi.ctypes.data, codes_h.ctypes.data, Q_h.ctypes.data, K_h.ctypes.data,
+                                                      N_h.ctypes.data, nh, n, m, H, d, knn, 0))
+    th = time.perf_counter() - t0
+    res["host_scan"] = {"value": nh / th, "unit": "queries/s", "queries": nh, "threads": os.cpu_count(), "kind": "this library's host scan (lsq_linscan_aqd_query_extra_byte)",
+                        "same_results": bool(np.array_equal(hi, di[:nh].cpu().numpy()) and np.array_equal(hd, dd[:nh].cpu().numpy()))}
+    import oracle as O
+    if O.ref_linscan_path() is not None:
+        nr = min(nh, 256)
+        t0 = time.perf_counter()
+        rd, ri = O.ref_linscan(codes_h, Q_h[:nr], K_h, N_h, m, H, knn)
+        tr = time.perf_counter() - t0
+        res["reference_scan"] = {"value": nr / tr, "unit": "queries/s", "queries": nr, "kind": "reference (oracle/_ref: the reference's own linscan_aqd_pairwise_byte.cpp, OpenMP)",
+                                 "same_results": bool(np.array_equal(ri, di[:nr].cpu().numpy()) and np.array_equal(rd, dd[:nr].cpu().numpy()))}
+    return res
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
@@ -510,6 +572,9 @@ def main():
                                    "note": "north_star quotes its >= 50x target at 4 ILS iterations; same workload otherwise"}
         if not args.no_workloads and n * d * 4 <= 2 << 30:
             out["workloads"] = workloads_leg(lsq, eng, dX, dB0, dK, n, d, m, args, goff)
+            step()                                                       # dBs again holds the timed workload's codes
+            torch.cuda.synchronize()
+            out["search"] = search_leg(lsq, eng, dK, dBs[0].contiguous(), n, d, m)
         if args.multi_leg:
             devs = list(range(ndev)) if ndev > 1 else [0, 0]
             Xh, Kh = dX.cpu().numpy(), dK.cpu().numpy()

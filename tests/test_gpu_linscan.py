@@ -54,6 +54,17 @@ def test_thresholded_candidate_lists(lsq, oracle, n, nq, d, m, knn, ties):
     assert st["candidates"] < 0.25 * n * nq and st["candidates"] >= knn * nq, st      # a small part of the distances was ever written
 
 
+def test_reference_default_knn_and_query_batches(lsq, oracle):
+    """Linscan.jl's default k = 10000 on a 300 000-code database (thresholded road with long lists), and more queries than one batch of the
+    exhaustive road holds (2^28 / n per batch)"""
+    rng = np.random.default_rng(21)
+    codes, Q, K, dbnorms = _case(rng, 300_000, 6, 16, 8)
+    st = _check(lsq, oracle, codes, Q, K, dbnorms, 8, 10_000, expect={"exhaustive": 0, "fallback_queries": 0})
+    assert st["list_capacity"] < 100_000, st
+    codes, Q, K, dbnorms = _case(rng, 60_000, 4500, 8, 4)
+    _check(lsq, oracle, codes, Q, K, dbnorms, 4, 5, expect={"exhaustive": 1, "batches": 2})
+
+
 def test_short_lists_fall_back(lsq, oracle):
     """threshold = the sample's MINIMUM (option linscan_rank = 1): every list is far too short -> every query is redone exhaustively"""
     rng = np.random.default_rng(11)

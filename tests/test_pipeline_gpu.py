@@ -47,6 +47,9 @@ def test_demo_flow_on_synthetic_data(lsq):
     db_norms = np.asarray(cbnorms, dtype=np.float32)[dbnormsB.astype(np.int64) - 1]
     dists, idx = lsq.linscan_lsq((B_base - 1).astype(np.uint8), x_query, C, db_norms, np.eye(d, dtype=np.float32), knn)
     assert idx.shape == (knn, nq) and idx.min() >= 1 and idx.max() <= nbase
+    with lsq.Engine(0) as eng:                                              # the same search on the device: identical neighbours and distances
+        dists_d, idx_d = lsq.linscan_lsq((B_base - 1).astype(np.uint8), x_query, C, db_norms, np.eye(d, dtype=np.float32), knn, engine=eng)
+    assert np.array_equal(idx_d, idx) and np.array_equal(dists_d, dists)
     d2 = ((x_base[:, :, None] - x_query[:, None, :]) ** 2).sum(0)          # (nbase, nq) exact
     gt = d2.argmin(0) + 1
     rec = lsq.eval_recall(gt.astype(np.uint32), idx.astype(np.uint32), knn)

@@ -60,7 +60,15 @@ def main():
     B_base = Bs[-1]
     print("Encoded %d base vectors in %.3f s (%.0f vectors/s, host buffers); error in base is %e" % (x_base.shape[1], dt, x_base.shape[1] / dt, objs[-1]))
     db_norms = np.asarray(cbnorms, dtype=np.float32)[lsq.quantize_norms(B_base, C, cbnorms).astype(np.int64) - 1]
-    dists, idx = lsq.linscan_lsq((B_base - 1).astype(np.uint8), x_query, C, db_norms, np.eye(d, dtype=np.float32), knn)
+    t0 = time.perf_counter()
+    with lsq.Engine(0) as eng:                                              # the ADC scan on the device (lsq_linscan) ...
+        dists, idx = lsq.linscan_lsq((B_base - 1).astype(np.uint8), x_query, C, db_norms, np.eye(d, dtype=np.float32), knn, engine=eng)
+    t_dev = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    dists_h, idx_h = lsq.linscan_lsq((B_base - 1).astype(np.uint8), x_query, C, db_norms, np.eye(d, dtype=np.float32), knn)   # ... and on the host cores
+    t_host = time.perf_counter() - t0
+    assert np.array_equal(idx, idx_h) and np.array_equal(dists, dists_h), "device and host scans disagree"
+    print("Searched %d queries: device %.3f s (host buffers, incl. copies), host %.3f s; identical results" % (x_query.shape[1], t_dev, t_host))
     rec = lsq.eval_recall(gt, idx.astype(np.uint32), knn, True)
     print("%s: recall@1 = %.4f, recall@%d = %.4f" % (name, rec[0], knn, rec[knn - 1]))
 

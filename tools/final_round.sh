@@ -26,6 +26,11 @@ LSQ_SB_SCHEDULE=6 python tools/sweep_breakdown.py "$O/sb6" > "$O/sb6.log" 2>&1 &
 { echo "== one launch per node update (phases of block 0)"; python tools/walkq_phases.py 1000000 1 0 2>&1 | tail -66;
   echo "== production schedule (one launch per ILS iteration): active count : microseconds per node update of block 0"; python tools/walkq_phases.py 1000000 0 160 2>&1 | tail -4;
   echo "== 125 000 vectors, production schedule"; python tools/walkq_phases.py 125000 0 160 2>&1 | tail -4; } > "$O/${TAG}_walkq_phases.txt"
+# the device ADC scan: SIFT1M-shaped search at m = 8 / 16 and three neighbour counts, then its kernel times
+{ python tools/linscan_bench.py 1000000 10000 128 8 1000; python tools/linscan_bench.py 1000000 10000 128 8 100; python tools/linscan_bench.py 1000000 10000 128 8 1;
+  python tools/linscan_bench.py 1000000 10000 128 16 1000; python tools/linscan_bench.py 1000000 10000 128 8 10000; python tools/linscan_bench.py 1000000 1000 960 8 1000; } > "$O/${TAG}_linscan.jsonl" 2> "$O/linscan.err"
+( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$O/linscan_stats" -o k --output-format csv -- python "$R/tools/linscan_bench.py" > "$O/linscan_stats.log" 2>&1 )
+cp "$(find "$O/linscan_stats" -name '*kernel_stats.csv' | head -1)" "$O/${TAG}_linscan_kernel_stats.csv" 2>/dev/null
 [ -x tools/bin/ubench_lds ] && tools/bin/ubench_lds > "$O/ubench_lds_${TAG}.txt" 2>&1
 find "$O" -name "*.csv" -size +4M -delete
 ls -la "$O"
