@@ -30,6 +30,7 @@
 #include "lsq_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -201,22 +202,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         float *__restrict__ Dl = (Q16 == 2) ? nullptr : D + coff + (rbase + lrow) * rstride;
         uint16_t *__restrict__ ql = qtile + (wy * 64 + 4 * lhi) * QLD + wx * 64 + tj * 32 + l31;
         const float *__restrict__ sgl = sgs + wy * 64 + 4 * lhi;
+        f32x4 sg4 = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ro = ti * 32 + (r & 3) + 8 * (r >> 2);            // compile-time
+                if ((r & 3) == 0 && Q16 != 0) sg4 = *reinterpret_cast<const f32x4 *>(sgl + ro);      // the shifts of rows ro .. ro + 3: one 16-byte LDS read
+                const float sg = (r & 3) == 0 ? sg4.x : ((r & 3) == 1 ? sg4.y : ((r & 3) == 2 ? sg4.z : sg4.w));
                 if (full || lrow + ro < M) {
                     float v = acc[ti][tj][r];
                     if (addv) v = v + add;           // one rounded add (utils.jl:112-118)
                     if (Q16 == 2) {
-                        const float w = v + sgl[ro];
+                        const float w = v + sg;
                         vmin = fminf(vmin, w); vmax = fmaxf(vmax, w);
                         continue;
                     }
                     Dl[(int64_t)ro * rstride] = v;
                     if (q16) {
-                        const float qf = rintf((v - sgl[ro]) * qinv);
+                        const float qf = rintf((v - sg) * qinv);
                         const float qc = __builtin_amdgcn_fmed3f(qf, 0.0f, qhi);       // clamp to the level range (NaN -> 0)
                         if (!(qf == qc)) {                                               // outside [0, hiq] or NaN: flag the (vector, node) pair
                             const int64_t row = lrow + ro;
