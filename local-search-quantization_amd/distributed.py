@@ -87,3 +87,66 @@ def encode_sharded(X_shard, B0_shard, K, m, ilsiters, icmiter, npert, randord, s
     else:
         gathered = codes
     return codes, objs, gstats, gathered
+
+
+# ---- the search step, sharded the same way ---------------------------------------------------------------------------------------------
+def _hip_shard_scanner(device_index):
+    eng = _engine.Engine(device_index)
+
+    def run(codes, Q, K, dbnorms, m, knn):
+        return eng.linscan_dev(codes, Q, K, dbnorms, m, knn)
+
+    run.engine = eng
+    return run
+
+
+def _pair_keys(dists, ids):
+    """(dist, id) pairs -> int64 keys whose order is the pairs' lexicographic order (std::pair<float,int>'s, the reference's partial_sort order,
+    linscan_aqd_pairwise_byte.cpp:84): order-preserving float bits << 31 | id.  NaN distances sort last."""
+    import torch
+    bits = dists.contiguous().view(torch.int32).to(torch.int64)
+    u = bits & 0xFFFFFFFF
+    k = torch.where(bits < 0, u ^ 0xFFFFFFFF, u ^ 0x80000000)
+    k = torch.where(torch.isnan(dists), torch.full_like(k, 0xFFFFFFFF), k)
+    return (k << 31) | ids.to(torch.int64)
+
+
+def search_sharded(codes_shard, dbnorms_shard, Q, K, m, knn, n_total, shard_start, group=None, shard_scanner=None):
+    """ADC linear scan (src/linscan/Linscan.jl:46-73) over a database sharded like the encode: rank r holds the codes and norms of
+    splitarray(1:n, world)[r].  Every rank scans its share for its own knn nearest (fewer if the share is smaller), ids are made global
+    (1-based, + shard_start), ONE all-gather carries the world x knn candidates per query and every rank merges them by (distance, id) --
+    the result is what one scan of the whole database returns, ties included.  Q and K need to be valid on rank 0 only (broadcast in place).
+    -> dists (nq, knn) float32 ascending, ids (nq, knn) int32, on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if knn > n_total:
+        raise ValueError("knn = %d exceeds the database size %d" % (knn, n_total))
+    if world > 1:
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast(K, src=src, group=group)
+        dist.broadcast(Q, src=src, group=group)
+    if shard_scanner is None:
+        if not torch.cuda.is_available():
+            raise RuntimeError("no GPU visible: the sharded search has no CPU fallback")
+        shard_scanner = _hip_shard_scanner(torch.cuda.current_device())
+    n_loc = int(codes_shard.shape[0])
+    k_loc = min(knn, n_loc)
+    nq = int(Q.shape[0])
+    INF, NOID = float("inf"), 2 ** 31 - 1
+    d_pad = torch.full((nq, knn), INF, dtype=torch.float32, device=Q.device)
+    i_pad = torch.full((nq, knn), NOID, dtype=torch.int32, device=Q.device)
+    if k_loc > 0 and nq > 0:
+        d_loc, i_loc = shard_scanner(codes_shard, Q, K, dbnorms_shard, m, k_loc)
+        d_pad[:, :k_loc] = torch.as_tensor(d_loc).to(Q.device)
+        i_pad[:, :k_loc] = torch.as_tensor(i_loc).to(Q.device) + int(shard_start)
+    if world == 1:
+        return d_pad, i_pad
+    d_all = [torch.empty_like(d_pad) for _ in range(world)]
+    i_all = [torch.empty_like(i_pad) for _ in range(world)]
+    dist.all_gather(d_all, d_pad, group=group)
+    dist.all_gather(i_all, i_pad, group=group)
+    d_cat, i_cat = torch.cat(d_all, dim=1), torch.cat(i_all, dim=1)
+    order = torch.argsort(_pair_keys(d_cat, i_cat), dim=1)[:, :knn]
+    return torch.gather(d_cat, 1, order), torch.gather(i_cat, 1, order)

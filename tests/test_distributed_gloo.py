@@ -89,3 +89,79 @@ def test_product_shard_encoder_refuses_cpu(lsq):
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         lsq.distributed.encode_sharded(torch.zeros(4, 8), torch.zeros(4, 2, dtype=torch.uint8), torch.zeros(512, 8), 2, [1], 1, 1,
                                        True, 0, n_total=4, shard_start=0)
+
+
+# ---- the search step sharded the same way (database partitions, one all-gather of the per-rank nearest lists) ----------------------------
+def _host_shard_scanner(codes, Q, K, dbnorms, m, knn):
+    """this library's HOST scan as the injected per-shard scanner (the product default is the device scan and refuses to run without a GPU)"""
+    import importlib
+    lsq = importlib.import_module("local-search-quantization_amd")
+    L = lsq._lib.load()
+    c, q, k, nrm = (np.ascontiguousarray(t.numpy()) for t in (codes, Q, K, dbnorms))
+    dists = np.zeros((q.shape[0], knn), np.float32)
+    ids = np.zeros((q.shape[0], knn), np.int32)
+    lsq._lib.check(L.lsq_linscan_aqd_query_extra_byte(dists.ctypes.data, ids.ctypes.data, c.ctypes.data, q.ctypes.data, k.ctypes.data, nrm.ctypes.data,
+                                                      q.shape[0], c.shape[0], m, H, q.shape[1], knn, 2))
+    return torch.from_numpy(dists), torch.from_numpy(ids)
+
+
+def _search_case(n):
+    rng = np.random.default_rng(n)
+    d, m, nq = 16, 4, 9
+    K = (rng.standard_normal((m * H, d)) * 0.5).astype(np.float32)
+    codes = rng.integers(0, H, size=(n, m), dtype=np.uint8)
+    codes[n // 2:] = codes[: n - n // 2]                 # duplicated entries: exact ties ACROSS the two shards, ordered by global id
+    Q = rng.standard_normal((nq, d)).astype(np.float32)
+    recon = sum(K[j * H + codes[:, j].astype(np.int64)] for j in range(m))
+    dbnorms = (recon.astype(np.float64) ** 2).sum(1).astype(np.float32)
+    return codes, Q, K, dbnorms, m
+
+
+def _search_worker(rank, world, port, n, knn, q):
+    sys.path.insert(0, ROOT)
+    import importlib
+    lsq = importlib.import_module("local-search-quantization_amd")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        codes, Q, K, dbnorms, m = _search_case(n)
+        s, e = lsq.distributed.shard_range(n, world, rank)
+        Kt = torch.from_numpy(K.copy()) if rank == 0 else torch.zeros_like(torch.from_numpy(K))      # only rank 0 has codebooks and queries
+        Qt = torch.from_numpy(Q.copy()) if rank == 0 else torch.zeros_like(torch.from_numpy(Q))
+        dd, ii = lsq.distributed.search_sharded(torch.from_numpy(codes[s:e].copy()), torch.from_numpy(dbnorms[s:e].copy()), Qt, Kt, m, knn,
+                                                n_total=n, shard_start=s, shard_scanner=_host_shard_scanner)
+        q.put((rank, dd.numpy(), ii.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,knn", [(301, 40), (64, 64), (50, 30)])
+def test_two_rank_sharded_search_equals_one_scan(lsq, n, knn):
+    """knn = 64 = n: every shard is SMALLER than knn (padded lists); knn = 30 > the 25-entry shards likewise"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_search_worker, args=(r, world, port, n, knn, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r = q.get(timeout=180)
+        res[r[0]] = r
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    codes, Q, K, dbnorms, m = _search_case(n)
+    dref, iref = _host_shard_scanner(*(torch.from_numpy(a) for a in (codes, Q, K, dbnorms)), m, knn)
+    for r in (0, 1):
+        assert np.array_equal(res[r][2], iref.numpy()) and np.array_equal(res[r][1], dref.numpy())
+
+
+def test_product_shard_scanner_refuses_cpu(lsq):
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        lsq.distributed.search_sharded(torch.zeros(4, 2, dtype=torch.uint8), torch.zeros(4), torch.zeros(1, 8), torch.zeros(512, 8), 2, 1,
+                                       n_total=4, shard_start=0)

@@ -144,3 +144,17 @@ def test_bad_arguments(lsq):
             eng.linscan(z, np.zeros((1, 3), np.float32), np.zeros((2 * 16, 3), np.float32), np.zeros(4, np.float32), 2, 1, h=16)   # h != 256
         d, i = eng.linscan(z, np.zeros((0, 3), np.float32), np.zeros((2 * H, 3), np.float32), np.zeros(4, np.float32), 2, 1)   # no queries
         assert d.shape == (0, 1) and i.shape == (0, 1)
+
+
+def test_sharded_search_default_scanner_is_the_device_scan(lsq, oracle):
+    """distributed.search_sharded with its product default (the device scan) in a one-rank world; the two-rank merge runs on CPU under gloo
+    (tests/test_distributed_gloo.py)"""
+    import torch
+    rng = np.random.default_rng(31)
+    n, nq, d, m, knn = 90_000, 11, 16, 8, 77
+    codes, Q, K, dbnorms = _case(rng, n, nq, d, m, ties=True)
+    dref, iref = _reference(lsq, oracle, codes, Q, K, dbnorms, m, knn)
+    dev = torch.device("cuda:0")
+    dd, ii = lsq.distributed.search_sharded(torch.from_numpy(codes).to(dev), torch.from_numpy(dbnorms).to(dev), torch.from_numpy(Q).to(dev),
+                                            torch.from_numpy(K).to(dev), m, knn, n_total=n, shard_start=0)
+    assert np.array_equal(ii.cpu().numpy(), iref) and np.array_equal(dd.cpu().numpy(), dref)
