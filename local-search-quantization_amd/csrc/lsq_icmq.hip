@@ -131,6 +131,30 @@ __global__ __launch_bounds__(256) void unary_shift_kernel(const float *__restric
         const int64_t i = base + (lane >> 4);
         const bool live = i < n;
         const float *x = X + (live ? i : 0) * (int64_t)d;
+        if (vec && d <= 256) {                                      // the vector stays in registers (16 floats per lane) while the m means pass by (L1)
+            f32x4 xr[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                xr[t] = 4 * lp + 64 * t < d ? *reinterpret_cast<const f32x4 *>(x + 4 * lp + 64 * t) : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            for (int j = 0; j < m; ++j) {
+                const float *r = R + (int64_t)j * d + 4 * lp;
+                float acc = 0.0f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (4 * lp + 64 * t < d) {
+                        const f32x4 rv = *reinterpret_cast<const f32x4 *>(r + 64 * t);
+                        acc += xr[t].x * rv.x + xr[t].y * rv.y + xr[t].z * rv.z + xr[t].w * rv.w;
+                    }
+                acc = acc + dpp_self<DPP_XOR1, 0xf>(acc);
+                acc = acc + dpp_self<DPP_XOR2, 0xf>(acc);
+                acc = acc + dpp_self<DPP_HALF_MIRROR, 0xf>(acc);
+                acc = acc + dpp_self<DPP_MIRROR, 0xf>(acc);
+                const float sg = 2.0f * acc;
+                if (live && lp == 0) sigma[i * m + j] = sg;
+                if (live) amax = fmaxf(amax, fabsf(sg));
+            }
+            continue;
+        }
         for (int j = 0; j < m; ++j) {
             const float *r = R + (int64_t)j * d;
             float acc = 0.0f;
