@@ -158,3 +158,18 @@ def test_sharded_search_default_scanner_is_the_device_scan(lsq, oracle):
     dd, ii = lsq.distributed.search_sharded(torch.from_numpy(codes).to(dev), torch.from_numpy(dbnorms).to(dev), torch.from_numpy(Q).to(dev),
                                             torch.from_numpy(K).to(dev), m, knn, n_total=n, shard_start=0)
     assert np.array_equal(ii.cpu().numpy(), iref) and np.array_equal(dd.cpu().numpy(), dref)
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_random_shapes(lsq, oracle, case):
+    """seeded random shapes over both roads: any m in 1..16 (dword and byte code reads), ragged query tiles, code ranges that do not divide, nn from 1 to n"""
+    rng = np.random.default_rng(1000 + case)
+    m = int(rng.integers(1, 17))
+    d = int(rng.choice([1, 3, 8, 17, 32, 100, 128]))
+    big = case % 2 == 1
+    n = int(rng.integers(70_000, 260_000)) if big else int(rng.integers(1, 9_000))
+    nq = int(rng.integers(1, 70))
+    knn = int(min(n, rng.choice([1, 2, 10, 100, 777]) if big else rng.integers(1, n + 1)))
+    codes, Q, K, dbnorms = _case(rng, n, nq, d, m, ties=bool(case % 3 == 0))
+    st = _check(lsq, oracle, codes, Q, K, dbnorms, m, knn, expect={"queries": nq})
+    assert st["exhaustive"] == (0 if big else 1), (n, nq, d, m, knn, st)
