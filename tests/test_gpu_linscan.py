@@ -173,3 +173,19 @@ def test_random_shapes(lsq, oracle, case):
     codes, Q, K, dbnorms = _case(rng, n, nq, d, m, ties=bool(case % 3 == 0))
     st = _check(lsq, oracle, codes, Q, K, dbnorms, m, knn, expect={"queries": nq})
     assert st["exhaustive"] == (0 if big else 1), (n, nq, d, m, knn, st)
+
+
+def test_sift1m_shape_every_query(lsq):
+    """BASELINE configs[1]'s search at full size -- 10^6 codes, 10^4 queries, 1000 neighbours each -- against this library's host scan (pinned to the
+    reference build in tests/test_linscan.py) on EVERY query, twice (the candidate lists are filled by atomics in a different order every time;
+    the answer must not notice)"""
+    rng = np.random.default_rng(17)
+    n, nq, d, m, knn = 1_000_000, 10_000, 128, 8, 1000
+    codes, Q, K, dbnorms = _case(rng, n, nq, d, m)
+    dref, iref = _ours(lsq, codes, Q, K, dbnorms, m, knn)
+    with lsq.Engine(0) as eng:
+        for _ in range(2):
+            dists, ids = eng.linscan(codes, Q, K, dbnorms, m, knn)
+            assert np.array_equal(ids, iref) and np.array_equal(dists.view(np.uint32), dref.view(np.uint32))
+        st = eng.linscan_stats()
+    assert st["fallback_queries"] == 0 and st["queries"] == 2 * nq, st
