@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define LSQ_VERSION 310
+#define LSQ_VERSION 320
 
 #if defined(__GNUC__)
 #define LSQ_API __attribute__((visibility("default")))
@@ -258,6 +258,16 @@ typedef struct lsq_linscan_stats {
     double lut_ms, sample_ms, scan_ms, select_ms;
 } lsq_linscan_stats;
 LSQ_API int lsq_get_linscan_stats(lsq_ctx *ctx, lsq_linscan_stats *out);
+
+/* quantize_norms(B, C, cbnorms) -> dbnormsB      src/utils.jl:6-31: per database vector the squared norm of its reconstruction
+ * (f32; codebooks, then dimensions, ascending) and the 1-based index of the nearest of the `ncb` (<= 256) scalar centroids, first minimum of
+ * (norm - cbnorms[j])^2 like findmin.  `dbnorms` (optional) receives cbnorms[index] -- what the scan consumes (demos/demo_lsq_gpu.jl:57-60);
+ * `norms` (optional) the unquantised norms (the input of the reference's norm k-means, src/lsq/LSQ.jl:80-84).  PARITY UNPINNED: the reference's
+ * norm loop is `@simd`; this is the sequential order.  The _dev variant takes device pointers and uint8 0-BASED codes [n][m], index output 0-based. */
+LSQ_API int lsq_quantize_norms(lsq_ctx *ctx, const int16_t *B, const float *K, const float *cbnorms, int ncb, int d, int64_t n, int m, int h,
+                               int16_t *idx_out, float *dbnorms, float *norms);
+LSQ_API int lsq_quantize_norms_dev(lsq_ctx *ctx, const uint8_t *d_codes, const float *d_K, const float *d_cbnorms, int ncb, int d, int64_t n,
+                                   int m, int h, uint8_t *d_idx_out, float *d_dbnorms, float *d_norms);
 
 /* update_codebooks(X, B, h) -> C      src/codebook_update.jl:52-86 (host code; north_star keeps it on the host).
  * K[t, :] = lsqr(sparsify_codes(B, h), X[t, :]) for every dimension t (LSQR of Paige & Saunders, Float32,

@@ -932,6 +932,37 @@ extern "C" int lsq_veccost(lsq_ctx *c, const float *X, const int16_t *B, const f
     return LSQ_OK;
 }
 
+extern "C" int lsq_quantize_norms(lsq_ctx *c, const int16_t *B, const float *K, const float *cbnorms, int ncb, int d, int64_t n, int m, int h,
+                                  int16_t *idx_out, float *dbnorms, float *norms) {
+    LSQ_TRY(use_device(c));
+    LSQ_TRY(check_shape("lsq_quantize_norms", d, n, m, h));
+    if (ncb < 1 || ncb > LSQ_H) { lsq_set_error("lsq_quantize_norms: ncb=%d must lie in 1..256", ncb); return LSQ_EINVAL; }
+    if (!K || !cbnorms || (n > 0 && !B)) { lsq_set_error("lsq_quantize_norms: null pointer"); return LSQ_EINVAL; }
+    if (n == 0) return LSQ_OK;
+    LSQ_TRY(upload_xk(c, nullptr, K, d, n, m));
+    LSQ_TRY(upload_codes(c, B, n, m, h, c->recCur));
+    LSQ_TRY(c->sF32.ensure(sizeof(float) * ((size_t)LSQ_H + 2 * (size_t)n)));
+    LSQ_TRY(c->sOut16.ensure(sizeof(int16_t) * (size_t)n));
+    float *dcb = c->sF32.as<float>(), *ddb = dcb + LSQ_H, *dnr = ddb + n;
+    LSQ_HIP(hipMemcpyAsync(dcb, cbnorms, sizeof(float) * (size_t)ncb, hipMemcpyHostToDevice, c->stream));
+    LSQ_TRY(lsq_launch_quantize_norms(c->stream, c->recCur.as<uint8_t>(), lsq_code_stride(m), c->sK.as<float>(), dcb, ncb, n, d, m, nullptr,
+                                      c->sOut16.as<int16_t>(), ddb, dnr));
+    if (idx_out) LSQ_HIP(hipMemcpyAsync(idx_out, c->sOut16.p, sizeof(int16_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (dbnorms) LSQ_HIP(hipMemcpyAsync(dbnorms, ddb, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (norms) LSQ_HIP(hipMemcpyAsync(norms, dnr, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    LSQ_HIP(hipStreamSynchronize(c->stream));
+    return LSQ_OK;
+}
+
+extern "C" int lsq_quantize_norms_dev(lsq_ctx *c, const uint8_t *d_codes, const float *d_K, const float *d_cbnorms, int ncb, int d, int64_t n, int m,
+                                      int h, uint8_t *d_idx_out, float *d_dbnorms, float *d_norms) {
+    LSQ_TRY(use_device(c));
+    LSQ_TRY(check_shape("lsq_quantize_norms_dev", d, n, m, h));
+    if (ncb < 1 || ncb > LSQ_H) { lsq_set_error("lsq_quantize_norms_dev: ncb=%d must lie in 1..256", ncb); return LSQ_EINVAL; }
+    if (!d_K || !d_cbnorms || (n > 0 && !d_codes)) { lsq_set_error("lsq_quantize_norms_dev: null pointer"); return LSQ_EINVAL; }
+    return lsq_launch_quantize_norms(c->stream, d_codes, m, d_K, d_cbnorms, ncb, n, d, m, d_idx_out, nullptr, d_dbnorms, d_norms);
+}
+
 extern "C" int lsq_qerror(lsq_ctx *c, const float *X, const int16_t *B, const float *K, int d, int64_t n, int m, int h, double *out) {
     LSQ_TRY(use_device(c));
     LSQ_TRY(check_shape("lsq_qerror", d, n, m, h));

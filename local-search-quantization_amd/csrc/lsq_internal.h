@@ -193,3 +193,7 @@ int lsq_adc_search(hipStream_t s, lsq_adc_state **st, float *dists, int *idx, co
 int lsq_adc_search_host(hipStream_t s, lsq_adc_state **st, float *dists, int *idx, const unsigned char *codes, const float *Q, const float *K,
                         const float *dbnorms, int nq, int n, int m, int d, int nn, int force_exhaustive, int rank_override, lsq_linscan_stats *stats,
                         int timed);
+
+// ---- quantize_norms on the device (lsq_norms.hip): codes [n][stride] u8 0-based; any of the four outputs may be null ----------------------
+int lsq_launch_quantize_norms(hipStream_t s, const uint8_t *codes, int stride, const float *K, const float *cb, int ncb, int64_t n, int d, int m,
+                              uint8_t *idx0, int16_t *idx1, float *dbnorms, float *norms);

@@ -168,6 +168,36 @@ class Engine:
                                                 dnorms.data_ptr(), nq, n, m, h, d, int(k)))
         return dists, ids
 
+    def quantize_norms(self, B, K, cbnorms, m, h=H):
+        """B (n,m) int16 1-based, K (m*h,d), cbnorms (<= 256,): host arrays.
+        -> idx (n,) int16 1-based index of the nearest norm centroid, dbnorms (n,) = cbnorms[idx-1], norms (n,) unquantised   [lsq_quantize_norms]"""
+        B, K, cb = _np(B, np.int16), _np(K, np.float32), _np(cbnorms, np.float32).reshape(-1)
+        n, d = B.shape[0], K.shape[1]
+        if B.shape != (n, m) or K.shape != (m * h, d):
+            raise ValueError("shape mismatch: B %s K %s m=%d h=%d" % (B.shape, K.shape, m, h))
+        idx = np.zeros(n, dtype=np.int16)
+        dbn = np.zeros(n, dtype=np.float32)
+        nrm = np.zeros(n, dtype=np.float32)
+        self._check(self._L.lsq_quantize_norms(self._h, B.ctypes.data, K.ctypes.data, cb.ctypes.data, cb.shape[0], d, n, m, h,
+                                               idx.ctypes.data, dbn.ctypes.data, nrm.ctypes.data))
+        return idx, dbn, nrm
+
+    def quantize_norms_dev(self, dcodes, dK, dcb, m, h=H):
+        """device tensors: codes (n,m) uint8 0-based, K (m*h,d) f32, cbnorms (<= 256,) f32 -> idx (n,) uint8 0-BASED, dbnorms (n,), norms (n,)   [lsq_quantize_norms_dev]"""
+        import torch
+        assert dcodes.is_cuda and dK.is_cuda and dcb.is_cuda and dcodes.dtype == torch.uint8 and dK.dtype == torch.float32 and dcb.dtype == torch.float32
+        assert dcodes.is_contiguous() and dK.is_contiguous() and dcb.is_contiguous()
+        n, d = dcodes.shape[0], dK.shape[1]
+        if dcodes.shape != (n, m) or dK.shape != (m * h, d):
+            raise ValueError("shape mismatch")
+        idx = torch.empty(n, dtype=torch.uint8, device=dK.device)
+        dbn = torch.empty(n, dtype=torch.float32, device=dK.device)
+        nrm = torch.empty(n, dtype=torch.float32, device=dK.device)
+        with self._on_torch_stream():
+            self._check(self._L.lsq_quantize_norms_dev(self._h, dcodes.data_ptr(), dK.data_ptr(), dcb.data_ptr(), int(dcb.numel()), d, n, m, h,
+                                                       idx.data_ptr(), dbn.data_ptr(), nrm.data_ptr()))
+        return idx, dbn, nrm
+
     def linscan_stats(self):
         t = _lib.LinscanStats()
         self._check(self._L.lsq_get_linscan_stats(self._h, C.byref(t)))

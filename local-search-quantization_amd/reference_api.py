@@ -216,9 +216,13 @@ def reconstruct(B, C):
     return CB
 
 
-def quantize_norms(B, C, cbnorms):
+def quantize_norms(B, C, cbnorms, *, engine=None):
     """src/utils.jl:6-31: squared norm of every reconstruction (f32, dimensions ascending), then the index
-    (1-based Int16) of the nearest scalar centroid in `cbnorms`; ties -> lowest index (findmin)."""
+    (1-based Int16) of the nearest scalar centroid in `cbnorms`; ties -> lowest index (findmin).
+    engine=<Engine>: the device kernel (lsq_quantize_norms) -- the same numbers bit for bit."""
+    if engine is not None:
+        idx, _, _ = engine.quantize_norms(np.ascontiguousarray(np.asarray(B, dtype=np.int16).T), _K_of(C), cbnorms, len(C), h=np.asarray(C[0]).shape[1])
+        return idx
     CB = reconstruct(B, C)
     norms = np.zeros(CB.shape[1], dtype=np.float32)
     for j in range(CB.shape[0]):                      # sequential f32 accumulation, j ascending

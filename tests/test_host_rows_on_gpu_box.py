@@ -7,6 +7,7 @@ box's host cores and through the same C-ABI library the GPU tests load:
   f-2  quantize_norms / reconstruct (src/utils.jl:6-31, :203-223) and the *vecs readers (src/read/*.jl);
   f-3  lsq_update_codebooks == scipy's LSQR on the reference's sparse system (src/codebook_update.jl:52-86).
 """
+import numpy as np
 import pytest
 
 import test_linscan as TL
@@ -36,3 +37,31 @@ def test_f2_quantize_norms_reconstruct_and_readers(lsq, tmp_path):
 def test_f3_update_codebooks_matches_scipy_lsqr(lsq):
     TP.test_update_codebooks_matches_scipy_lsqr(lsq)
     TP.test_update_codebooks_training_scale_matches_scipy(lsq)
+
+
+# ---- row 8(f)-2 on the device: lsq_quantize_norms / lsq_quantize_norms_dev against the Python mirror of src/utils.jl:6-31 ------------------
+@pytest.mark.parametrize("d,n,m,ncb", [(16, 600, 4, 256), (128, 20_000, 8, 256), (30, 999, 7, 100), (960, 300, 16, 256), (5, 64, 1, 2)])
+def test_quantize_norms_device_equals_the_mirror(lsq, d, n, m, ncb):
+    import torch
+    H = 256
+    rng = np.random.default_rng(d + n)
+    C = [rng.standard_normal((d, H)).astype(np.float32) for _ in range(m)]
+    B = rng.integers(1, H + 1, size=(m, n)).astype(np.int16)
+    CB = lsq.reconstruct(B, C)
+    norms = np.zeros(n, dtype=np.float32)
+    for t in range(d):                                              # the mirror's own order: dimensions ascending, square rounded before the add
+        norms += CB[t] * CB[t]
+    cb = np.sort(rng.choice(norms, size=ncb, replace=False)).astype(np.float32)
+    if ncb > 4:
+        cb[3] = cb[2]                                               # duplicated centroid: the first index wins (findmin)
+    ref = lsq.quantize_norms(B, C, cb)
+    K = np.ascontiguousarray(np.concatenate([c.T for c in C], axis=0))
+    with lsq.Engine(0) as eng:
+        idx, dbn, nrm = eng.quantize_norms(np.ascontiguousarray(B.T), K, cb, m)
+        assert np.array_equal(nrm.view(np.uint32), norms.view(np.uint32)), "norms differ from the sequential f32 order"
+        assert np.array_equal(idx, ref) and np.array_equal(dbn, cb[ref.astype(np.int64) - 1])
+        assert np.array_equal(lsq.quantize_norms(B, C, cb, engine=eng), ref)
+        dev = torch.device("cuda:0")
+        di, dd, dn = eng.quantize_norms_dev(torch.from_numpy(np.ascontiguousarray((B.T - 1).astype(np.uint8))).to(dev), torch.from_numpy(K).to(dev), torch.from_numpy(cb).to(dev), m)
+        torch.cuda.synchronize()
+        assert np.array_equal(di.cpu().numpy().astype(np.int16) + 1, ref) and np.array_equal(dd.cpu().numpy(), dbn) and np.array_equal(dn.cpu().numpy(), nrm)

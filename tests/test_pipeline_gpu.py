@@ -44,6 +44,8 @@ def test_demo_flow_on_synthetic_data(lsq):
 
     # === norms, search, recall === (:57-76)
     dbnormsB = lsq.quantize_norms(B_base, C, cbnorms)
+    with lsq.Engine(0) as eng:                                              # the same on the device
+        assert np.array_equal(lsq.quantize_norms(B_base, C, cbnorms, engine=eng), dbnormsB)
     db_norms = np.asarray(cbnorms, dtype=np.float32)[dbnormsB.astype(np.int64) - 1]
     dists, idx = lsq.linscan_lsq((B_base - 1).astype(np.uint8), x_query, C, db_norms, np.eye(d, dtype=np.float32), knn)
     assert idx.shape == (knn, nq) and idx.min() >= 1 and idx.max() <= nbase

@@ -59,7 +59,10 @@ def main():
     dt = time.perf_counter() - t0
     B_base = Bs[-1]
     print("Encoded %d base vectors in %.3f s (%.0f vectors/s, host buffers); error in base is %e" % (x_base.shape[1], dt, x_base.shape[1] / dt, objs[-1]))
-    db_norms = np.asarray(cbnorms, dtype=np.float32)[lsq.quantize_norms(B_base, C, cbnorms).astype(np.int64) - 1]
+    with lsq.Engine(0) as eng:                                              # norm quantisation on the device (lsq_quantize_norms), checked against the mirror
+        nidx = lsq.quantize_norms(B_base, C, cbnorms, engine=eng)
+    assert np.array_equal(nidx, lsq.quantize_norms(B_base, C, cbnorms)), "device and host norm quantisation disagree"
+    db_norms = np.asarray(cbnorms, dtype=np.float32)[nidx.astype(np.int64) - 1]
     t0 = time.perf_counter()
     with lsq.Engine(0) as eng:                                              # the ADC scan on the device (lsq_linscan) ...
         dists, idx = lsq.linscan_lsq((B_base - 1).astype(np.uint8), x_query, C, db_norms, np.eye(d, dtype=np.float32), knn, engine=eng)
