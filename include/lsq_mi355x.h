@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define LSQ_VERSION 320
+#define LSQ_VERSION 330
 
 #if defined(__GNUC__)
 #define LSQ_API __attribute__((visibility("default")))
@@ -275,6 +275,14 @@ LSQ_API int lsq_quantize_norms_dev(lsq_ctx *ctx, const uint8_t *d_codes, const f
  * reference neither vendors nor pins IterativeSolvers).  X d x n, B m x n Int16 1-based; K_out d x (m*h)
  * = hcat(C...) caller-allocated.  nthreads 0 = all cores (dimensions are independent). */
 LSQ_API int lsq_update_codebooks(const float *X, const int16_t *B, int d, int64_t n, int m, int h, int nthreads, float *K_out);
+
+/* The same update ON THE DEVICE (csrc/lsq_lsqr.hip): all d systems advanced together, the same LSQR restatement (Float32 recurrences, the long sums
+ * in double, IterativeSolvers' default stopping rules).  Agrees with lsq_update_codebooks to ~1e-6 relative (the order of the double additions
+ * differs), not bit for bit.  _gpu: host buffers, Julia layout as above (X d x n, B m x n Int16 1-based, K_out d x (m*h));  _dev: device buffers,
+ * codes [n][m] uint8 0-BASED.  h must be 256.  iterations (optional): LSQR iterations of the slowest dimension. */
+LSQ_API int lsq_update_codebooks_gpu(lsq_ctx *ctx, const float *X, const int16_t *B, int d, int64_t n, int m, int h, float *K_out, int *iterations);
+LSQ_API int lsq_update_codebooks_dev(lsq_ctx *ctx, const float *d_X, const uint8_t *d_codes, int d, int64_t n, int m, int h, float *d_K_out,
+                                     int *iterations);
 
 /* ---- (4) device-side generators used by the benchmark harness -----------------------------
  * X[i][t] = float(uniform integer 0..255) (SIFT-like);  codes uniform 0..h-1 (randinit);

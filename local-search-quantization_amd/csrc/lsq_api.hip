@@ -85,6 +85,7 @@ struct lsq_ctx {
     // the same shape is remembered instead (re-probed every 16th call)
     int64_t call_I = 0, call_q16_chunks = 0;
     int64_t sticky_n = -1; int sticky_d = 0, sticky_m = 0, sticky_bad = 0, sticky_count = 0;
+    lsq_lsqr_state *lsqr = nullptr;                    // device LSQR (lsq_lsqr.hip): work buffers, created on first use
     lsq_adc_state *adc = nullptr;                      // device ADC scan (lsq_adc.hip): buffers, created on first use
     lsq_linscan_stats adc_stats{};
     int adc_exhaustive = 0, adc_rank = 0;              // options "linscan_exhaustive", "linscan_rank": test hooks of the scan's selection
@@ -173,6 +174,7 @@ extern "C" int lsq_destroy(lsq_ctx *c) {
                       &c->sX, &c->sX2, &c->sK, &c->sB16, &c->sOut16, &c->sTight, &c->sF32};
     for (DevBuf *b : bufs) b->release();
     lsq_adc_free(c->adc);
+    lsq_lsqr_free(c->lsqr);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
@@ -961,6 +963,30 @@ extern "C" int lsq_quantize_norms_dev(lsq_ctx *c, const uint8_t *d_codes, const 
     if (ncb < 1 || ncb > LSQ_H) { lsq_set_error("lsq_quantize_norms_dev: ncb=%d must lie in 1..256", ncb); return LSQ_EINVAL; }
     if (!d_K || !d_cbnorms || (n > 0 && !d_codes)) { lsq_set_error("lsq_quantize_norms_dev: null pointer"); return LSQ_EINVAL; }
     return lsq_launch_quantize_norms(c->stream, d_codes, m, d_K, d_cbnorms, ncb, n, d, m, d_idx_out, nullptr, d_dbnorms, d_norms);
+}
+
+extern "C" int lsq_update_codebooks_dev(lsq_ctx *c, const float *d_X, const uint8_t *d_codes, int d, int64_t n, int m, int h, float *d_K_out,
+                                        int *iterations) {
+    LSQ_TRY(use_device(c));
+    LSQ_TRY(check_shape("lsq_update_codebooks_dev", d, n, m, h));
+    if (n < 1 || !d_X || !d_codes || !d_K_out) { lsq_set_error("lsq_update_codebooks_dev: bad arguments"); return LSQ_EINVAL; }
+    return lsq_lsqr_update_codebooks(c->stream, &c->lsqr, d_X, d_codes, d, n, m, d_K_out, iterations);
+}
+
+extern "C" int lsq_update_codebooks_gpu(lsq_ctx *c, const float *X, const int16_t *B, int d, int64_t n, int m, int h, float *K_out, int *iterations) {
+    LSQ_TRY(use_device(c));
+    LSQ_TRY(check_shape("lsq_update_codebooks_gpu", d, n, m, h));
+    if (n < 1 || !X || !B || !K_out) { lsq_set_error("lsq_update_codebooks_gpu: bad arguments"); return LSQ_EINVAL; }
+    LSQ_TRY(c->sX.ensure(sizeof(float) * (size_t)n * d));
+    LSQ_TRY(c->sK.ensure(sizeof(float) * (size_t)m * LSQ_H * d));
+    LSQ_HIP(hipMemcpyAsync(c->sX.p, X, sizeof(float) * (size_t)n * d, hipMemcpyHostToDevice, c->stream));
+    LSQ_TRY(upload_codes(c, B, n, m, h, c->recCur));                          // records of stride 8 / 16 -> tight [n][m] below
+    LSQ_TRY(c->sTight.ensure((size_t)n * m));
+    LSQ_TRY(lsq_launch_codes_compact(c->stream, c->recCur.as<uint8_t>(), n, m, c->sTight.as<uint8_t>()));
+    LSQ_TRY(lsq_lsqr_update_codebooks(c->stream, &c->lsqr, c->sX.as<float>(), c->sTight.as<uint8_t>(), d, n, m, c->sK.as<float>(), iterations));
+    LSQ_HIP(hipMemcpyAsync(K_out, c->sK.p, sizeof(float) * (size_t)m * LSQ_H * d, hipMemcpyDeviceToHost, c->stream));
+    LSQ_HIP(hipStreamSynchronize(c->stream));
+    return LSQ_OK;
 }
 
 extern "C" int lsq_qerror(lsq_ctx *c, const float *X, const int16_t *B, const float *K, int d, int64_t n, int m, int h, double *out) {

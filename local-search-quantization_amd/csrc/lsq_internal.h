@@ -197,3 +197,8 @@ int lsq_adc_search_host(hipStream_t s, lsq_adc_state **st, float *dists, int *id
 // ---- quantize_norms on the device (lsq_norms.hip): codes [n][stride] u8 0-based; any of the four outputs may be null ----------------------
 int lsq_launch_quantize_norms(hipStream_t s, const uint8_t *codes, int stride, const float *K, const float *cb, int ncb, int64_t n, int d, int m,
                               uint8_t *idx0, int16_t *idx1, float *dbnorms, float *norms);
+
+// ---- LSQR codebook update on the device (lsq_lsqr.hip) ---------------------------------------------------------------------------------------
+struct lsq_lsqr_state;
+void lsq_lsqr_free(lsq_lsqr_state *st);
+int lsq_lsqr_update_codebooks(hipStream_t s, lsq_lsqr_state **st, const float *dX, const uint8_t *dcodes, int d, int64_t n, int m, float *dK, int *iters_out);

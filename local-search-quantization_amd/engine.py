@@ -198,6 +198,30 @@ class Engine:
                                                        idx.data_ptr(), dbn.data_ptr(), nrm.data_ptr()))
         return idx, dbn, nrm
 
+    def update_codebooks(self, X, B, m, h=H):
+        """X (n,d) f32, B (n,m) int16 1-based: host arrays -> K (m*h,d) least-squares codebooks, LSQR iterations   [lsq_update_codebooks_gpu]"""
+        X, B = _np(X, np.float32), _np(B, np.int16)
+        n, d = X.shape
+        if B.shape != (n, m):
+            raise ValueError("shape mismatch: X %s B %s m=%d" % (X.shape, B.shape, m))
+        K = np.zeros((m * h, d), dtype=np.float32)
+        it = C.c_int(0)
+        self._check(self._L.lsq_update_codebooks_gpu(self._h, X.ctypes.data, B.ctypes.data, d, n, m, h, K.ctypes.data, C.byref(it)))
+        return K, int(it.value)
+
+    def update_codebooks_dev(self, dX, dcodes, m, h=H, out=None):
+        """device tensors: X (n,d) f32, codes (n,m) uint8 0-based -> K (m*h,d) f32 tensor, LSQR iterations   [lsq_update_codebooks_dev]"""
+        import torch
+        assert dX.is_cuda and dcodes.is_cuda and dX.dtype == torch.float32 and dcodes.dtype == torch.uint8 and dX.is_contiguous() and dcodes.is_contiguous()
+        n, d = dX.shape
+        if dcodes.shape != (n, m):
+            raise ValueError("shape mismatch")
+        dK = out if out is not None else torch.empty((m * h, d), dtype=torch.float32, device=dX.device)
+        it = C.c_int(0)
+        with self._on_torch_stream():
+            self._check(self._L.lsq_update_codebooks_dev(self._h, dX.data_ptr(), dcodes.data_ptr(), d, n, m, h, dK.data_ptr(), C.byref(it)))
+        return dK, int(it.value)
+
     def linscan_stats(self):
         t = _lib.LinscanStats()
         self._check(self._L.lsq_get_linscan_stats(self._h, C.byref(t)))

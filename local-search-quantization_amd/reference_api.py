@@ -154,20 +154,25 @@ def eval_recall(ids_gnd, ids_predicted, k, V=False):
     return rec
 
 
-def update_codebooks(X, B, h, V=False, codebook_upd_method="lsqr", *, nthreads=0):
-    """src/codebook_update.jl:52-86 -> list of m (d, h) codebooks minimising ||X - sum_j C_j[:, B_j]||^2 (LSQR)."""
+def update_codebooks(X, B, h, V=False, codebook_upd_method="lsqr", *, nthreads=0, engine=None):
+    """src/codebook_update.jl:52-86 -> list of m (d, h) codebooks minimising ||X - sum_j C_j[:, B_j]||^2 (LSQR).
+    engine=None: the host solver (std::thread workers over the dimensions, the reference's own division of labour);
+    engine=<Engine>: the device solver (lsq_update_codebooks_gpu: all dimensions at once) -- agrees to ~1e-6, not bit for bit."""
     from . import _lib
     if codebook_upd_method != "lsqr":
         raise ValueError("only the reference's default method 'lsqr' is provided")
     Xr, Br = _X_of(X), _B_of(B)
     n, d = Xr.shape
     m = Br.shape[1]
+    if engine is not None:
+        K, _ = engine.update_codebooks(Xr, Br, m, h=h)
+        return [np.ascontiguousarray(K[j * h:(j + 1) * h].T) for j in range(m)]
     K = np.zeros((m * h, d), dtype=np.float32)
     _lib.check(_lib.load().lsq_update_codebooks(Xr.ctypes.data, Br.ctypes.data, d, n, m, h, int(nthreads), K.ctypes.data))
     return [np.ascontiguousarray(K[j * h:(j + 1) * h].T) for j in range(m)]
 
 
-def train_lsq(X, m, h, R, B, C, niter, ilsiter, icmiter, randord, npert, V=False, *, seed=0, engine=None):
+def train_lsq(X, m, h, R, B, C, niter, ilsiter, icmiter, randord, npert, V=False, *, seed=0, engine=None, device_update=False):
     """src/lsq/LSQ.jl:10-88: alternate codebook update (host LSQR) and ILS/ICM encoding (GPU).
     -> (C, B, cbnorms, B_norms, obj).  The final norm codebook is the reference's plain k-means on the squared
     norms of the reconstructions (Clustering.kmeans there; a seeded Lloyd iteration here -- unpinned)."""
@@ -175,7 +180,8 @@ def train_lsq(X, m, h, R, B, C, niter, ilsiter, icmiter, randord, npert, V=False
     R = np.asarray(R, dtype=np.float32)
     d, n = X.shape
     RX = R.T @ X
-    C = update_codebooks(RX, B, h, V)
+    upd_engine = engine if device_update else None          # device_update: the LSQR codebook update on the device too (needs `engine`)
+    C = update_codebooks(RX, B, h, V, engine=upd_engine)
     C = [R @ Ci for Ci in C]
     it = 0
 
@@ -189,7 +195,7 @@ def train_lsq(X, m, h, R, B, C, niter, ilsiter, icmiter, randord, npert, V=False
         obj[iter_] = qerror(X, B, C, engine=engine)
         if V:
             print("%3d %e" % (iter_ + 1, obj[iter_]))
-        C = update_codebooks(X, B, h, V)
+        C = update_codebooks(X, B, h, V, engine=upd_engine)
         it += 1
         B = encode(B, it)
     CB = reconstruct(B, C)

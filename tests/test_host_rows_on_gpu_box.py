@@ -65,3 +65,53 @@ def test_quantize_norms_device_equals_the_mirror(lsq, d, n, m, ncb):
         di, dd, dn = eng.quantize_norms_dev(torch.from_numpy(np.ascontiguousarray((B.T - 1).astype(np.uint8))).to(dev), torch.from_numpy(K).to(dev), torch.from_numpy(cb).to(dev), m)
         torch.cuda.synchronize()
         assert np.array_equal(di.cpu().numpy().astype(np.int16) + 1, ref) and np.array_equal(dd.cpu().numpy(), dbn) and np.array_equal(dn.cpu().numpy(), nrm)
+
+
+# ---- row 8(f)-3 on the device: lsq_update_codebooks_gpu / _dev against the host solver and scipy -----------------------------------------
+@pytest.mark.parametrize("d,n,m,noise", [(12, 4000, 4, 0.01), (128, 20_000, 8, 0.05), (7, 999, 3, 0.0), (33, 120_000, 8, 0.05)])
+def test_update_codebooks_device_agrees_with_host_and_scipy(lsq, d, n, m, noise):
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    import torch
+    H = 256
+    rng = np.random.default_rng(d + n)
+    X, B = TP._problem(rng, d, n, m, noise=noise)                   # X (d, n), B (m, n): Julia shapes
+    C_host = lsq.update_codebooks(X, B, H, nthreads=8)
+    with lsq.Engine(0) as eng:
+        C_dev = lsq.update_codebooks(X, B, H, engine=eng)
+        dK, iters = eng.update_codebooks_dev(torch.from_numpy(np.ascontiguousarray(X.T)).cuda(),
+                                             torch.from_numpy(np.ascontiguousarray((B.T - 1).astype(np.uint8))).cuda(), m)
+        torch.cuda.synchronize()
+    Kh, Kd = np.concatenate(C_host, axis=1), np.concatenate(C_dev, axis=1)          # d x (m*h)
+    assert np.array_equal(dK.cpu().numpy().T, Kd) and 1 <= iters <= 200, iters
+    rows = np.tile(np.arange(n), m)
+    cols = np.concatenate([(B[j] - 1) + j * H for j in range(m)])
+    S = sp.csr_matrix((np.ones(n * m), (rows, cols)), shape=(n, m * H))
+    # S has an (m - 1)-dimensional null space (constant shifts between codebooks): compare what is determined -- the reconstruction
+    rec_h, rec_d = (S @ Kh.T).T, (S @ Kd.T).T
+    assert np.linalg.norm(rec_d - rec_h) <= 1e-5 * np.linalg.norm(rec_h), np.linalg.norm(rec_d - rec_h) / np.linalg.norm(rec_h)
+    assert np.linalg.norm(Kd - Kh) <= 1e-4 * np.linalg.norm(Kh)
+    if d <= 33 and n <= 20_000:
+        tol = float(np.sqrt(np.finfo(np.float32).eps))
+        Kref = np.stack([spl.lsqr(S, X[t].astype(np.float64), atol=tol, btol=tol)[0] for t in range(d)])
+        rec_ref = (S @ Kref.T).T
+        # both solvers stop at a relative residual of sqrt(eps(Float32)) = 3.4e-4: that is how far two correct answers may be apart when the
+        # data are exactly representable (noise = 0: the residual itself is at that level)
+        assert np.linalg.norm(rec_d - rec_ref) <= (2e-4 if noise > 0 else 2e-3) * np.linalg.norm(rec_ref)
+        assert np.linalg.norm(X - rec_d) <= np.linalg.norm(X - rec_ref) * (1 + 1e-4) + 2e-3 * np.linalg.norm(X)
+
+
+def test_update_codebooks_device_degenerate_systems(lsq):
+    """a dimension that is identically zero stops at once with a zero row; unused codes keep zero codewords"""
+    H = 256
+    rng = np.random.default_rng(4)
+    d, n, m = 6, 3000, 2
+    X, B = TP._problem(rng, d, n, m)
+    X[2] = 0.0
+    B[0] = np.minimum(B[0], 100)                                    # codes 101..256 of the first codebook never occur
+    with lsq.Engine(0) as eng:
+        C = lsq.update_codebooks(X, B, H, engine=eng)
+    assert np.all(C[0][2] == 0) and np.all(C[1][2] == 0)
+    assert np.all(C[0][:, 100:] == 0)
+    Ch = lsq.update_codebooks(X, B, H)
+    assert np.linalg.norm(np.concatenate(C, axis=1) - np.concatenate(Ch, axis=1)) <= 1e-4 * np.linalg.norm(np.concatenate(Ch, axis=1))

@@ -29,8 +29,12 @@ def test_demo_flow_on_synthetic_data(lsq):
     assert chain_err[-1] <= opq_err[-1] * 1.02
     # === LSQ train === (:33-40)
     ilsiter, icmiter, randord, npert = 4, 4, True, 2
+    B_in, C_in = B.copy(), [c.copy() for c in C]
     C, B, cbnorms, B_norms, obj = lsq.train_lsq(x_train, m, H, R, B, C, 3, ilsiter, icmiter, randord, npert, seed=5)
     assert obj[-1] <= obj[0] * 1.001 and obj[-1] <= chain_err[-1] * 1.02
+    with lsq.Engine(0) as eng:                             # the same training with the codebook update on the device too (lsq_update_codebooks_gpu)
+        C2, B2, _, _, obj2 = lsq.train_lsq(x_train, m, H, R, B_in, C_in, 3, ilsiter, icmiter, randord, npert, seed=5, engine=eng, device_update=True)
+    assert np.allclose(obj2, obj, rtol=1e-4) and obj2[-1] <= chain_err[-1] * 1.02       # the two LSQR solvers agree to ~1e-6; the trajectories stay together
     assert len(C) == m and C[0].shape == (d, H) and cbnorms.shape[0] <= H
 
     # === Encode the base set === (:42-55)

@@ -31,6 +31,8 @@ LSQ_SB_SCHEDULE=6 python tools/sweep_breakdown.py "$O/sb6" > "$O/sb6.log" 2>&1 &
   python tools/linscan_bench.py 1000000 10000 128 16 1000; python tools/linscan_bench.py 1000000 10000 128 8 10000; python tools/linscan_bench.py 1000000 1000 960 8 1000; } > "$O/${TAG}_linscan.jsonl" 2> "$O/linscan.err"
 ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$O/linscan_stats" -o k --output-format csv -- python "$R/tools/linscan_bench.py" > "$O/linscan_stats.log" 2>&1 )
 cp "$(find "$O/linscan_stats" -name '*kernel_stats.csv' | head -1)" "$O/${TAG}_linscan_kernel_stats.csv" 2>/dev/null
+# the codebook update on the device: host LSQR vs device LSQR on three shapes
+{ python tools/lsqr_bench.py 100000 128 8; python tools/lsqr_bench.py 1000000 128 8; python tools/lsqr_bench.py 100000 960 8; } > "$O/${TAG}_lsqr.jsonl" 2> "$O/lsqr.err"
 [ -x tools/bin/ubench_lds ] && tools/bin/ubench_lds > "$O/ubench_lds_${TAG}.txt" 2>&1
 find "$O" -name "*.csv" -size +4M -delete
 ls -la "$O"
