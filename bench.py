@@ -300,7 +300,7 @@ def search_leg(lsq, eng, dK, dcodes, n, d, m, nq=10000, knn=1000):
         recon += dK[j * H + dcodes[:, j].long()]
     dN = (recon.double() ** 2).sum(1).float().contiguous()
     del recon
-    eng.linscan_dev(dcodes, dQ[:64].contiguous(), dK, dN, m, knn)
+    eng.linscan_dev(dcodes, dQ, dK, dN, m, knn)                 # warm-up at full size: the scan's work buffers (2 x 1.2 GB of candidate lists) are allocated here
     torch.cuda.synchronize()
     eng.reset_timings()
     reps = 3

@@ -20,7 +20,7 @@ for j in range(m):
 dN = (recon.double() ** 2).sum(1).float().contiguous()
 del recon
 with lsq.Engine(0, profile=True) as eng:
-    eng.linscan_dev(dC, dQ[:64].contiguous(), dK, dN, m, knn)
+    eng.linscan_dev(dC, dQ, dK, dN, m, knn)                      # warm-up at full size (allocates the scan's work buffers)
     torch.cuda.synchronize()
     eng.reset_timings()
     reps = 3
