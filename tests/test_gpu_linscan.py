@@ -189,3 +189,12 @@ def test_sift1m_shape_every_query(lsq):
             assert np.array_equal(ids, iref) and np.array_equal(dists.view(np.uint32), dref.view(np.uint32))
         st = eng.linscan_stats()
     assert st["fallback_queries"] == 0 and st["queries"] == 2 * nq, st
+
+
+def test_more_queries_than_one_thresholded_batch(lsq, oracle):
+    """20 000 queries on the thresholded road: two batches of candidate lists (16 384 queries each at most), ragged second batch"""
+    rng = np.random.default_rng(41)
+    n, nq, d, m, knn = 70_000, 20_000, 8, 4, 3
+    codes, Q, K, dbnorms = _case(rng, n, nq, d, m)
+    st = _check(lsq, oracle, codes, Q, K, dbnorms, m, knn, expect={"exhaustive": 0, "batches": 2})
+    assert st["fallback_queries"] <= 2, st          # 1e-8 per query by design
