@@ -355,34 +355,21 @@ __global__ void adc_gather_kernel(const uint64_t *__restrict__ sorted, const int
     }
 }
 
-struct Buf {
-    void *p = nullptr;
-    size_t cap = 0;
-    int ensure(size_t bytes) {
-        if (bytes <= cap) return LSQ_OK;
-        if (p) { LSQ_HIP(hipFree(p)); p = nullptr; cap = 0; }
-        LSQ_HIP(hipMalloc(&p, bytes));
-        cap = bytes;
-        return LSQ_OK;
-    }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
-    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
-};
 
 }  // namespace
 
 struct lsq_adc_state {
-    Buf lut, keys_a, keys_b, tau, count, seg, fail, qsel, tmp;
-    Buf h_codes, h_q, h_k, h_norms, h_dists, h_idx;      // staging of the host-buffer entry point
+    DevBuf lut, keys_a, keys_b, tau, count, seg, fail, qsel, tmp;
+    DevBuf h_codes, h_q, h_k, h_norms, h_dists, h_idx;      // staging of the host-buffer entry point
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool attr_set = false;
 };
 
 void lsq_adc_free(lsq_adc_state *st) {
     if (!st) return;
-    Buf *all[] = {&st->lut, &st->keys_a, &st->keys_b, &st->tau, &st->count, &st->seg, &st->fail, &st->qsel, &st->tmp,
+    DevBuf *all[] = {&st->lut, &st->keys_a, &st->keys_b, &st->tau, &st->count, &st->seg, &st->fail, &st->qsel, &st->tmp,
                   &st->h_codes, &st->h_q, &st->h_k, &st->h_norms, &st->h_dists, &st->h_idx};
-    for (Buf *b : all) b->release();
+    for (DevBuf *b : all) b->release();
     for (hipEvent_t e : st->ev) if (e) (void)hipEventDestroy(e);
     delete st;
 }

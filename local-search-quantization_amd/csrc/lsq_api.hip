@@ -36,20 +36,6 @@ extern "C" int lsq_device_count(int *count) {
 }
 
 // ---- context ------------------------------------------------------------------------------------
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    int ensure(size_t bytes) {
-        if (bytes <= cap) return LSQ_OK;
-        if (p) { LSQ_HIP(hipFree(p)); p = nullptr; cap = 0; }
-        if (bytes == 0) return LSQ_OK;
-        LSQ_HIP(hipMalloc(&p, bytes));
-        cap = bytes;
-        return LSQ_OK;
-    }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
-    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
-};
 
 enum { CAT_TABLES = 0, CAT_UNARIES, CAT_PERTURB, CAT_ICM, CAT_COST, CAT_OTHER, CAT_COUNT };
 

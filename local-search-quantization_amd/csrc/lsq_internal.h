@@ -39,6 +39,22 @@ void lsq_set_error(const char *fmt, ...);
         if (rc_ != LSQ_OK) return rc_; \
     } while (0)
 
+// ---- a device buffer that only grows (owned by a context or by one of its sub-states) --------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return LSQ_OK;
+        if (p) { LSQ_HIP(hipFree(p)); p = nullptr; cap = 0; }
+        if (bytes == 0) return LSQ_OK;
+        LSQ_HIP(hipMalloc(&p, bytes));
+        cap = bytes;
+        return LSQ_OK;
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
 // ---- Philox4x32-10 (Random123; Salmon et al. SC'11), shared by host and device -----------
 // Stream layout (build-defined, mirrored by oracle/lsq_oracle.c):
 //   counter = (idx_lo, idx_hi, it, (domain << 16) | (word >> 2)),  key = (seed_lo, seed_hi),

@@ -208,13 +208,12 @@ __global__ void lsqr_scal_stop(int d, Scal S, float atol, float btol, float ctol
 }  // namespace
 
 struct lsq_lsqr_state {
-    void *buf = nullptr;
-    size_t cap = 0;
+    DevBuf work;      // U, V, W, the double column sums and the per-system scalars of one update
 };
 
 void lsq_lsqr_free(lsq_lsqr_state *st) {
     if (!st) return;
-    if (st->buf) (void)hipFree(st->buf);
+    st->work.release();
     delete st;
 }
 
@@ -227,12 +226,8 @@ int lsq_lsqr_update_codebooks(hipStream_t s, lsq_lsqr_state **pst, const float *
     const size_t nd = (size_t)n * d, cd = (size_t)cols * d;
     const size_t f_scal = 20, off_U = 0, off_V = off_U + nd * 4, off_W = off_V + cd * 4, off_tmpn = (off_W + cd * 4 + 15) & ~(size_t)15,
                  off_sc = off_tmpn + cd * 8, off_dbl = (off_sc + f_scal * d * 4 + d * 4 + 15) & ~(size_t)15, total = off_dbl + 3 * (size_t)d * 8 + 64;
-    if (total > st->cap) {
-        if (st->buf) { LSQ_HIP(hipFree(st->buf)); st->buf = nullptr; st->cap = 0; }
-        LSQ_HIP(hipMalloc(&st->buf, total));
-        st->cap = total;
-    }
-    char *base = reinterpret_cast<char *>(st->buf);
+    LSQ_TRY(st->work.ensure(total));
+    char *base = st->work.as<char>();
     float *U = reinterpret_cast<float *>(base + off_U), *V = reinterpret_cast<float *>(base + off_V), *W = reinterpret_cast<float *>(base + off_W);
     double *tmpn = reinterpret_cast<double *>(base + off_tmpn);
     float *sc = reinterpret_cast<float *>(base + off_sc);
