@@ -71,6 +71,7 @@ struct lsq_ctx {
     // the same shape is remembered instead (re-probed every 16th call)
     int64_t call_I = 0, call_q16_chunks = 0;
     int64_t sticky_n = -1; int sticky_d = 0, sticky_m = 0, sticky_bad = 0, sticky_count = 0;
+    float *q_colshift = nullptr;                       // inside qscratch: the per-candidate shift of the unary levels (double-centred tables)
     lsq_lsqr_state *lsqr = nullptr;                    // device LSQR (lsq_lsqr.hip): work buffers, created on first use
     lsq_adc_state *adc = nullptr;                      // device ADC scan (lsq_adc.hip): buffers, created on first use
     lsq_linscan_stats adc_stats{};
@@ -383,9 +384,12 @@ static int build_unaries(lsq_ctx *c, const float *dX, const float *dK, int d, in
         Timer t(c, CAT_TABLES);
         LSQ_TRY(c->Uq.ensure(sizeof(uint16_t) * (size_t)m * (size_t)cn * LSQ_H));
         LSQ_TRY(c->Tq.ensure(sizeof(uint16_t) * (size_t)m * (size_t)(m > 1 ? m - 1 : 1) * LSQ_H * LSQ_H));
-        // scratch: [16] bad, [64..200) range keys, [256..) table ranges (2 m m floats), row minima (m m h floats), codebook means (m d floats)
-        const size_t off_rowmin = (256 + sizeof(float) * 2 * (size_t)m * m + 255) & ~(size_t)255;
-        const size_t off_means = off_rowmin + sizeof(float) * (size_t)m * m * LSQ_H;
+        // scratch: [16] bad, [64..200) range keys, [256..) table ranges (3 m m floats), row minima and column means (m m h floats each), the unary's
+        // column shift (m h floats), codebook means (m d floats)
+        const size_t off_rowmin = (256 + sizeof(float) * 3 * (size_t)m * m + 255) & ~(size_t)255;
+        const size_t off_colmean = off_rowmin + sizeof(float) * (size_t)m * m * LSQ_H;
+        const size_t off_colshift = off_colmean + sizeof(float) * (size_t)m * m * LSQ_H;
+        const size_t off_means = off_colshift + sizeof(float) * (size_t)m * LSQ_H;
         LSQ_TRY(c->qscratch.ensure(off_means + sizeof(float) * (size_t)m * d));
         LSQ_TRY(c->qsigma.ensure(sizeof(float) * (size_t)cn * m));      // per-(vector, node) unary shift: levels only (lsq_icmq.hip)
         LSQ_TRY(c->qflag.ensure(sizeof(unsigned short) * (size_t)(cn + 2)));
@@ -395,7 +399,9 @@ static int build_unaries(lsq_ctx *c, const float *dX, const float *dK, int d, in
         LSQ_TRY(lsq_launch_q16_prepare(c->stream, dX, cn, d, dK, c->sci.as<float>(), c->T.as<float>(), m, c->Tq.as<uint16_t>(),
                                        reinterpret_cast<int *>(sc + 16), reinterpret_cast<float *>(sc + 256), reinterpret_cast<unsigned *>(sc + 64),
                                        c->qflag.as<unsigned short>(), c->qp.as<lsq_q16_params>(), c->tables_changed,
-                                       reinterpret_cast<float *>(sc + off_rowmin), reinterpret_cast<float *>(sc + off_means), c->qsigma.as<float>()));
+                                       reinterpret_cast<float *>(sc + off_rowmin), reinterpret_cast<float *>(sc + off_means), c->qsigma.as<float>(),
+                                       reinterpret_cast<float *>(sc + off_colmean), reinterpret_cast<float *>(sc + off_colshift)));
+        c->q_colshift = reinterpret_cast<float *>(sc + off_colshift);
         c->tables_changed = 0;
     }
     {
@@ -406,7 +412,8 @@ static int build_unaries(lsq_ctx *c, const float *dX, const float *dK, int d, in
         uint16_t *dq = q16 ? c->Uq.as<uint16_t>() : nullptr;
         LSQ_TRY(lsq_launch_chain_gemm(c->stream, dX + r0 * d, dK, c->sci.as<float>(), -2.0f, rows, m * LSQ_H, d, LSQ_H, cn * (int64_t)LSQ_H, LSQ_H,
                                       c->U.as<float>(), slice, cn, r0, dq, dq ? lsq_q16_slice_width(m) : 0, dq ? c->qp.as<lsq_q16_params>() : nullptr, 0,
-                                      dq ? c->qflag.as<unsigned short>() : nullptr, nullptr, 1, dq ? c->qsigma.as<float>() : nullptr));
+                                      dq ? c->qflag.as<unsigned short>() : nullptr, nullptr, 1, dq ? c->qsigma.as<float>() : nullptr,
+                                      dq ? c->q_colshift : nullptr));
     }
     if (q16) {
         // The chunk's verdict (three words, ONE host round trip per resident chunk -- 10^6 vectors, ~50 ms of work): usable bounds, and few enough

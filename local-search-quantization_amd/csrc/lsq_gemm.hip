@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                          float *__restrict__ D, int64_t row_tiles, int col_tiles, int slice,
                                                          int64_t Mtot, int64_t rbase, uint16_t *__restrict__ Dq, int slice_q,
                                                          lsq_q16_params *__restrict__ qp, int64_t lda, unsigned short *__restrict__ qflag,
-                                                         unsigned *__restrict__ qrange, int rts, const float *__restrict__ sigma) {
+                                                         unsigned *__restrict__ qrange, int rts, const float *__restrict__ sigma,
+                                                         const float *__restrict__ colshift) {
     constexpr int LD = BK + LSQ_GEMM_PAD;
     __shared__ float smem[2 * BM * LD + 2 * BN * LD];      // A and B panels, double-buffered; reused by the u16 epilogue as a 128 x 128 level tile
     float (*As)[BM * LD] = reinterpret_cast<float (*)[BM * LD]>(smem);
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const int c = col0 + wx * 64 + tj * 32 + l31;
         if (c >= N) continue;
         const float add = addv ? addv[c] : 0.0f;
+        const float gc = (Q16 != 0 && colshift) ? colshift[c] : 0.0f;      // per-candidate shift of the LEVEL input (double-centred tables: lsq_icmq.hip)
         // row-major planes: off = (c/h)*plane + (c%h) + r*row_stride
         // slice-major planes (slice = SL > 0): off = (c/h)*plane + ((c%h)/SL)*(Mtot*SL) + (c%h)%SL + r*SL
         // (r counts from rbase: the launch may cover rows [rbase, rbase + M) of a Mtot-row output)
@@ -214,13 +216,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     float v = acc[ti][tj][r];
                     if (addv) v = v + add;           // one rounded add (utils.jl:112-118)
                     if (Q16 == 2) {
-                        const float w = v + sg;
+                        const float w = (v + gc) + sg;
                         vmin = fminf(vmin, w); vmax = fmaxf(vmax, w);
                         continue;
                     }
                     Dl[(int64_t)ro * rstride] = v;
                     if (q16) {
-                        const float qf = rintf((v - sg) * qinv);
+                        const float qf = rintf(((v + gc) - sg) * qinv);
                         const float qc = __builtin_amdgcn_fmed3f(qf, 0.0f, qhi);       // clamp to the level range (NaN -> 0)
                         if (!(qf == qc)) {                                               // outside [0, hiq] or NaN: flag the (vector, node) pair
                             const int64_t row = lrow + ro;
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(256) void sqnorms_kernel(const float *__restrict__ 
 
 int lsq_launch_chain_gemm(hipStream_t s, const float *A, const float *Bm, const float *addv, float alpha, int64_t M,
                           int N, int Kd, int h, int64_t plane_stride, int64_t row_stride, float *D, int slice, int64_t Mtot, int64_t rbase,
-                          uint16_t *Dq, int slice_q, lsq_q16_params *qp, int64_t lda, unsigned short *qflag, unsigned *qrange, int rts, const float *sigma) {
+                          uint16_t *Dq, int slice_q, lsq_q16_params *qp, int64_t lda, unsigned short *qflag, unsigned *qrange, int rts, const float *sigma, const float *colshift) {
     if (lda <= 0) lda = Kd;
     if (rts < 1) rts = 1;
     if (M <= 0 || N <= 0) return LSQ_OK;
@@ -302,10 +304,10 @@ int lsq_launch_chain_gemm(hipStream_t s, const float *A, const float *Bm, const 
     if (qrange) {          // range-only pass
         if (vec4 && lda % 4 == 0)
             hipLaunchKernelGGL((chain_gemm_kernel<true, 16, 2>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                               plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, qrange, rts, sigma);
+                               plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, qrange, rts, sigma, colshift);
         else
             hipLaunchKernelGGL((chain_gemm_kernel<false, 16, 2>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                               plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, qrange, rts, sigma);
+                               plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, qrange, rts, sigma, colshift);
         LSQ_HIP(hipGetLastError());
         return LSQ_OK;
     }
@@ -313,22 +315,22 @@ int lsq_launch_chain_gemm(hipStream_t s, const float *A, const float *Bm, const 
         if (!qp || !qflag || slice_q < 1) { lsq_set_error("chain_gemm: quantised output needs parameters"); return LSQ_EINVAL; }
         if (vec4)
             hipLaunchKernelGGL((chain_gemm_kernel<true, 16, 1>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                               plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, Dq, slice_q, qp, lda, qflag, nullptr, 1, sigma);
+                               plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, Dq, slice_q, qp, lda, qflag, nullptr, 1, sigma, colshift);
         else
             hipLaunchKernelGGL((chain_gemm_kernel<false, 16, 1>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                               plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, Dq, slice_q, qp, lda, qflag, nullptr, 1, sigma);
+                               plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, Dq, slice_q, qp, lda, qflag, nullptr, 1, sigma, colshift);
         LSQ_HIP(hipGetLastError());
         return LSQ_OK;
     }
     if (vec4 && bk == 8)
         hipLaunchKernelGGL((chain_gemm_kernel<true, 8>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, nullptr, 1, nullptr);
+                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, nullptr, 1, nullptr, nullptr);
     else if (vec4)
         hipLaunchKernelGGL((chain_gemm_kernel<true, 16>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, nullptr, 1, nullptr);
+                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, nullptr, 1, nullptr, nullptr);
     else
         hipLaunchKernelGGL((chain_gemm_kernel<false, 16>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, nullptr, 1, nullptr);
+                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, nullptr, 1, nullptr, nullptr);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }

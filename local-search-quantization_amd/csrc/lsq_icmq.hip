@@ -10,10 +10,13 @@
 //            (Uq, slice-major u16), the pair tables by tables_to_q16_slices_kernel (Tq).  The levels of a candidate are summed as
 //            packed pairs, Q[a] = qU[a] + SUM_k qT_k[a] < 65536 by construction (lsq_q16_node::hiq), so plain 32-bit three-operand
 //            adds are exact: 512 B of unaries and (m-1) x 512 B of table rows per vector and node.  A wave tracks the two smallest keys.
-//   SHIFTS   a term that is the same for all 256 candidates of a node update cannot change its argmin, so it needs no level range: the levels
-//            are taken of U_j[a] + sigma_ij (sigma_ij = 2 <x_i, mean codeword of codebook j>: unary_shift_kernel) and of T_jk[b][a] - min_a
-//            T_jk[b][:] (table_range_kernel).  The ranges the common step must cover shrink by a third on SIFT-like data (D 11.3 -> 7.4 at
-//            m = 8), and the ambiguous node updates with them (1.7 % -> 1.2 %; m = 16: 3.2 % -> 2.1 %).
+//   SHIFTS   a term that is the same for all 256 candidates of a node update cannot change its argmin, so it needs no level range; and a term that
+//            depends on the candidate alone may sit in the unary as well as in a table.  The levels are taken of
+//                U_j[a] + sigma_ij + SUM_k g_jk[a]      sigma_ij = 2 <x_i, mean codeword of codebook j>  (unary_shift_kernel),
+//                T_jk[b][a] - g_jk[a] - min_a(...)      g_jk[a] = mean_b T_jk[b][a]  (table_colmean_kernel, table_range_kernel):
+//            the unary against the residual of x after the other codebooks' mean codewords, the tables without their additive row + column
+//            structure.  The ranges the common step must cover shrink to 40 % on SIFT-like data (D 11.3 -> 7.4 -> 4.5 at m = 8, 5.9 -> 3.9 -> 2.2 at
+//            m = 16), and the ambiguous node updates with them (1.7 % -> 1.2 % -> 0.8 %; m = 16: 3.2 % -> 2.2 % -> 1.4 %).
 //   BOUND    |C_i + D Q[a] - s_f32[a]| <= slack := m (0.5 + 2^-5) D + eps_f32  for every candidate, C_i the same for all of them (rounding of
 //            each level, of the shifts, of the f32 chain).  Hence the exact argmin a* obeys  Q[a*] <= Qmin + window,  window = floor(2 slack / D) + 1.
 //   REFINE   second - best > window: the best key IS the exact argmin (>= 98 % of the node updates).  Otherwise (q16_refine) every
@@ -68,34 +71,65 @@ __device__ inline uint32_t dpp_u32(uint32_t v) {
 
 // ---- parameters -----------------------------------------------------------------------------------------------------------------
 // Shifts that are the same for every candidate of a node update cannot change its argmin, so they need no level range.  A table row T[j][k][b][:]
-// enters a conditioned sum as a whole (the row of the code b that codebook k holds): its minimum is such a shift.  Per off-diagonal pair table (65536
-// floats): rowmin[(j*m + k)*256 + b] = min_a T[j][k][b][a];  range[(j*m + k)*2] = max_b (max_a - min_a) -- the range the CENTRED rows need, 13 %
-// less than the table's own range on SIFT-like data --;  range[(j*m + k)*2 + 1] = max |T| (for the f32 rounding term of the bound).
-__global__ __launch_bounds__(256) void table_range_kernel(const float *__restrict__ T, int m, float *__restrict__ range, float *__restrict__ rowmin,
-                                                          int *__restrict__ bad) {
+// enters a conditioned sum as a whole (the row of the code b that codebook k holds): its minimum is such a shift.  And a shift g_jk[a] that depends on
+// the CANDIDATE alone can be moved from the table to the unary: s[a] = (U[a] + SUM_k g_jk[a]) + SUM_k (T_jk[b_k][a] - g_jk[a]).  With g = the column
+// means the tables lose their additive row + column structure (T_jk[b][a] = 2 <c_a, c_b>: what is left is the interaction of the two deviations from
+// the codebook means) and the unary becomes ||c_a||^2 - 2 <c_a, x - the other codebooks' mean codewords>, against the residual instead of x: both
+// ranges shrink, the common step D by another 40 % (7.3 -> 4.5 at cfg2, 3.9 -> 2.2 at m = 16) on top of the row / sigma shifts.
+// table_colmean_kernel: g[(j*m + k)*256 + a] = mean_b T[j][k][b][a] (double sum, rounded once).
+__global__ __launch_bounds__(256) void table_colmean_kernel(const float *__restrict__ T, int m, float *__restrict__ colmean) {
+    const int jk = blockIdx.x, j = jk / m, k = jk % m, a = threadIdx.x;
+    if (j == k) { colmean[(int64_t)jk * LSQ_H + a] = 0.0f; return; }
+    const float *p = T + (int64_t)jk * LSQ_H * LSQ_H;
+    double acc = 0.0;
+    for (int b = 0; b < LSQ_H; ++b) acc += (double)p[(int64_t)b * LSQ_H + a];      // coalesced over a
+    colmean[(int64_t)jk * LSQ_H + a] = (float)(acc * (1.0 / LSQ_H));
+}
+// colshift[j*256 + a] = fl32( SUM_{k != j} g_jk[a] ) (double sum of the f32 means: ONE rounding, bounded in q16_params_kernel)
+__global__ __launch_bounds__(256) void unary_colshift_kernel(const float *__restrict__ colmean, int m, float *__restrict__ colshift) {
+    const int j = blockIdx.x, a = threadIdx.x;
+    double acc = 0.0;
+    for (int k = 0; k < m; ++k)
+        if (k != j) acc += (double)colmean[((int64_t)j * m + k) * LSQ_H + a];
+    colshift[j * LSQ_H + a] = (float)acc;
+}
+// Per off-diagonal pair table (65536 floats), on the column-centred entries c = fl(t - g[a]):  rowmin[(j*m + k)*256 + b] = min_a c;
+// range[(j*m + k)*3] = max_b (max_a c - min_a c) -- the range the levels need --;  range[.. + 1] = max |t|, range[.. + 2] = max |g| (for the f32 rounding
+// terms of the bound).
+__global__ __launch_bounds__(256) void table_range_kernel(const float *__restrict__ T, int m, const float *__restrict__ colmean, float *__restrict__ range,
+                                                          float *__restrict__ rowmin, int *__restrict__ bad) {
     const int jk = blockIdx.x, j = jk / m, k = jk % m;
     if (j == k) return;
     const float *p = T + (int64_t)jk * LSQ_H * LSQ_H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const f32x4 g = *reinterpret_cast<const f32x4 *>(colmean + (int64_t)jk * LSQ_H + 4 * lane);
     float rng = 0.0f, mag = 0.0f;
+    float gmag = fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w)));
     bool nonfinite = false;
     for (int b = wave; b < LSQ_H; b += 4) {                       // one wave per row: 64 lanes x 16 B = the row's 1 KiB in one load
         const f32x4 v = *reinterpret_cast<const f32x4 *>(p + (int64_t)b * LSQ_H + 4 * lane);
         nonfinite = nonfinite || !(fabsf(v.x) <= 3.0e38f) || !(fabsf(v.y) <= 3.0e38f) || !(fabsf(v.z) <= 3.0e38f) || !(fabsf(v.w) <= 3.0e38f);
-        float lo = fminf(fminf(v.x, v.y), fminf(v.z, v.w)), hi = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+        const f32x4 c = v - g;
+        float lo = fminf(fminf(c.x, c.y), fminf(c.z, c.w)), hi = fmaxf(fmaxf(c.x, c.y), fmaxf(c.z, c.w));
+        float am = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off, 64)); hi = fmaxf(hi, __shfl_xor(hi, off, 64)); }
+        for (int off = 32; off > 0; off >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, off, 64)); hi = fmaxf(hi, __shfl_xor(hi, off, 64)); am = fmaxf(am, __shfl_xor(am, off, 64));
+        }
         if (lane == 0) rowmin[(int64_t)jk * LSQ_H + b] = lo;
         rng = fmaxf(rng, hi - lo);                                // rounded up below (the params kernel works in double and adds its own margin)
-        mag = fmaxf(mag, fmaxf(fabsf(lo), fabsf(hi)));
+        mag = fmaxf(mag, am);
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) gmag = fmaxf(gmag, __shfl_xor(gmag, off, 64));
     __shared__ float srng[4], smag[4];
     if (__ballot(nonfinite) != 0ull && lane == 0) atomicExch(bad, 1);
     if (lane == 0) { srng[wave] = rng; smag[wave] = mag; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        range[jk * 2 + 0] = fmaxf(fmaxf(srng[0], srng[1]), fmaxf(srng[2], srng[3]));
-        range[jk * 2 + 1] = fmaxf(fmaxf(smag[0], smag[1]), fmaxf(smag[2], smag[3]));
+        range[jk * 3 + 0] = fmaxf(fmaxf(srng[0], srng[1]), fmaxf(srng[2], srng[3]));
+        range[jk * 3 + 1] = fmaxf(fmaxf(smag[0], smag[1]), fmaxf(smag[2], smag[3]));
+        range[jk * 3 + 2] = gmag;
     }
 }
 
@@ -204,18 +238,24 @@ __global__ __launch_bounds__(64) void q16_params_kernel(const float *__restrict_
         nd.loU = (float)loU;
         if ((double)nd.loU > loU) nd.loU = nextafterf(nd.loU, -__builtin_inff());
         loU = (double)nd.loU;
-        double rsum = hiU - loU, smax = fmax(fabs(loU), fabs(hiU)) + sigmax, sub = fmax(fabs(loU), fabs(hiU));
+        // W = the sampled bound of the shifted unary w = (v + G[a]) + sigma_i;  the unshifted |v| <= W + sigmax + Gmax
+        const double W = fmax(fabs(loU), fabs(hiU));
+        double Gmax = 0.0;                                     // |colshift| <= SUM_k max |g_jk|
+        double rsum = hiU - loU, tsum = 0.0, sub = 0.0;
         for (int k = 0; k < m; ++k) {
             if (k == j) continue;
-            const double tr = (double)trange[(j * m + k) * 2] * (1.0 + 1e-6), tm = (double)trange[(j * m + k) * 2 + 1];      // centred-row range, magnitude
-            rsum += tr;
-            smax += tm;
-            sub += 2.0 * tm;                               // |t - rowmin| <= 2 max|t|: the f32 subtraction that centres a table entry
+            const double tr = (double)trange[(j * m + k) * 3] * (1.0 + 1e-6), tm = (double)trange[(j * m + k) * 3 + 1], gm = (double)trange[(j * m + k) * 3 + 2];
+            rsum += tr;                                        // centred-entry range
+            tsum += tm;
+            Gmax += gm;
+            sub += 2.0 * (tm + gm) + tr;                       // the two f32 subtractions that centre a table entry: t - g[a], then - rowmin[b]
         }
+        const double smax = W + sigmax + Gmax + tsum;          // magnitudes along the canonical f32 chain U + T + T + ...
+        sub += (W + Gmax + sigmax) * 3.0 + 2.0 * Gmax;         // the unary side: v + G[a], the row's lo_row = loU - sigma, their difference; the f32 rounding of G itself
         const double D = rsum / 65500.0;
-        // f32 chain vs real sum: <= m roundings of <= 2^-24 smax (x2 margin);  + one f32 rounding each for the shifted unary (v + sigma) and the centred
-        // table entries (t - rowmin), <= 2^-24 of their magnitudes (x2 margin)
-        const double eps = (double)(m + 1) * smax * 5.9604644775390625e-8 * 2.0 + (sub + sigmax) * 5.9604644775390625e-8 * 2.0;
+        // f32 chain vs real sum: <= m roundings of <= 2^-24 smax (x2 margin);  + every f32 rounding on the way to a level's input, <= 2^-24 of the
+        // magnitudes collected in `sub` (x2 margin)
+        const double eps = (double)(m + 1) * smax * 5.9604644775390625e-8 * 2.0 + sub * 5.9604644775390625e-8 * 2.0;
         const double slack = (double)m * (0.5 + 1.0 / 32.0) * D + eps + 65535.0 * D * 2.384185791015625e-7;      // + the f32 rounding of D and 1/D over 65535 levels
         nd.D = (float)D;
         nd.invD = (float)(1.0 / D);
@@ -232,10 +272,11 @@ __global__ __launch_bounds__(64) void q16_params_kernel(const float *__restrict_
     P->nflag = 0;                // per chunk: raised by the GEMM epilogue that follows
 }
 
-// Tq[j][slice][kk][b][SLQ] (u16)  <-  rint((T[j][k(kk)][b][slice*SLQ ..] - rowmin[j][k][b]) * invD_j)      (one thread per 8 levels = 16 B)
+// Tq[j][slice][kk][b][SLQ] (u16)  <-  rint(((T[j][k(kk)][b][slice*SLQ ..] - g_jk[a]) - rowmin[j][k][b]) * invD_j)      (one thread per 8 levels = 16 B)
 template <int SLQ>
 __global__ __launch_bounds__(256) void tables_to_q16_slices_kernel(const float *__restrict__ T, uint16_t *__restrict__ Tq, int m,
-                                                                   const lsq_q16_params *__restrict__ P, const float *__restrict__ rowmin) {
+                                                                   const lsq_q16_params *__restrict__ P, const float *__restrict__ rowmin,
+                                                                   const float *__restrict__ colmean) {
     constexpr int NS = LSQ_H / SLQ, LPV = SLQ / 8;
     const int64_t total = (int64_t)m * NS * (m - 1) * LSQ_H * LPV;
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -247,13 +288,14 @@ __global__ __launch_bounds__(256) void tables_to_q16_slices_kernel(const float *
     const int slice = (int)(r % NS);
     const int j = (int)(r / NS);
     const int k = kk + (kk >= j ? 1 : 0);
-    const float lo = rowmin[((int64_t)j * m + k) * LSQ_H + b], inv = P->node[j].invD;      // the row's own minimum: a shift common to all candidates
+    const float lo = rowmin[((int64_t)j * m + k) * LSQ_H + b], inv = P->node[j].invD;      // the centred row's own minimum: a shift common to all candidates
     const float *src = T + (((int64_t)j * m + k) * LSQ_H + b) * LSQ_H + slice * SLQ + qq * 8;
+    const float *gs = colmean + ((int64_t)j * m + k) * LSQ_H + slice * SLQ + qq * 8;          // the candidates' column means (moved to the unary levels)
     uint32_t w[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const float q0 = fminf(fmaxf(rintf((src[2 * t] - lo) * inv), 0.0f), 65535.0f);
-        const float q1 = fminf(fmaxf(rintf((src[2 * t + 1] - lo) * inv), 0.0f), 65535.0f);
+        const float q0 = fminf(fmaxf(rintf(((src[2 * t] - gs[2 * t]) - lo) * inv), 0.0f), 65535.0f);
+        const float q1 = fminf(fmaxf(rintf(((src[2 * t + 1] - gs[2 * t + 1]) - lo) * inv), 0.0f), 65535.0f);
         w[t] = (uint32_t)q0 | ((uint32_t)q1 << 16);
     }
     reinterpret_cast<u32x4 *>(Tq)[e] = (u32x4){w[0], w[1], w[2], w[3]};
@@ -881,11 +923,14 @@ int lsq_q16_slice_width(int m) {
 
 int lsq_launch_q16_prepare(hipStream_t s, const float *X, int64_t n, int d, const float *K, const float *sci, const float *T, int m, uint16_t *Tq,
                            int *bad, float *trange, unsigned *qrange, unsigned short *qflag, lsq_q16_params *P, int tables_changed,
-                           float *rowmin, float *means, float *sigma) {
-    // bad[0]: a non-finite pair table (per call); rowmin [m*m*256], means [m*d]: per call; sigma [n*m]: per chunk; qrange[2*16 + 1]: sample flag, [2*16 + 2]: max |sigma|
+                           float *rowmin, float *means, float *sigma, float *colmean, float *colshift) {
+    // bad[0]: a non-finite pair table (per call); rowmin / colmean [m*m*256], colshift [m*256], means [m*d]: per call; sigma [n*m]: per chunk;
+    // qrange[2*16 + 1]: sample flag, [2*16 + 2]: max |sigma|
     if (tables_changed) {
         LSQ_HIP(hipMemsetAsync(bad, 0, sizeof(int), s));
-        if (m > 1) hipLaunchKernelGGL(table_range_kernel, dim3((unsigned)(m * m)), dim3(256), 0, s, T, m, trange, rowmin, bad);
+        hipLaunchKernelGGL(table_colmean_kernel, dim3((unsigned)(m * m)), dim3(256), 0, s, T, m, colmean);
+        hipLaunchKernelGGL(unary_colshift_kernel, dim3((unsigned)m), dim3(256), 0, s, colmean, m, colshift);
+        if (m > 1) hipLaunchKernelGGL(table_range_kernel, dim3((unsigned)(m * m)), dim3(256), 0, s, T, m, colmean, trange, rowmin, bad);
         hipLaunchKernelGGL(codebook_means_kernel, dim3((unsigned)((d + 63) / 64), (unsigned)m), dim3(256), 0, s, K, m, d, means);
     }
     // sampled range of the SHIFTED unaries: about 16 384 vectors at d <= 128 (every rts-th panel of 128 consecutive ones) through the range-only GEMM pass
@@ -897,7 +942,8 @@ int lsq_launch_q16_prepare(hipStream_t s, const float *X, int64_t n, int d, cons
                            qrange + 2 * LSQ_MAX_M + 1);
         const int64_t nsample = d <= 128 ? 16384 : (d <= 512 ? 8192 : 4096);      // the pass costs 2 d m h flops per sampled vector: fewer of them at large d
         const int rts = n > nsample ? (int)(n / nsample) : 1;
-        LSQ_TRY(lsq_launch_chain_gemm(s, X, K, sci, -2.0f, n, m * LSQ_H, d, LSQ_H, 0, 0, nullptr, 0, n, 0, nullptr, 0, nullptr, 0, nullptr, qrange, rts, sigma));
+        LSQ_TRY(lsq_launch_chain_gemm(s, X, K, sci, -2.0f, n, m * LSQ_H, d, LSQ_H, 0, 0, nullptr, 0, n, 0, nullptr, 0, nullptr, 0, nullptr, qrange, rts, sigma,
+                                      colshift));
         LSQ_HIP(hipMemsetAsync(qflag, 0, sizeof(unsigned short) * (size_t)((n + 1) & ~(int64_t)1), s));
     }
     hipLaunchKernelGGL(q16_params_kernel, dim3(1), dim3(64), 0, s, trange, bad, qrange, m, P, qrange + 2 * LSQ_MAX_M + 1);
@@ -905,8 +951,8 @@ int lsq_launch_q16_prepare(hipStream_t s, const float *X, int64_t n, int d, cons
         const int slq = lsq_q16_slice_width(m);
         const int64_t total = (int64_t)m * (LSQ_H / slq) * (m - 1) * LSQ_H * (slq / 8);
         const unsigned grid = (unsigned)((total + 255) / 256);
-        if (slq == 32) hipLaunchKernelGGL(tables_to_q16_slices_kernel<32>, dim3(grid), dim3(256), 0, s, T, Tq, m, P, rowmin);
-        else hipLaunchKernelGGL(tables_to_q16_slices_kernel<16>, dim3(grid), dim3(256), 0, s, T, Tq, m, P, rowmin);
+        if (slq == 32) hipLaunchKernelGGL(tables_to_q16_slices_kernel<32>, dim3(grid), dim3(256), 0, s, T, Tq, m, P, rowmin, colmean);
+        else hipLaunchKernelGGL(tables_to_q16_slices_kernel<16>, dim3(grid), dim3(256), 0, s, T, Tq, m, P, rowmin, colmean);
     }
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;

@@ -94,8 +94,8 @@ __host__ __device__ inline uint32_t lsq_mulhi32(uint32_t a, uint32_t b) { return
 
 // ---- 16-bit filtered walk: quantisation parameters (device memory, one per resident chunk) ---------------------------------
 // Every term of a conditioned sum s[a] = U_j[a] + SUM_k T_jk[b_k][a] is ALSO held as a 16-bit level on ONE common step D_j per node:
-//   U level = rint((u + sigma_ij - loU) / D),  table level = rint((t - min of t's table row) / D)  (shifts shared by all candidates of a node
-//   update: lsq_icmq.hip),  so that the sum of the m levels Q[a] fits 16 bits and s[a] = C_i + D * Q[a] up to (0.5 + 2^-5) D per term.  Rigorous
+//   U level = rint((u + g_j[a] + sigma_ij - loU) / D),  table level = rint((t - g_jk[a] - min of the centred row) / D)  (shifts shared by all
+//   candidates of a node update, and per-candidate shifts moved from the tables to the unary: lsq_icmq.hip),  so that the sum of the m levels Q[a] fits 16 bits and s[a] = C_i + D * Q[a] up to (0.5 + 2^-5) D per term.  Rigorous
 //   consequence (see icm_walkq_kernel): the exact fp32 argmin lies among the candidates with Q <= Qmin + window.  ok = 0 (non-finite or
 //   degenerate bounds) sends the chunk to the fp32 walk instead.
 struct lsq_q16_node {
@@ -121,13 +121,13 @@ struct lsq_q16_params {
 // Chain = k-ascending fmaf from +0.  The launch covers output rows [rbase, rbase + M) of a Mtot-row result (A points at
 // row rbase): row r above counts from rbase -- lets the caller build the unaries panel by panel under the H2D copies.
 // Optional second output (Dq != nullptr): the same values as 16-bit fixed-point levels in slice-major u16 planes of slice width slice_q,
-// Dq[(c / h) * Mtot * h + ((c % h) / slice_q) * Mtot * slice_q + r * slice_q + (c % h) % slice_q] = rint((v + sigma[r][c / h] - qp->node[c / h].loU) * invD).
+// Dq[(c / h) * Mtot * h + ((c % h) / slice_q) * Mtot * slice_q + r * slice_q + (c % h) % slice_q] = rint((v + colshift[c] + sigma[r][c / h] - qp->node[c / h].loU) * invD).
 int lsq_launch_chain_gemm(hipStream_t s, const float *A, const float *Bm, const float *addv, float alpha,
                           int64_t M, int N, int Kd, int h, int64_t plane_stride, int64_t row_stride, float *D, int slice,
                           int64_t Mtot, int64_t rbase, uint16_t *Dq = nullptr, int slice_q = 0, struct lsq_q16_params *qp = nullptr,
-                          int64_t lda = 0, unsigned short *qflag = nullptr, unsigned *qrange = nullptr, int rts = 1, const float *sigma = nullptr);
-// sigma (optional, [Mtot][N / h] floats): per-(row, plane) shift added to a value before its LEVEL is taken (and in the range-only pass); the f32
-// output D is not shifted.  A shift common to all candidates of a node update cannot change its argmin (lsq_icmq.hip).
+                          int64_t lda = 0, unsigned short *qflag = nullptr, unsigned *qrange = nullptr, int rts = 1, const float *sigma = nullptr, const float *colshift = nullptr);
+// sigma (optional, [Mtot][N / h] floats) / colshift (optional, [N] floats): per-(row, plane) and per-column shifts added to a value before its LEVEL is
+// taken (and in the range-only pass); the f32 output D is not shifted.  A shift common to all candidates of a node update cannot change its argmin (lsq_icmq.hip).
 // lda: row stride of A in floats (0 = Kd).  rts: range-only pass over every rts-th 128-row panel of A.  qflag [Mtot] u16 (Mtot even-padded): bit j raised when a value of
 // plane j fell outside the level range (Dq output).  qrange != nullptr: range-only pass, nothing stored; qrange[2 j], [2 j + 1] = min / max keys.
 // sci[r] = chain_t(Kb[r][t]^2)
@@ -172,12 +172,13 @@ int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const fl
 // idle_if_set (optional, device): the launch does nothing when *idle_if_set != 0 (the filtered walk handled it)
 // 16-bit filtered walk (lsq_icmq.hip).  lsq_launch_q16_prepare: per chunk, after the pair tables and before the unary GEMM -- bounds,
 // parameters P and the 16-bit slice tables Tq [m][256/SLQ][m-1][256][SLQ]; tables_changed = 1 on the first chunk of a call.
-// bad (1 int), trange (2 m m floats), qrange (2 * 16 + 2 u32): scratch.  lsq_launch_icm_walkq: same contract as lsq_launch_icm_walk plus
+// bad (1 int), trange (3 m m floats), qrange (2 * 16 + 2 u32): scratch.  lsq_launch_icm_walkq: same contract as lsq_launch_icm_walk plus
 // Uq (the GEMM's u16 planes), Tq and P; the caller launches it only after reading the chunk's verdict (P->ok, P->nflag) on the host.
 int lsq_q16_slice_width(int m);
 int lsq_launch_q16_prepare(hipStream_t s, const float *X, int64_t n, int d, const float *K, const float *sci, const float *T, int m, uint16_t *Tq,
                            int *bad, float *trange, unsigned *qrange, unsigned short *qflag, lsq_q16_params *P, int tables_changed,
-                           float *rowmin, float *means, float *sigma);      // rowmin [m*m*256], means [m*d] (per call), sigma [n*m] (per chunk)
+                           float *rowmin, float *means, float *sigma, float *colmean, float *colshift);
+// rowmin [m*m*256], means [m*d], colmean [m*m*256], colshift [m*256] (per call), sigma [n*m] (per chunk); trange: 3 floats per pair table
 int lsq_launch_icm_walkq(hipStream_t s, const float *U, const uint16_t *Uq, const uint16_t *Tq, const float *T, uint8_t *rec, unsigned short *valid,
                          int64_t n, int m, const int32_t *order, int nnodes, int pos0, int use_skip, unsigned long long *active_total, int light,
                          const uint8_t *ref_rec, const unsigned short *ref_valid, const lsq_q16_params *P, const unsigned short *qflag);
