@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define LSQ_VERSION 330
+#define LSQ_VERSION 340
 
 #if defined(__GNUC__)
 #define LSQ_API __attribute__((visibility("default")))
@@ -247,6 +247,10 @@ LSQ_API int lsq_linscan(lsq_ctx *ctx, float *dists, int *idx, const unsigned cha
                         const float *dbnorms, int nqueries, int ncodes, int m, int h, int d, int nn);
 LSQ_API int lsq_linscan_dev(lsq_ctx *ctx, float *d_dists, int *d_idx, const uint8_t *d_codes, const float *d_queries, const float *d_codebooks,
                             const float *d_dbnorms, int nqueries, int ncodes, int m, int h, int d, int nn);
+/* The same over a database sharded across the devices of an lsq_multi (splitarray shards, one host thread per device, host merge of the per-device
+ * lists by (distance, id)): the result of ONE scan of the whole database, ties across shards included. */
+LSQ_API int lsq_multi_linscan(lsq_multi *mg, float *dists, int *idx, const unsigned char *codes, const float *queries, const float *codebooks,
+                              const float *dbnorms, int nqueries, int ncodes, int m, int h, int d, int nn);
 /* What the device scan did since the last lsq_reset_timings (times only with option "profile" = 1). */
 typedef struct lsq_linscan_stats {
     int64_t queries, codes;          /* queries searched (accumulated); database size of the last call */

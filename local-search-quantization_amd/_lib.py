@@ -77,6 +77,7 @@ SIGNATURES = {
     "lsq_linscan_aqd_query_extra_byte": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
     "lsq_linscan": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
     "lsq_linscan_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
+    "lsq_multi_linscan": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
     "lsq_get_linscan_stats": (_i, [_vp, C.POINTER(LinscanStats)]),
     "lsq_quantize_norms": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _i, _i, _vp, _vp, _vp]),
     "lsq_quantize_norms_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _i, _i, _vp, _vp, _vp]),

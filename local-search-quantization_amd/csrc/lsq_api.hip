@@ -816,6 +816,76 @@ extern "C" int lsq_multi_encode_icm(lsq_multi *mg, const float *RX, const int16_
     return LSQ_OK;
 }
 
+// The ADC scan over a database sharded across the devices (splitarray shards, one host thread per device): every device returns its own nn nearest
+// (fewer if its shard is smaller), ids become global, and the host merges the lists by (distance, id) -- std::pair's order, the reference's
+// partial_sort order -- so the result is what ONE scan of the whole database returns, ties across shards included.
+extern "C" int lsq_multi_linscan(lsq_multi *mg, float *dists, int *idx, const unsigned char *codes, const float *queries, const float *codebooks,
+                                 const float *dbnorms, int nqueries, int ncodes, int m, int h, int d, int nn) {
+    if (!mg || mg->ctx.empty()) { lsq_set_error("null lsq_multi"); return LSQ_EINVAL; }
+    LSQ_TRY(linscan_check("lsq_multi_linscan", dists, idx, codes, queries, codebooks, dbnorms, nqueries, ncodes, m, h, d, nn));
+    if (nqueries == 0) return LSQ_OK;
+    const int G = (int)mg->ctx.size();
+    std::vector<std::vector<float>> pd((size_t)G);
+    std::vector<std::vector<int>> pi((size_t)G);
+    std::vector<int> klen((size_t)G, 0), rc((size_t)G, LSQ_OK);
+    std::vector<int64_t> start((size_t)G, 0);
+    std::vector<std::string> err((size_t)G);
+    std::vector<std::thread> th;
+    for (int p = 0; p < G; ++p) {
+        th.emplace_back([&, p]() {
+            int64_t s0 = 0, len = 0;
+            rc[(size_t)p] = lsq_splitarray(ncodes, G, p, &s0, &len);
+            start[(size_t)p] = s0;
+            if (rc[(size_t)p] != LSQ_OK || len == 0) return;
+            const int k = (int)std::min<int64_t>(nn, len);
+            klen[(size_t)p] = k;
+            pd[(size_t)p].resize((size_t)nqueries * k);
+            pi[(size_t)p].resize((size_t)nqueries * k);
+            rc[(size_t)p] = lsq_linscan(mg->ctx[(size_t)p], pd[(size_t)p].data(), pi[(size_t)p].data(), codes + s0 * m, queries, codebooks, dbnorms + s0,
+                                        nqueries, (int)len, m, h, d, k);
+            if (rc[(size_t)p] != LSQ_OK) err[(size_t)p] = lsq_last_error();      // the error string is thread-local
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int p = 0; p < G; ++p)
+        if (rc[(size_t)p] != LSQ_OK) { lsq_set_error("device shard %d: %s", p, err[(size_t)p].c_str()); return rc[(size_t)p]; }
+    // G-way merge per query; the lists are sorted by (distance, local id) and the shards are contiguous id ranges: (distance, global id) order
+    // inside a list is the same.  NaN distances (sorted last by the device scan) lose every comparison here as well.
+    auto less = [](float da, int ia, float db, int ib) {
+        const bool na = da != da, nb = db != db;
+        if (na != nb) return nb;
+        if (!na && da != db) return da < db;
+        return ia < ib;
+    };
+    const int nt = std::max(1, std::min<int>((int)std::thread::hardware_concurrency(), nqueries));
+    std::vector<std::thread> mt;
+    for (int t = 0; t < nt; ++t) {
+        mt.emplace_back([&, t]() {
+            std::vector<int> pos((size_t)G);
+            for (int q = (int)((int64_t)nqueries * t / nt); q < (int)((int64_t)nqueries * (t + 1) / nt); ++q) {
+                std::fill(pos.begin(), pos.end(), 0);
+                for (int r = 0; r < nn; ++r) {
+                    int best = -1;
+                    float bd = 0.0f;
+                    int bi = 0;
+                    for (int p = 0; p < G; ++p) {
+                        if (pos[(size_t)p] >= klen[(size_t)p]) continue;
+                        const size_t e = (size_t)q * klen[(size_t)p] + (size_t)pos[(size_t)p];
+                        const float dd = pd[(size_t)p][e];
+                        const int ii = pi[(size_t)p][e] + (int)start[(size_t)p];
+                        if (best < 0 || less(dd, ii, bd, bi)) { best = p; bd = dd; bi = ii; }
+                    }
+                    dists[(size_t)q * nn + r] = bd;
+                    idx[(size_t)q * nn + r] = bi;
+                    pos[(size_t)best] += 1;
+                }
+            }
+        });
+    }
+    for (auto &t : mt) t.join();
+    return LSQ_OK;
+}
+
 extern "C" int lsq_encoding_icm(lsq_ctx *c, const float *X, const int16_t *oldB, const float *K, int d, int64_t n, int m, int h,
                                 int niter, int randord, int npert, uint64_t seed, uint32_t it, uint64_t global_offset, int16_t *outB) {
     const int64_t one = 1;

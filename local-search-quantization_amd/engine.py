@@ -369,6 +369,18 @@ class MultiEngine:
                                                 int(seed), int(global_offset), int(bool(verbose)), Bs.ctypes.data, objs.ctypes.data))
         return Bs, objs
 
+    def linscan(self, codes, Q, K, dbnorms, m, k, h=H):
+        """the ADC scan over a database sharded across the devices; Engine.linscan's signature and results   [lsq_multi_linscan]"""
+        codes, Q, K, dbn = _np(codes, np.uint8), _np(Q, np.float32), _np(K, np.float32), _np(dbnorms, np.float32)
+        n, nq, d = codes.shape[0], Q.shape[0], Q.shape[1]
+        if codes.shape != (n, m) or K.shape != (m * h, d) or dbn.shape != (n,):
+            raise ValueError("shape mismatch: codes %s Q %s K %s dbnorms %s m=%d h=%d" % (codes.shape, Q.shape, K.shape, dbn.shape, m, h))
+        dists = np.zeros((nq, k), dtype=np.float32)
+        ids = np.zeros((nq, k), dtype=np.int32)
+        _lib.check(self._L.lsq_multi_linscan(self._h, dists.ctypes.data, ids.ctypes.data, codes.ctypes.data, Q.ctypes.data, K.ctypes.data,
+                                             dbn.ctypes.data, nq, n, m, h, d, int(k)))
+        return dists, ids
+
     def close(self):
         if self._h is not None and self._h.value:
             self._L.lsq_multi_destroy(self._h)

@@ -198,3 +198,24 @@ def test_more_queries_than_one_thresholded_batch(lsq, oracle):
     codes, Q, K, dbnorms = _case(rng, n, nq, d, m)
     st = _check(lsq, oracle, codes, Q, K, dbnorms, m, knn, expect={"exhaustive": 0, "batches": 2})
     assert st["fallback_queries"] <= 2, st          # 1e-8 per query by design
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]])
+def test_single_process_multi_device_scan(lsq, oracle, devices):
+    """lsq_multi_linscan with the one GPU listed two / three times (contexts, host threads, shards and the host merge are those of a real multi-GPU
+    node): duplicated entries tie ACROSS the shards and must come out ordered by global id; one shard is smaller than nn"""
+    rng = np.random.default_rng(51)
+    n, nq, d, m, knn = 90_001, 23, 16, 8, 300
+    codes, Q, K, dbnorms = _case(rng, n, nq, d, m, ties=True)
+    dref, iref = _reference(lsq, oracle, codes, Q, K, dbnorms, m, knn)
+    with lsq.MultiEngine(devices) as mg:
+        dists, ids = mg.linscan(codes, Q, K, dbnorms, m, knn)
+        assert np.array_equal(ids, iref) and np.array_equal(dists.view(np.uint32), dref.view(np.uint32))
+        C = [np.ascontiguousarray(K[j * H:(j + 1) * H].T) for j in range(m)]
+        d2, r2 = lsq.linscan_lsq(codes.T, Q.T, C, dbnorms, np.eye(d, dtype=np.float32), knn, engine=mg)
+        assert np.array_equal(r2.T, iref) and np.array_equal(d2.T, dref)
+        # a database smaller than nn x devices: every shard returns all of its entries
+        small = 250
+        ds, is_ = mg.linscan(codes[:small], Q, K, dbnorms[:small], m, 200)
+    dr, ir = _reference(lsq, oracle, codes[:small], Q, K, dbnorms[:small], m, 200)
+    assert np.array_equal(is_, ir) and np.array_equal(ds, dr)
