@@ -281,8 +281,9 @@ LSQ_API int lsq_quantize_norms_dev(lsq_ctx *ctx, const uint8_t *d_codes, const f
 LSQ_API int lsq_update_codebooks(const float *X, const int16_t *B, int d, int64_t n, int m, int h, int nthreads, float *K_out);
 
 /* The same update ON THE DEVICE (csrc/lsq_lsqr.hip): all d systems advanced together, the same LSQR restatement (Float32 recurrences, the long sums
- * in double, IterativeSolvers' default stopping rules).  Agrees with lsq_update_codebooks to ~1e-6 relative (the order of the double additions
- * differs), not bit for bit.  _gpu: host buffers, Julia layout as above (X d x n, B m x n Int16 1-based, K_out d x (m*h));  _dev: device buffers,
+ * in double, IterativeSolvers' default stopping rules), the rows sorted by code once per call so that S'u is added in the host's order without atomics.
+ * The same bits on every call; the same bits as lsq_update_codebooks on every tested problem (its norms are added in another order: agreement is
+ * required to 1e-5 only).  _gpu: host buffers, Julia layout as above (X d x n, B m x n Int16 1-based, K_out d x (m*h));  _dev: device buffers,
  * codes [n][m] uint8 0-BASED.  h must be 256.  iterations (optional): LSQR iterations of the slowest dimension. */
 LSQ_API int lsq_update_codebooks_gpu(lsq_ctx *ctx, const float *X, const int16_t *B, int d, int64_t n, int m, int h, float *K_out, int *iterations);
 LSQ_API int lsq_update_codebooks_dev(lsq_ctx *ctx, const float *d_X, const uint8_t *d_codes, int d, int64_t n, int m, int h, float *d_K_out,

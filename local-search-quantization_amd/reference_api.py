@@ -157,7 +157,7 @@ def eval_recall(ids_gnd, ids_predicted, k, V=False):
 def update_codebooks(X, B, h, V=False, codebook_upd_method="lsqr", *, nthreads=0, engine=None):
     """src/codebook_update.jl:52-86 -> list of m (d, h) codebooks minimising ||X - sum_j C_j[:, B_j]||^2 (LSQR).
     engine=None: the host solver (std::thread workers over the dimensions, the reference's own division of labour);
-    engine=<Engine>: the device solver (lsq_update_codebooks_gpu: all dimensions at once) -- agrees to ~1e-6, not bit for bit."""
+    engine=<Engine>: the device solver (lsq_update_codebooks_gpu: all dimensions at once) -- the same result on every tested problem (required: 1e-5)."""
     from . import _lib
     if codebook_upd_method != "lsqr":
         raise ValueError("only the reference's default method 'lsqr' is provided")

@@ -65,7 +65,7 @@ for n, d, m in [(100_000, 128, 8), (30_000, 33, 5)]:
             K1, it1 = eng.update_codebooks_dev(dX, dB, m)
             if it1 != it0 or not torch.equal(K1, K0):
                 diff += 1
-        print("lsqr n=%d d=%d m=%d: %d of %d repetitions differ in some bit (double atomics: allowed, reported)" % (n, d, m, diff, reps))
+        print("lsqr n=%d d=%d m=%d: %d of %d repetitions differ in some bit (fixed order of addition: none expected)" % (n, d, m, diff, reps))
 print("soak (scan + lsqr) done, scan mismatches so far:", bad)
 print("SOAK", "FAILED" if bad else "OK", bad)
 sys.exit(1 if bad else 0)
