@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define LSQ_VERSION 340
+#define LSQ_VERSION 400
 
 #if defined(__GNUC__)
 #define LSQ_API __attribute__((visibility("default")))
@@ -80,6 +80,9 @@ typedef struct lsq_timings {
     int64_t filter_fallback_chunks; /* resident chunks the filter handed to the f32 walk: non-finite / degenerate value ranges, more than 1/64 of the
                                 * (vector, node) pairs outside the sampled level range, or a first ILS iteration in which the filter decided too
                                 * little (since v300)                                                                   */
+    int64_t xs_launches;     /* schedule 7: launches of the XCD-cooperative kernel (since v400)                                  */
+    int64_t xs_fallback_launches; /* ... of which the start barrier turned away (the device was shared: not all 256 blocks resident, or the blocks
+                                * were not spread 32 per XCD): the block-per-range filtered walk did that launch's work instead (since v400) */
 } lsq_timings;
 
 LSQ_API const char *lsq_last_error(void);

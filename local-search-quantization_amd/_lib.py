@@ -28,7 +28,7 @@ class Timings(C.Structure):
                 ("icm_launches", C.c_int64), ("icm_node_updates", C.c_int64),
                 ("staged_blocks", C.c_int64), ("light_blocks", C.c_int64), ("filtered_blocks", C.c_int64),
                 ("filter_refined", C.c_int64), ("filter_exact", C.c_int64), ("filter_f32", C.c_int64),
-                ("filter_fallback_chunks", C.c_int64)]
+                ("filter_fallback_chunks", C.c_int64), ("xs_launches", C.c_int64), ("xs_fallback_launches", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

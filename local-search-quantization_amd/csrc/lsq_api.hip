@@ -63,6 +63,11 @@ struct lsq_ctx {
     unsigned long long *walk_counters = nullptr;       // where the walk launches accumulate their statistics (c->active, or c->probe during that first iteration)
     int64_t probe_div = 8;                             // option "filter_probe_div": after the first iteration the chunk goes to the f32 walk when
                                                        // (refined + f32-routed) * div > recomputed node updates (0 = never)
+    DevBuf xsPart, xsSync, xsErr;                      // schedule 7 (lsq_icmx.hip): ring of partial keys, the launch's sync words, the call's two error words
+    int xs_dev_ok = 0;                                 // the device has the 8 x 32 CUs the kernel's groups are laid out for
+    int64_t xs_min = 32768;                            // option "xs_min": smaller chunks take the block-per-range walk (schedule 6's kernels)
+    int64_t xs_launches = 0;
+    int64_t xs_fallback_launches = 0;                  // launches whose start barrier said no (the predicated icm_walkq_kernel launch did the work)
     DevBuf Uq, Tq, qp, qscratch, qflag, qsigma;                // 16-bit filtered walk: u16 unary planes, u16 slice tables, lsq_q16_params, bound scratch, per-vector out-of-range flags
     bool chunk_q16 = false;                            // the resident chunk runs the filtered walk (set by build_unaries from the chunk's verdict)
     int64_t fallback_div = 64;                         // option "filter_fallback_div": the chunk goes to the f32 walk when flagged pairs * div > all pairs (0 = never)
@@ -147,6 +152,7 @@ extern "C" int lsq_create(lsq_ctx **out, int device) {
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; lsq_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return LSQ_EHIP; }
     c->stream = c->own_stream;
+    c->xs_dev_ok = prop.multiProcessorCount == 256;
     *out = c;
     return LSQ_OK;
 }
@@ -157,7 +163,7 @@ extern "C" int lsq_destroy(lsq_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : c->pool) (void)hipEventDestroy(e);
-    DevBuf *bufs[] = {&c->probe, &c->Uq, &c->Tq, &c->qp, &c->qscratch, &c->qflag, &c->qsigma, &c->sci, &c->T, &c->Ts, &c->U, &c->part, &c->vCur, &c->vNew, &c->active, &c->recCur, &c->recNew, &c->prev, &c->counters, &c->obj, &c->bad,
+    DevBuf *bufs[] = {&c->xsPart, &c->xsSync, &c->xsErr, &c->probe, &c->Uq, &c->Tq, &c->qp, &c->qscratch, &c->qflag, &c->qsigma, &c->sci, &c->T, &c->Ts, &c->U, &c->part, &c->vCur, &c->vNew, &c->active, &c->recCur, &c->recNew, &c->prev, &c->counters, &c->obj, &c->bad,
                       &c->sX, &c->sX2, &c->sK, &c->sB16, &c->sOut16, &c->sTight, &c->sF32};
     for (DevBuf *b : bufs) b->release();
     lsq_adc_free(c->adc);
@@ -190,6 +196,7 @@ extern "C" int lsq_set_option(lsq_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "wave_max")) c->wave_max = (int)value;
     else if (!strcmp(key, "fallback")) c->fallback = (int)value;
     else if (!strcmp(key, "q16_min")) c->q16_min = value;
+    else if (!strcmp(key, "xs_min")) c->xs_min = value;
     else if (!strcmp(key, "per_node")) c->per_node = value != 0;
     else if (!strcmp(key, "filter_probe_div")) {
         if (value < 0) { lsq_set_error("filter_probe_div must be >= 0"); return LSQ_EINVAL; }
@@ -210,9 +217,9 @@ extern "C" int lsq_set_option(lsq_ctx *c, const char *key, int64_t value) {
     }
     else if (!strcmp(key, "schedule")) {
 #ifdef LSQ_TUNING
-        if (value < 0 || value > 6 || value == 5) { lsq_set_error("schedule must be 0..4 or 6"); return LSQ_EINVAL; }
+        if (value < 0 || value > 7 || value == 5) { lsq_set_error("schedule must be 0..4, 6 or 7"); return LSQ_EINVAL; }
 #else
-        if (value != 3 && value != 4 && value != 6) { lsq_set_error("schedule must be 3, 4 or 6 (schedules 0..2 exist in the tuning build only)"); return LSQ_EINVAL; }
+        if (value != 3 && value != 4 && value != 6 && value != 7) { lsq_set_error("schedule must be 3, 4, 6 or 7 (schedules 0..2 exist in the tuning build only)"); return LSQ_EINVAL; }
 #endif
         c->schedule = (int)value;
     } else { lsq_set_error("unknown option '%s'", key); return LSQ_EINVAL; }
@@ -238,6 +245,8 @@ extern "C" int lsq_get_timings(lsq_ctx *c, lsq_timings *out) {
     out->filter_exact = c->filter_exact;
     out->filter_f32 = c->filter_f32;
     out->filter_fallback_chunks = c->filter_fallback_chunks;
+    out->xs_launches = c->xs_launches;
+    out->xs_fallback_launches = c->xs_fallback_launches;
     return LSQ_OK;
 }
 
@@ -253,6 +262,7 @@ extern "C" int lsq_reset_timings(lsq_ctx *c) {
     for (double &v : c->cat_ms) v = 0.0;
     c->icm_launches = c->icm_node_updates = c->staged_blocks = c->light_blocks = c->filtered_blocks = c->filter_refined = c->filter_exact = c->filter_f32 = 0;
     c->filter_fallback_chunks = 0;
+    c->xs_launches = c->xs_fallback_launches = 0;
     for (int64_t &v : c->trace) v = 0;
     c->adc_stats = lsq_linscan_stats{};
     return LSQ_OK;
@@ -370,7 +380,7 @@ static int prepare_tables(lsq_ctx *c, const float *dK, int d, int m) {
 }
 
 // unaries of rows [r0, r0 + rows) of a cn-vector chunk (dX points at the chunk's first vector)
-static bool use_q16(const lsq_ctx *c, int64_t cn) { return c->schedule == 6 && cn >= c->q16_min; }
+static bool use_q16(const lsq_ctx *c, int64_t cn) { return c->schedule >= 6 && cn >= c->q16_min; }
 
 static int build_unaries(lsq_ctx *c, const float *dX, const float *dK, int d, int64_t cn, int m, int slice, int64_t r0, int64_t rows) {
     c->chunk_q16 = false;
@@ -463,11 +473,21 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t c
             // 16-bit filtered walk on the level planes of this chunk (build_unaries read the chunk's verdict); 64 node updates per launch
             const lsq_q16_params *P = c->qp.as<lsq_q16_params>();
             const size_t per_launch = c->per_node ? 1 : 64;
+            // schedule 7: the slices of a node spread over the CUs of an XCD (lsq_icmx.hip).  Its start barrier may turn a launch away (another
+            // process' kernels on the device: not all 256 blocks resident): the filtered walk behind it is predicated on that verdict.
+            const bool xs = c->schedule == 7 && c->xs_dev_ok && cn >= c->xs_min && lsq_icm_xs_applies(cn, m) && !c->per_node;
             for (size_t done = 0; done < seq.size(); done += per_launch) {
                 const int cntn = (int)std::min<size_t>(per_launch, seq.size() - done);
+                const unsigned *gate = nullptr;
+                if (xs)
+                    LSQ_TRY(lsq_launch_icm_xs(c->stream, c->U.as<float>(), c->Uq.as<uint16_t>(), c->Tq.as<uint16_t>(), c->T.as<float>(), rec, valid, cn, m,
+                                              seq.data() + done, cntn, (int)done, c->skip, c->walk_counters, c->fallback ? ref_rec : nullptr,
+                                              c->fallback ? ref_valid : nullptr, P, c->qflag.as<unsigned short>(), &c->xsPart, &c->xsSync,
+                                              c->xsErr.as<unsigned>(), &gate));
+                if (xs) c->xs_launches += 1;
                 LSQ_TRY(lsq_launch_icm_walkq(c->stream, c->U.as<float>(), c->Uq.as<uint16_t>(), c->Tq.as<uint16_t>(), c->T.as<float>(), rec, valid, cn, m,
                                              seq.data() + done, cntn, (int)done, c->skip, c->walk_counters, c->light,
-                                             c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr, P, c->qflag.as<unsigned short>()));
+                                             c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr, P, c->qflag.as<unsigned short>(), gate));
             }
             c->icm_launches += ((int64_t)seq.size() + (int64_t)per_launch - 1) / (int64_t)per_launch;
             return LSQ_OK;
@@ -517,8 +537,8 @@ static int encode_chunk(lsq_ctx *c, const float *dXc, const float *dK, int64_t c
     if (I == 1) { c->sticky_n = cn; c->sticky_d = P.d; c->sticky_m = P.m; }
     LSQ_TRY(c->recNew.ensure((size_t)cn * cs));
     LSQ_TRY(c->prev.ensure(sizeof(float) * (size_t)cn));
-    LSQ_TRY(c->vCur.ensure(sizeof(unsigned short) * (size_t)cn));
-    LSQ_TRY(c->vNew.ensure(sizeof(unsigned short) * (size_t)cn));
+    LSQ_TRY(c->vCur.ensure(sizeof(unsigned short) * (size_t)(cn + 8)));      // + 8: icm_xs_kernel's lister reads the words four at a time
+    LSQ_TRY(c->vNew.ensure(sizeof(unsigned short) * (size_t)(cn + 8)));
     LSQ_HIP(hipMemsetAsync(c->vCur.p, 0, sizeof(unsigned short) * (size_t)cn, c->stream));      // nothing is known to be an argmin yet
     unsigned short *vcur = c->vCur.as<unsigned short>(), *vnew = c->vNew.as<unsigned short>();
     uint8_t *cur = c->recCur.as<uint8_t>(), *nw = c->recNew.as<uint8_t>();
@@ -587,6 +607,21 @@ static int validate_encode(const char *fn, int d, int64_t n, int m, int h, const
     return LSQ_OK;
 }
 
+// schedule 7's per-call error words: [0] = give-up code of any icm_xs_kernel launch, [1] = launches its start barrier turned away
+static int xs_begin(lsq_ctx *c) {
+    LSQ_TRY(c->xsErr.ensure(2 * sizeof(unsigned)));
+    LSQ_HIP(hipMemsetAsync(c->xsErr.p, 0, 2 * sizeof(unsigned), c->stream));
+    return LSQ_OK;
+}
+static int xs_verdict(lsq_ctx *c, const unsigned (&xs_err)[2]) {      // after the stream has been synchronised
+    c->xs_fallback_launches += (int64_t)xs_err[1];
+    if (xs_err[0] != 0u) {        // never silently: a wait inside a schedule-7 launch gave up (a lost block, a protocol fault): this call's codes are invalid
+        lsq_set_error("icm_xs_kernel gave up waiting (code %u): the codes of this call are invalid; option \"schedule\" = 6 avoids the kernel", xs_err[0]);
+        return LSQ_EHIP;
+    }
+    return LSQ_OK;
+}
+
 static int begin_call(lsq_ctx *c, int64_t I, int nr) {
     LSQ_TRY(c->counters.ensure(sizeof(unsigned long long) * 2 * (size_t)std::max<int64_t>(I, 1)));
     LSQ_TRY(c->obj.ensure(sizeof(double) * (size_t)std::max(nr, 1)));
@@ -598,6 +633,7 @@ static int begin_call(lsq_ctx *c, int64_t I, int nr) {
     LSQ_HIP(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long) * 2 * (size_t)std::max<int64_t>(I, 1), c->stream));
     LSQ_HIP(hipMemsetAsync(c->obj.p, 0, sizeof(double) * (size_t)std::max(nr, 1), c->stream));
     LSQ_HIP(hipMemsetAsync(c->bad.p, 0, sizeof(int), c->stream));
+    LSQ_TRY(xs_begin(c));
     return LSQ_OK;
 }
 
@@ -619,8 +655,11 @@ static int finish_call(lsq_ctx *c, int64_t I, int nr, double *obj_sums, int64_t 
     LSQ_HIP(hipMemcpyAsync(cnt.data(), c->counters.p, sizeof(unsigned long long) * cnt.size(), hipMemcpyDeviceToHost, c->stream));
     unsigned long long act[LSQ_WALK_COUNTERS] = {0};
     LSQ_HIP(hipMemcpyAsync(act, c->active.p, sizeof(act), hipMemcpyDeviceToHost, c->stream));
+    unsigned xs_err[2] = {0u, 0u};
+    LSQ_HIP(hipMemcpyAsync(xs_err, c->xsErr.p, sizeof(xs_err), hipMemcpyDeviceToHost, c->stream));
     LSQ_HIP(hipStreamSynchronize(c->stream));
     fold_walk_counters(c, act);
+    LSQ_TRY(xs_verdict(c, xs_err));
     if (I == 1 && c->call_q16_chunks > 0 && c->probe_div > 0) {      // the whole call was its own probe: remember the answer for the next call of this shape
         const unsigned long long hard = act[4 + LSQ_WALK_TRACE] + act[4 + LSQ_WALK_TRACE + 2];
         c->sticky_bad = ((long double)hard * (long double)c->probe_div > (long double)act[0]) ? 1 : 0;
@@ -933,10 +972,11 @@ extern "C" int lsq_encode_icm_fully(lsq_ctx *c, int16_t *B, const float *X, cons
     LSQ_TRY(use_device(c));
     LSQ_TRY(check_shape("lsq_encode_icm_fully", d, n, m, h));
     if (!K || niter < 0 || npert < 0 || idx_first < 1 || (n > 0 && (!B || !X))) { lsq_set_error("lsq_encode_icm_fully: bad arguments"); return LSQ_EINVAL; }
-    const bool autoit = it == LSQ_IT_AUTO;
-    if (autoit) { it = c->auto_it; if (c->auto_it < LSQ_IT_AUTO - 1u) ++c->auto_it; }
+    const bool autoit = it == LSQ_IT_AUTO;      // the context's counter advances only when the call succeeds (as in lsq_encoding_icm)
+    if (autoit) it = c->auto_it;
     if (n == 0) return LSQ_OK;
     if (n > c->chunk) { lsq_set_error("lsq_encode_icm_fully: n = %lld exceeds the resident chunk (%lld); raise option \"chunk\"", (long long)n, (long long)c->chunk); return LSQ_EINVAL; }
+    LSQ_TRY(xs_begin(c));
     LSQ_TRY(upload_xk(c, X, K, d, n, m));
     LSQ_TRY(upload_codes(c, B, n, m, h, c->recCur));
     LSQ_TRY(prepare_tables(c, c->sK.as<float>(), d, m));
@@ -946,14 +986,18 @@ extern "C" int lsq_encode_icm_fully(lsq_ctx *c, int16_t *B, const float *X, cons
     LSQ_TRY(c->recNew.ensure((size_t)n * lsq_code_stride(m)));
     int32_t order[LSQ_MAX_M];
     LSQ_TRY(lsq_node_order(seed, it, m, randord, order));
-    LSQ_TRY(c->vNew.ensure(sizeof(unsigned short) * (size_t)n));
+    LSQ_TRY(c->vNew.ensure(sizeof(unsigned short) * (size_t)(n + 8)));
     LSQ_TRY(c->active.ensure(sizeof(unsigned long long) * LSQ_WALK_COUNTERS));
     LSQ_HIP(hipMemsetAsync(c->vNew.p, 0, sizeof(unsigned short) * (size_t)n, c->stream));
     LSQ_TRY(lsq_launch_perturb(c->stream, c->recCur.as<uint8_t>(), c->recNew.as<uint8_t>(), n, m, npert, seed, it, (uint64_t)(idx_first - 1), nullptr, nullptr));
     LSQ_TRY(run_sweeps(c, c->recNew.as<uint8_t>(), c->vNew.as<unsigned short>(), n, m, order, niter));
     LSQ_TRY(lsq_launch_codes_to_i16(c->stream, c->recNew.as<uint8_t>(), n, m, c->sB16.as<int16_t>()));
     LSQ_HIP(hipMemcpyAsync(B, c->sB16.p, sizeof(int16_t) * (size_t)n * m, hipMemcpyDeviceToHost, c->stream));
+    unsigned xs_err[2] = {0u, 0u};
+    LSQ_HIP(hipMemcpyAsync(xs_err, c->xsErr.p, sizeof(xs_err), hipMemcpyDeviceToHost, c->stream));
     LSQ_HIP(hipStreamSynchronize(c->stream));
+    LSQ_TRY(xs_verdict(c, xs_err));
+    if (autoit && c->auto_it < LSQ_IT_AUTO - 1u) ++c->auto_it;
     return LSQ_OK;
 }
 

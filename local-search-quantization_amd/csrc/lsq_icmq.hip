@@ -30,10 +30,7 @@
 
 #include <type_traits>
 
-#include "lsq_wave.h"
-
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#include "lsq_q16.h"
 
 #ifdef LSQ_TUNING
 __device__ unsigned long long *g_walkq_dbg = nullptr;      // [launch slot][block][16] timestamps (tools only)
@@ -47,27 +44,6 @@ __device__ unsigned long long *g_walkq_blk = nullptr;       // [block][2] start 
 #endif
 
 namespace {
-
-__device__ inline uint32_t pk_add_u16(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b));      // v_pk_add_u16
-}
-__device__ inline uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
-__device__ inline uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
-// smallest / middle of three (v_min3_u32 / v_med3_u32): the two smallest of a triple in two instructions
-__device__ inline uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) { uint32_t r; asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-__device__ inline uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) { uint32_t r; asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-// two smallest of the union of two (lo <= hi) pairs
-__device__ inline void top2_merge(uint32_t &lo, uint32_t &hi, uint32_t olo, uint32_t ohi) {
-    const uint32_t nhi = umin3(umax(lo, olo), hi, ohi);
-    lo = umin(lo, olo);
-    hi = nhi;
-}
-// quad permutations only (every source lane exists): old = 0 + bound_ctrl lets the compiler fold the permutation into the consuming
-// v_min_u32 / v_max_u32 (4 instructions per top2_merge stage instead of 7 with a self-referencing old operand)
-template <int CTRL>
-__device__ inline uint32_t dpp_u32(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
-}
 
 // ---- parameters -----------------------------------------------------------------------------------------------------------------
 // Shifts that are the same for every candidate of a node update cannot change its argmin, so they need no level range.  A table row T[j][k][b][:]
@@ -301,21 +277,6 @@ __global__ __launch_bounds__(256) void tables_to_q16_slices_kernel(const float *
     reinterpret_cast<u32x4 *>(Tq)[e] = (u32x4){w[0], w[1], w[2], w[3]};
 }
 
-// exact f32 conditioned value of candidate a of node j for vector i (canonical order, encode_icm.jl:84-101), from the f32 unaries
-template <int M, int RW>
-__device__ inline float q16_exact_value(const float *__restrict__ U, const float *__restrict__ T, int64_t n, int SLF, int j, int64_t i,
-                            const uint32_t (&rw)[RW], int a) {
-    float s = U[(int64_t)j * n * LSQ_H + ((int64_t)(a / SLF) * n + i) * SLF + (a % SLF)];
-    const float *Tj = T + (int64_t)j * M * LSQ_H * LSQ_H;
-#pragma unroll
-    for (int k = 0; k < M; ++k) {
-        if (k == j) continue;
-        const uint32_t bk = (rw[k >> 2] >> (8 * (k & 3))) & 0xffu;
-        s = s + Tj[((int64_t)(k * LSQ_H) + bk) * LSQ_H + a];
-    }
-    return s;
-}
-
 // Exact refinement of the block's ambiguous vectors (records arec[0 .. namb): {ci | a1 << 16 | a2 << 24, limit, record words}, written by
 // the decide phase): 16 lanes per vector, 4 vectors per wave at a time.  ONE dependent global round trip in the common case:
 //   * lane t recomputes the level sums of candidates [16 t, 16 t + 16) from the u16 planes and the u16 slice tables (the codes come from
@@ -452,30 +413,14 @@ __device__ inline int q16_refine(const float *__restrict__ U, const uint16_t *__
 // Block / pass / node structure, compaction of the active vectors, light blocks and the validity bookkeeping are those of
 // icm_walk_kernel; the slice walk runs on 16-bit levels (slices of SLQ = 32 candidates for m <= 8, 16 above: the same 64 / 32-byte
 // pieces and the same LDS table footprint as the f32 walk, half as many slices).
-// LDS placement of a slice table.  A lane owns CPL = 8 NR candidates of its vector's slice: NR 16-byte chunks, chunk c = r LPV + q (r-th read of
-// lane q).  The table is stored as NR planes (plane r = the chunks every lane reads r-th, LPV per row), later planes skewed by 128 bytes:
-// the layout tools/ubench_lds.hip measured best for two lanes per vector (NR = 1: plain rows).  Global Tq keeps plain rows.
-template <int SLQ, int CPL>
-struct WalkqTab {
-    static constexpr int NR = CPL / 8, LPV = SLQ / CPL, EPR = SLQ / 8;                      // reads per lane and table / lanes per vector / entries per row
-    static constexpr int PLANE_E = LSQ_H * LPV + (NR > 1 ? 8 : 0), TS_E = NR * PLANE_E;     // 16-byte entries per plane / per table
-    __device__ static constexpr int entry(int kk, int code, int c) { return kk * TS_E + (c / LPV) * PLANE_E + code * LPV + (c % LPV); }
-    static constexpr int lds_entries(int m) { return (m - 1) * TS_E; }
-    // vectors per block pass with BPC blocks per CU: the slice table + 10 B per vector within the block's share of the 160 KiB
-    static constexpr int pp(int m, int bpc) {
-        const int avail = 160 * 1024 / bpc - 768 - lds_entries(m) * 16;
-        const int v = avail / 10 / 64 * 64;
-        return v > 4096 / bpc ? 4096 / bpc : v;
-    }
-};
-
 template <int M, int SLQ, int CPL, int DEPTH, int NT, int BPC>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BPC / 4, NT / 64 * BPC / 4))) void icm_walkq_kernel(const float *__restrict__ U, const uint16_t *__restrict__ Uq, const uint16_t *__restrict__ Tq,
                                                        const float *__restrict__ T, uint8_t *__restrict__ rec, unsigned short *__restrict__ valid,
                                                        int64_t n, const WalkNodes nodes, int per_pass, int use_skip, int direct_max,
                                                        unsigned long long *__restrict__ active_total,
                                                        const uint8_t *__restrict__ ref_rec, const unsigned short *__restrict__ ref_valid,
-                                                       const lsq_q16_params *__restrict__ P, int SLF, const unsigned short *__restrict__ qflag, int abl) {
+                                                       const lsq_q16_params *__restrict__ P, int SLF, const unsigned short *__restrict__ qflag, int abl,
+                                                       const unsigned *__restrict__ gate) {
     constexpr int CS = (M <= 8) ? 8 : 16;
     constexpr int NS = LSQ_H / SLQ;
     using TL = WalkqTab<SLQ, CPL>;
@@ -489,6 +434,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
     constexpr int LTAB = TL::lds_entries(M);             // ... in LDS (planes, skew)
     constexpr int PP = TL::pp(M, BPC);                   // BPC = 1: the f32 walk's geometry (4096 up to m = 14); BPC = 2: two 512-thread blocks share a CU
     if (P->ok == 0) return;                              // never launched in that case (the host read the verdict after the GEMM); kept as a guard
+    if (gate && *gate != 2u) return;                     // stand-in of an icm_xs_kernel launch (lsq_icmx.hip): runs only when that launch's start barrier said no
 #ifdef LSQ_TUNING
     unsigned long long *dbgp = nullptr;
     if (g_walkq_dbg) {
@@ -961,7 +907,7 @@ int lsq_launch_q16_prepare(hipStream_t s, const float *X, int64_t n, int d, cons
 template <int M, int SLQ, int CPL, int DEPTH, int NT, int BPC>
 static int launch_walkq_t(hipStream_t s, const float *U, const uint16_t *Uq, const uint16_t *Tq, const float *T, uint8_t *rec, unsigned short *valid,
                           int64_t n, const WalkNodes &nodes, int use_skip, unsigned long long *active_total, int light,
-                          const uint8_t *ref_rec, const unsigned short *ref_valid, const lsq_q16_params *P, const unsigned short *qflag) {
+                          const uint8_t *ref_rec, const unsigned short *ref_valid, const lsq_q16_params *P, const unsigned short *qflag, const unsigned *gate) {
     constexpr int PP = WalkqTab<SLQ, CPL>::pp(M, BPC);
     constexpr int LDS_BYTES = WalkqTab<SLQ, CPL>::lds_entries(M) * 16 + PP * 8 + PP * 2;      // slice table (planes, skew) + two smallest keys + active list
     static_assert((LDS_BYTES + 768) * BPC <= 160 * 1024, "slice table + keys must fit the block's share of the 160 KiB LDS");
@@ -976,7 +922,7 @@ static int launch_walkq_t(hipStream_t s, const float *U, const uint16_t *Uq, con
     LSQ_TRY(optin_lds(optin, &icm_walkq_kernel<M, SLQ, CPL, DEPTH, NT, BPC>, LDS_BYTES));
     const unsigned grid = (unsigned)(npass < NBLK ? npass : NBLK);
     hipLaunchKernelGGL((icm_walkq_kernel<M, SLQ, CPL, DEPTH, NT, BPC>), dim3(grid), dim3(NT), LDS_BYTES, s, U, Uq, Tq, T, rec, valid, n, nodes, per_pass, skip,
-                       direct_max, active_total, skip ? ref_rec : nullptr, skip ? ref_valid : nullptr, P, lsq_walk_slice_width(M), qflag, LSQ_KNOB("LSQ_Q16_ABL", 0));
+                       direct_max, active_total, skip ? ref_rec : nullptr, skip ? ref_valid : nullptr, P, lsq_walk_slice_width(M), qflag, LSQ_KNOB("LSQ_Q16_ABL", 0), gate);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }
@@ -984,7 +930,7 @@ static int launch_walkq_t(hipStream_t s, const float *U, const uint16_t *Uq, con
 // the filtered counterpart of lsq_launch_icm_walk (the caller has read the chunk's verdict on the host)
 int lsq_launch_icm_walkq(hipStream_t s, const float *U, const uint16_t *Uq, const uint16_t *Tq, const float *T, uint8_t *rec, unsigned short *valid,
                          int64_t n, int m, const int32_t *order, int nnodes, int pos0, int use_skip, unsigned long long *active_total, int light,
-                         const uint8_t *ref_rec, const unsigned short *ref_valid, const lsq_q16_params *P, const unsigned short *qflag) {
+                         const uint8_t *ref_rec, const unsigned short *ref_valid, const lsq_q16_params *P, const unsigned short *qflag, const unsigned *gate) {
     if (n <= 0 || nnodes <= 0) return LSQ_OK;
     if (m < 1 || m > LSQ_MAX_M) { lsq_set_error("m = %d out of range 1..16", m); return LSQ_EINVAL; }
     for (int done = 0; done < nnodes; done += LSQ_WALK_MAX_NODES) {
@@ -996,7 +942,7 @@ int lsq_launch_icm_walkq(hipStream_t s, const float *U, const uint16_t *Uq, cons
             if (j < 0 || j >= m) { lsq_set_error("node %d out of range 0..%d", j, m - 1); return LSQ_EINVAL; }
             nodes.j[t] = (uint8_t)j;
         }
-#define LSQ_WQ_ARGS s, U, Uq, Tq, T, rec, valid, n, nodes, use_skip, active_total, light, ref_rec, ref_valid, P, qflag
+#define LSQ_WQ_ARGS s, U, Uq, Tq, T, rec, valid, n, nodes, use_skip, active_total, light, ref_rec, ref_valid, P, qflag, gate
 #define LSQ_WQ_CASE(MM, SLL, CPLL, DD, NTT) case MM: LSQ_TRY((launch_walkq_t<MM, SLL, CPLL, DD, NTT, 1>(LSQ_WQ_ARGS))); break;
 #define LSQ_WQ_CASE2(MM, SLL, CPLL, DD, NTT) case MM: LSQ_TRY((launch_walkq_t<MM, SLL, CPLL, DD, NTT, 2>(LSQ_WQ_ARGS))); break;
         // m <= 8: slices of 32 candidates, four lanes per vector (8 candidates per lane); above: slices of 16, two lanes of 8

@@ -181,7 +181,17 @@ int lsq_launch_q16_prepare(hipStream_t s, const float *X, int64_t n, int d, cons
 // rowmin [m*m*256], means [m*d], colmean [m*m*256], colshift [m*256] (per call), sigma [n*m] (per chunk); trange: 3 floats per pair table
 int lsq_launch_icm_walkq(hipStream_t s, const float *U, const uint16_t *Uq, const uint16_t *Tq, const float *T, uint8_t *rec, unsigned short *valid,
                          int64_t n, int m, const int32_t *order, int nnodes, int pos0, int use_skip, unsigned long long *active_total, int light,
-                         const uint8_t *ref_rec, const unsigned short *ref_valid, const lsq_q16_params *P, const unsigned short *qflag);
+                         const uint8_t *ref_rec, const unsigned short *ref_valid, const lsq_q16_params *P, const unsigned short *qflag,
+                         const unsigned *gate = nullptr);
+// gate (optional, device): the launch is the stand-in of an icm_xs_kernel launch and runs only when *gate == 2 (that launch's start barrier said no)
+// Schedule 7 (lsq_icmx.hip): the slices of a node spread over the CUs of an XCD, walker / lister / merger waves.  Same contract as
+// lsq_launch_icm_walkq for <= LSQ_WALK_MAX_NODES (64) node updates; part / syncb: work buffers owned by the context; err: two words zeroed
+// at the start of the call ([0] = give-up code of any launch, [1] = launches turned away by their start barrier); *gate_word: see above.
+bool lsq_icm_xs_applies(int64_t n, int m);
+int lsq_launch_icm_xs(hipStream_t s, const float *U, const uint16_t *Uq, const uint16_t *Tq, const float *T, uint8_t *rec, unsigned short *valid,
+                      int64_t n, int m, const int32_t *order, int nnodes, int pos0, int use_skip, unsigned long long *active_total,
+                      const uint8_t *ref_rec, const unsigned short *ref_valid, const lsq_q16_params *P, const unsigned short *qflag,
+                      DevBuf *part, DevBuf *syncb, unsigned *err, const unsigned **gate_word);
 // ref_rec / ref_valid (optional, read-only): the vectors' current records and their validity masks; a candidate that becomes
 // equal to its current record inherits those bits (exact: validity depends on the code tuple only)
 // light: blocks with <= light active vectors gather table columns from L2 instead of staging slices (-1 = default 256)

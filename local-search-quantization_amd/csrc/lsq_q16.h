@@ -1,0 +1,69 @@
+// lsq_q16.h -- pieces shared by the two 16-bit FILTERED node-update kernels (lsq_icmq.hip: one block walks all slices of its vectors;
+// lsq_icmx.hip: the slices of a node are spread over the CUs of an XCD).  gfx950 only; not a public header.
+#pragma once
+
+#include "lsq_wave.h"
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+
+__device__ inline uint32_t pk_add_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b));      // v_pk_add_u16
+}
+__device__ inline uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ inline uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+// smallest / middle of three (v_min3_u32 / v_med3_u32): the two smallest of a triple in two instructions
+__device__ inline uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) { uint32_t r; asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ inline uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) { uint32_t r; asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// two smallest of the union of two (lo <= hi) pairs
+__device__ inline void top2_merge(uint32_t &lo, uint32_t &hi, uint32_t olo, uint32_t ohi) {
+    const uint32_t nhi = umin3(umax(lo, olo), hi, ohi);
+    lo = umin(lo, olo);
+    hi = nhi;
+}
+// quad permutations only (every source lane exists): old = 0 + bound_ctrl lets the compiler fold the permutation into the consuming
+// v_min_u32 / v_max_u32 (4 instructions per top2_merge stage instead of 7 with a self-referencing old operand)
+template <int CTRL>
+__device__ inline uint32_t dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+
+
+// exact f32 conditioned value of candidate a of node j for vector i (canonical order, encode_icm.jl:84-101), from the f32 unaries
+template <int M, int RW>
+__device__ inline float q16_exact_value(const float *__restrict__ U, const float *__restrict__ T, int64_t n, int SLF, int j, int64_t i,
+                            const uint32_t (&rw)[RW], int a) {
+    float s = U[(int64_t)j * n * LSQ_H + ((int64_t)(a / SLF) * n + i) * SLF + (a % SLF)];
+    const float *Tj = T + (int64_t)j * M * LSQ_H * LSQ_H;
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+        if (k == j) continue;
+        const uint32_t bk = (rw[k >> 2] >> (8 * (k & 3))) & 0xffu;
+        s = s + Tj[((int64_t)(k * LSQ_H) + bk) * LSQ_H + a];
+    }
+    return s;
+}
+
+
+// LDS placement of a slice table.  A lane owns CPL = 8 NR candidates of its vector's slice: NR 16-byte chunks, chunk c = r LPV + q (r-th read of
+// lane q).  The table is stored as NR planes (plane r = the chunks every lane reads r-th, LPV per row), later planes skewed by 128 bytes:
+// the layout tools/ubench_lds.hip measured best for two lanes per vector (NR = 1: plain rows).  Global Tq keeps plain rows.
+template <int SLQ, int CPL>
+struct WalkqTab {
+    static constexpr int NR = CPL / 8, LPV = SLQ / CPL, EPR = SLQ / 8;                      // reads per lane and table / lanes per vector / entries per row
+    static constexpr int PLANE_E = LSQ_H * LPV + (NR > 1 ? 8 : 0), TS_E = NR * PLANE_E;     // 16-byte entries per plane / per table
+    __device__ static constexpr int entry(int kk, int code, int c) { return kk * TS_E + (c / LPV) * PLANE_E + code * LPV + (c % LPV); }
+    static constexpr int lds_entries(int m) { return (m - 1) * TS_E; }
+    // vectors per block pass with BPC blocks per CU: the slice table + 10 B per vector within the block's share of the 160 KiB
+    static constexpr int pp(int m, int bpc) {
+        const int avail = 160 * 1024 / bpc - 768 - lds_entries(m) * 16;
+        const int v = avail / 10 / 64 * 64;
+        return v > 4096 / bpc ? 4096 / bpc : v;
+    }
+};
+
+
+}  // namespace
