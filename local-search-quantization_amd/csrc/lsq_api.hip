@@ -58,7 +58,7 @@ struct lsq_ctx {
     int skip = 1;            // schedule 3: skip node updates whose inputs did not change (exact memoisation)
     uint32_t auto_it = 0;    // ILS-iteration counter of the CPU-shaped entry points called with it = LSQ_IT_AUTO: advances by one per call
     // workspace
-    DevBuf sci, T, Ts, U, part, vCur, vNew, active, recCur, recNew, prev, counters, obj, bad;
+    DevBuf sci, T, Ts, U, vCur, vNew, active, recCur, recNew, prev, counters, obj, bad;
     DevBuf probe;                                      // walk counters of a chunk's FIRST ILS iteration on the filtered path (read back: is the filter paying off?)
     unsigned long long *walk_counters = nullptr;       // where the walk launches accumulate their statistics (c->active, or c->probe during that first iteration)
     int64_t probe_div = 8;                             // option "filter_probe_div": after the first iteration the chunk goes to the f32 walk when
@@ -163,7 +163,7 @@ extern "C" int lsq_destroy(lsq_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : c->pool) (void)hipEventDestroy(e);
-    DevBuf *bufs[] = {&c->xsPart, &c->xsSync, &c->xsErr, &c->probe, &c->Uq, &c->Tq, &c->qp, &c->qscratch, &c->qflag, &c->qsigma, &c->sci, &c->T, &c->Ts, &c->U, &c->part, &c->vCur, &c->vNew, &c->active, &c->recCur, &c->recNew, &c->prev, &c->counters, &c->obj, &c->bad,
+    DevBuf *bufs[] = {&c->xsPart, &c->xsSync, &c->xsErr, &c->probe, &c->Uq, &c->Tq, &c->qp, &c->qscratch, &c->qflag, &c->qsigma, &c->sci, &c->T, &c->Ts, &c->U, &c->vCur, &c->vNew, &c->active, &c->recCur, &c->recNew, &c->prev, &c->counters, &c->obj, &c->bad,
                       &c->sX, &c->sX2, &c->sK, &c->sB16, &c->sOut16, &c->sTight, &c->sF32};
     for (DevBuf *b : bufs) b->release();
     lsq_adc_free(c->adc);
@@ -217,9 +217,9 @@ extern "C" int lsq_set_option(lsq_ctx *c, const char *key, int64_t value) {
     }
     else if (!strcmp(key, "schedule")) {
 #ifdef LSQ_TUNING
-        if (value < 0 || value > 7 || value == 5) { lsq_set_error("schedule must be 0..4, 6 or 7"); return LSQ_EINVAL; }
+        if (value != 3 && value != 4 && value != 6 && value != 7) { lsq_set_error("schedule must be 3, 4, 6 or 7"); return LSQ_EINVAL; }
 #else
-        if (value != 3 && value != 4 && value != 6 && value != 7) { lsq_set_error("schedule must be 3, 4, 6 or 7 (schedules 0..2 exist in the tuning build only)"); return LSQ_EINVAL; }
+        if (value != 3 && value != 4 && value != 6) { lsq_set_error("schedule must be 3, 4 or 6 (schedule 7 -- a measured, not adopted experiment -- exists in the tuning build only)"); return LSQ_EINVAL; }
 #endif
         c->schedule = (int)value;
     } else { lsq_set_error("unknown option '%s'", key); return LSQ_EINVAL; }
@@ -357,9 +357,6 @@ static int check_codes_host(const char *fn, const int16_t *B, int64_t n, int m, 
 
 // ---- device core ----------------------------------------------------------------------------------
 static int u_slice_width(const lsq_ctx *c, int m) {      // layout of the unary planes for the active schedule
-#ifdef LSQ_TUNING
-    if (c->schedule < 3) return c->schedule == 2 ? lsq_slice_width(m) : 0;
-#endif
     return lsq_walk_slice_width(m);
 }
 
@@ -444,26 +441,6 @@ static int build_unaries(lsq_ctx *c, const float *dX, const float *dK, int d, in
 static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t cn, int m, const int32_t *order, int nsweeps,
                       const uint8_t *ref_rec = nullptr, const unsigned short *ref_valid = nullptr) {
     Timer t(c, CAT_ICM);
-#ifdef LSQ_TUNING
-    if (c->schedule < 3) {
-        if (c->schedule == 1) {
-            LSQ_TRY(lsq_launch_icm_fused(c->stream, c->U.as<float>(), c->T.as<float>(), rec, cn, m, order, nsweeps));
-            c->icm_launches += 1;
-        } else {
-            if (c->schedule == 2) LSQ_TRY(c->part.ensure(sizeof(float2) * (size_t)cn * (LSQ_H / lsq_slice_width(m))));
-            for (int sw = 0; sw < nsweeps; ++sw)
-                for (int q = 0; q < m; ++q) {
-                    const int j = order[q];
-                    const float *Uj = c->U.as<float>() + (int64_t)j * cn * LSQ_H;
-                    if (c->schedule == 2) LSQ_TRY(lsq_launch_icm_slice(c->stream, Uj, c->T.as<float>(), rec, c->part.as<float2>(), cn, m, j));
-                    else LSQ_TRY(lsq_launch_icm_node(c->stream, Uj, c->T.as<float>(), rec, cn, m, j));
-                }
-            c->icm_launches += (int64_t)nsweeps * m;
-        }
-        c->icm_node_updates += cn * (int64_t)nsweeps * m;
-        return LSQ_OK;
-    }
-#endif
     if (c->schedule >= 4) {
         // the whole ILS iteration (nsweeps x m node updates) in ONE launch: a block owns its vectors throughout
         std::vector<int32_t> seq((size_t)nsweeps * m);
@@ -475,15 +452,21 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t c
             const size_t per_launch = c->per_node ? 1 : 64;
             // schedule 7: the slices of a node spread over the CUs of an XCD (lsq_icmx.hip).  Its start barrier may turn a launch away (another
             // process' kernels on the device: not all 256 blocks resident): the filtered walk behind it is predicated on that verdict.
+#ifdef LSQ_TUNING
             const bool xs = c->schedule == 7 && c->xs_dev_ok && cn >= c->xs_min && lsq_icm_xs_applies(cn, m) && !c->per_node;
+#else
+            const bool xs = false;
+#endif
             for (size_t done = 0; done < seq.size(); done += per_launch) {
                 const int cntn = (int)std::min<size_t>(per_launch, seq.size() - done);
                 const unsigned *gate = nullptr;
+#ifdef LSQ_TUNING
                 if (xs)
                     LSQ_TRY(lsq_launch_icm_xs(c->stream, c->U.as<float>(), c->Uq.as<uint16_t>(), c->Tq.as<uint16_t>(), c->T.as<float>(), rec, valid, cn, m,
                                               seq.data() + done, cntn, (int)done, c->skip, c->walk_counters, c->fallback ? ref_rec : nullptr,
                                               c->fallback ? ref_valid : nullptr, P, c->qflag.as<unsigned short>(), &c->xsPart, &c->xsSync,
                                               c->xsErr.as<unsigned>(), &gate));
+#endif
                 if (xs) c->xs_launches += 1;
                 LSQ_TRY(lsq_launch_icm_walkq(c->stream, c->U.as<float>(), c->Uq.as<uint16_t>(), c->Tq.as<uint16_t>(), c->T.as<float>(), rec, valid, cn, m,
                                              seq.data() + done, cntn, (int)done, c->skip, c->walk_counters, c->light,
@@ -638,7 +621,6 @@ static int begin_call(lsq_ctx *c, int64_t I, int nr) {
 }
 
 static void fold_walk_counters(lsq_ctx *c, const unsigned long long *act) {
-    if (c->schedule < 3) return;
     c->icm_node_updates += (int64_t)act[0];
     c->staged_blocks += (int64_t)act[1];
     c->light_blocks += (int64_t)act[2];

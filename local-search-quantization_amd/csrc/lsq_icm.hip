@@ -17,8 +17,7 @@
 //   Ts  [m][256/SL][m-1][256][SL] f32: the same columns regrouped per slice (one contiguous block per staged slice)
 //   rec [n][cs] u8        code records, cs = 8 (m <= 8) or 16: one aligned 8/16-byte load
 //   X   [n][d] f32,  K [m*256][d] f32  (the Julia buffers, read in place)
-// The three earlier schedules (per-node L2 gathers, fused sweeps, slices + combine) live in lsq_icm_legacy.hip and are
-// compiled into the tuning build only.
+// (The three schedules of round 1 -- per-node L2 gathers, fused sweeps, slices + combine -- were removed in round 4; `git log` has them.)
 #include <stdlib.h>
 
 #include <mutex>

@@ -30,6 +30,15 @@
 
 #include "lsq_q16.h"
 
+#ifdef LSQ_TUNING
+__device__ unsigned long long *g_xs_dbg = nullptr;      // tools only: [task][16] clock stamps (wall_clock64, 100 MHz) of ONE block (group 0, slice 0) of the latest launch
+#define XS_STAMP(t, k) do { if (dbgp && lane == 0 && (t) < 1024) dbgp[(size_t)(t) * 16 + (k)] = wall_clock64(); } while (0)
+#define XS_NOTE(t, k, v) do { if (dbgp && lane == 0 && (t) < 1024) dbgp[(size_t)(t) * 16 + (k)] = (unsigned long long)(v); } while (0)
+#else
+#define XS_STAMP(t, k) do {} while (0)
+#define XS_NOTE(t, k, v) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int XS_R = 4;                          // ring of partial-key slots per group (tasks in flight between walk and merge)
@@ -65,7 +74,7 @@ __device__ inline void lds_store(unsigned *w, unsigned v) { __hip_atomic_store(w
 __device__ inline void lds_add(unsigned *w, unsigned v) { __hip_atomic_fetch_add(w, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // control words of a block (LDS)
-enum { XC_LIST = 0, XC_NACT0, XC_NACT1, XC_WALK0, XC_WALK1, XC_TABBAR, XC_MRG0, XC_MRG1, XC_CDONE, XC_ABORT, XC_GROUP, XC_SLICE, XC_WORDS = 16 };
+enum { XC_LIST0 = 0, XC_LIST1, XC_NACT0, XC_NACT1, XC_NACT2, XC_NACT3, XC_WALK0, XC_WALK1, XC_TABBAR, XC_MRG0, XC_MRG1, XC_CDONE, XC_ABORT, XC_GROUP, XC_SLICE, XC_WORDS = 16 };
 
 struct XsCtl {
     unsigned *c;            // LDS control words
@@ -257,7 +266,7 @@ __device__ inline void xs_f32_update(const XsArgs &A, int j, int64_t vi, const u
     }
 }
 
-template <int M, int SLQ>
+template <int M, int SLQ, int NMERGE = 2>
 struct XsCfg {
     static constexpr int CS = (M <= 8) ? 8 : 16;
     static constexpr int RW = CS / 4;
@@ -265,16 +274,18 @@ struct XsCfg {
     static constexpr int G = NS;
     static constexpr int GPX = 32 / G;                     // groups per XCD
     static constexpr int NG = 8 * GPX;
-    static constexpr int W = 13, NM = 2;                   // waves: W walkers, 1 lister, NM mergers
-    static constexpr int NT = 64 * (W + 1 + NM);
+    static constexpr int NL = 2, NM = NMERGE, W = 16 - NL - NM;      // waves: W walkers, NL listers (lister l builds the lists of the tasks t = l mod NL), NM mergers
+    static constexpr int NT = 64 * (W + NL + NM);
     static constexpr int DEPTH = (M <= 8) ? 3 : 2;
-    static constexpr int LCAP = (M <= 8) ? 8192 : 6144;    // active vectors per task (list entries)
+    static constexpr int LCAP = (M <= 8) ? 7680 : 6144;    // active vectors per task (list entries)
+    static constexpr int SCAP = LCAP / G;                  // ... of which this CU merges at most this many (its share)
     static constexpr int AREC = 3 + 2 * RW;
-    static constexpr int ACAP = (M <= 8) ? 256 : 160;      // ambiguous-vector records per merger wave
+    static constexpr int ACAP = ((M <= 8) ? 320 : 192) / NM;       // ambiguous-vector records per merger wave
     using TL = WalkqTab<SLQ, 8>;
     static constexpr int LTAB = TL::lds_entries(M);        // 16-byte entries
     static constexpr int OFF_LIST = LTAB * 16;
-    static constexpr int OFF_AREC = OFF_LIST + 2 * LCAP * 2;
+    static constexpr int OFF_SHARE = OFF_LIST + 2 * LCAP * 2;   // ring of XS_R share lists: the list buffer is free as soon as the walkers are done with it
+    static constexpr int OFF_AREC = OFF_SHARE + XS_R * SCAP * 2;
     static constexpr int OFF_CTL = OFF_AREC + NM * ACAP * AREC * 4;
     static constexpr int OFF_TRACE = OFF_CTL + XC_WORDS * 4;   // per merger wave: recomputed node updates by position in the ILS iteration
     static constexpr int LDS_BYTES = OFF_TRACE + NM * LSQ_WALK_TRACE * 4;
@@ -282,18 +293,20 @@ struct XsCfg {
     static_assert(NT == 1024, "16 waves");
 };
 
-template <int M, int SLQ>
+template <int M, int SLQ, int NMERGE>
 __global__ __launch_bounds__(1024) void icm_xs_kernel(const XsArgs A, const WalkNodes nodes) {
-    using C = XsCfg<M, SLQ>;
+    using C = XsCfg<M, SLQ, NMERGE>;
     using TL = typename C::TL;
-    constexpr int CS = C::CS, RW = C::RW, NS = C::NS, G = C::G, GPX = C::GPX, W = C::W, NM = C::NM, DEPTH = C::DEPTH, LCAP = C::LCAP;
-    constexpr int AREC = C::AREC, ACAP = C::ACAP;
+    constexpr int CS = C::CS, RW = C::RW, NS = C::NS, G = C::G, GPX = C::GPX, W = C::W, NL = C::NL, NM = C::NM, DEPTH = C::DEPTH, LCAP = C::LCAP;
+    static_assert(NL == 2, "one lister per list buffer");
+    constexpr int AREC = C::AREC, ACAP = C::ACAP, SCAP = C::SCAP;
     constexpr int LPV = SLQ / 8, VPW = 64 / LPV, EPR = SLQ / 8;
     constexpr int TAB = (M - 1) * LSQ_H * EPR;             // 16-byte entries of one slice table
     constexpr int CW = (M - 1 + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_xs[];
     u32x4 *tab = reinterpret_cast<u32x4 *>(lds_xs);
     unsigned short *list0 = reinterpret_cast<unsigned short *>(lds_xs + C::OFF_LIST);
+    unsigned short *share0 = reinterpret_cast<unsigned short *>(lds_xs + C::OFF_SHARE);
     uint32_t *arec0 = reinterpret_cast<uint32_t *>(lds_xs + C::OFF_AREC);
     unsigned *ctl = reinterpret_cast<unsigned *>(lds_xs + C::OFF_CTL);
     XsSync *sync = A.sync;
@@ -351,6 +364,9 @@ __global__ __launch_bounds__(1024) void icm_xs_kernel(const XsArgs A, const Walk
     unsigned *progb = &sync->progb[group][0], *progc = &sync->progc[group][0];
     unsigned long long *part_g = A.part + (size_t)group * XS_R * G * (size_t)clen;   // [ring slot][slice][position]
     const bool have_ref = A.ref_rec && A.ref_valid;
+#ifdef LSQ_TUNING
+    unsigned long long *dbgp = (g_xs_dbg && group == 0 && slice == 0) ? g_xs_dbg : nullptr;
+#endif
 
     if (wave < W) {
         // =========================================================== WALKERS ===========================================================
@@ -365,11 +381,13 @@ __global__ __launch_bounds__(1024) void icm_xs_kernel(const XsArgs A, const Walk
             if (t - jn * Q == 0) {
                 // a new node: every walker must be done with the old table, then slice `slice` of node j's table goes to LDS (once per node and CU)
                 if (t > 0 && !X.wait_lds(XC_WALK0 + ((t - 1) & 1), (unsigned)(W * ((t - 1) / 2 + 1)), 10u)) return;
+                if (wave == 0) XS_STAMP(t, 3);
                 const u32x4 *src = reinterpret_cast<const u32x4 *>(A.Tq) + ((int64_t)j * NS + slice) * TAB;
                 for (int e = wave * 64 + lane; e < TAB; e += W * 64) tab[TL::entry(e / (LSQ_H * EPR), (e / EPR) % LSQ_H, e % EPR)] = src[e];
                 if (lane == 0) lds_add(ctl + XC_TABBAR, 1u);
                 ++nstaged;
                 if (!X.wait_lds(XC_TABBAR, (unsigned)W * nstaged, 11u)) return;
+                if (wave == 0) XS_STAMP(t, 4);
 #pragma unroll
                 for (int w = 0; w < CW; ++w) {
                     uint32_t sv = 0;
@@ -382,8 +400,10 @@ __global__ __launch_bounds__(1024) void icm_xs_kernel(const XsArgs A, const Walk
                     sel[w] = sv;
                 }
             }
-            if (!X.wait_lds(XC_LIST, (unsigned)(t + 1), 12u)) return;
-            const int nact = (int)ctl[XC_NACT0 + (t & 1)];
+            if (wave == 0) XS_STAMP(t, 0);
+            if (!X.wait_lds(XC_LIST0 + (t & 1), (unsigned)(t + 1), 12u)) return;
+            if (wave == 0) XS_STAMP(t, 1);
+            const int nact = (int)ctl[XC_NACT0 + (t % XS_R)];
             const int ipw = (wave * VPW < nact) ? (nact - wave * VPW + step - 1) / step : 0;
             if (ipw > 0) {
                 const unsigned short *list = list0 + (t & 1) * LCAP;
@@ -462,55 +482,82 @@ __global__ __launch_bounds__(1024) void icm_xs_kernel(const XsArgs A, const Walk
                     if (kk + e < ipw) compute(buf[e], kk + e);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // this wave's partial keys are in L2
+            if (wave == 0) XS_STAMP(t, 2);
             if (lane == 0) lds_add(ctl + XC_WALK0 + (t & 1), 1u);
         }
         return;
     }
 
-    if (wave == W) {
-        // =========================================================== LISTER ============================================================
+    if (wave < W + NL) {
+        // =========================================================== LISTERS ===========================================================
+        // Lister l owns list buffer l and the tasks t = l (mod 2).  It scans the cohort's validity words -- 16 bytes (8 vectors) per lane and load,
+        // NB loads in flight: one wave has to stream 2 bytes per vector of the whole cohort out of L2 -- and appends the active vectors in ascending order.
         const int use_skip = A.use_skip && A.valid;
-        for (int t = 0; t < ntasks; ++t) {
+        for (int t = wave - W; t < ntasks; t += NL) {
             const int jn = t / Q, cq = t - jn * Q;
             const int j = nodes.j[jn];
+            XS_STAMP(t, 5);
             int need = (jn > 0) ? t - Q + 1 : 0;                                      // the cohort's results of the previous node, from every CU of the group
             if (t - XS_R + 1 > need) need = t - XS_R + 1;                             // ... and the ring slot of the partial keys must be free
             if (need > 0 && !X.wait_prog(progc, G, (unsigned)need, 20u)) return;
-            if (t >= 2 && !X.wait_lds(XC_CDONE, (unsigned)(t - 1), 21u)) return;     // the list buffer: this CU's mergers are done with task t - 2
+            if (t >= 2 && !X.wait_lds(XC_WALK0 + (t & 1), (unsigned)(W * ((t - 2) / 2 + 1)), 21u)) return;      // the list buffer: the walkers are done with task t - 2
+            if (t >= XS_R && !X.wait_lds(XC_CDONE, (unsigned)(t - XS_R + 1), 22u)) return;                      // the share slot: this CU's mergers are done with task t - XS_R
+            XS_STAMP(t, 6);
             unsigned short *list = list0 + (t & 1) * LCAP;
             const int clo = cq * clen, chi = (clo + clen < glen) ? clo + clen : glen;
             int cnt = 0;
-            constexpr int NB = 8;                                                     // 8-byte loads (4 validity words each) in flight per lane
-            for (int base = clo; base < chi; base += 256 * NB) {
-                unsigned long long w[NB];
+            constexpr int NB = 16;                                                    // 8192 validity words per round trip
+            for (int base = clo; base < chi; base += 512 * NB) {
+                unsigned long long w[NB][2];
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
-                    const int idx0 = base + b * 256 + 4 * lane;
-                    w[b] = 0ull;
-                    if (idx0 < chi && use_skip) w[b] = ld_l2(reinterpret_cast<const unsigned long long *>(A.valid + gb + idx0));
+                    const int idx0 = base + b * 512 + 8 * lane;
+                    w[b][0] = 0ull; w[b][1] = 0ull;
+                    if (use_skip) {
+                        const unsigned long long *vp = reinterpret_cast<const unsigned long long *>(A.valid + gb + idx0);
+                        if (idx0 < chi) w[b][0] = ld_l2(vp);
+                        if (idx0 + 4 < chi) w[b][1] = ld_l2(vp + 1);
+                    }
                 }
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
-                    const int idx0 = base + b * 256 + 4 * lane;
-                    bool f[4];
+                    const int idx0 = base + b * 512 + 8 * lane;
+                    if (base + b * 512 >= chi) continue;                              // wave-uniform
+                    // bit j of the lane's 8 validity words, two per 32-bit register: vector e sits at bit (e >> 1) + 16 (e & 1) of `set`
+                    constexpr uint32_t M1 = 0x00010001u;
+                    const uint32_t set = (((uint32_t)w[b][0] >> j) & M1) | ((((uint32_t)(w[b][0] >> 32) >> j) & M1) << 1) |
+                                         ((((uint32_t)w[b][1] >> j) & M1) << 2) | ((((uint32_t)(w[b][1] >> 32) >> j) & M1) << 3);
+                    int nin = chi - idx0;
+                    nin = nin < 0 ? 0 : (nin > 8 ? 8 : nin);                           // vectors of this lane inside the cohort
+                    const uint32_t inr = ((1u << ((nin + 1) >> 1)) - 1u) | (((1u << (nin >> 1)) - 1u) << 16);
+                    uint32_t act = ~set & inr;
+                    const int c = __builtin_popcount(act);                            // 0 .. 8
                     int below = 0, total = 0;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        f[e] = (idx0 + e < chi) && !((w[b] >> (16 * e + j)) & 1ull);
-                        const unsigned long long mk = __ballot(f[e]);
-                        below += (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-                        total += __builtin_popcountll(mk);
+                    for (int bit = 0; bit < 4; ++bit) {
+                        const unsigned long long mk = __ballot((c >> bit) & 1);
+                        below += (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u)) << bit;
+                        total += __builtin_popcountll(mk) << bit;
                     }
                     int pos = cnt + below;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (f[e]) list[pos++] = (unsigned short)(idx0 + e);
+                    while (act) {                                                     // the lane's active vectors, in a fixed (not ascending) order: every
+                        const int bp = __builtin_ctz(act);                            // CU of the group builds the identical list
+                        act &= act - 1u;
+                        list[pos++] = (unsigned short)(idx0 + (((bp & 15) << 1) | (bp >> 4)));
+                    }
                     cnt += total;
                 }
             }
+            {   // this CU's share of the task's merge work: its own copy, so that the list buffer is free once the walkers are done
+                const int slo = (int)(((int64_t)cnt * slice) / G), shi = (int)(((int64_t)cnt * (slice + 1)) / G);
+                unsigned short *sh = share0 + (t % XS_R) * SCAP;
+                for (int e = lane; e < shi - slo; e += 64) sh[e] = list[slo + e];
+            }
+            XS_STAMP(t, 7);
+            XS_NOTE(t, 8, cnt);
             if (lane == 0) {                                                         // the list entries above, the count, then the flag: one wave, in order
-                ctl[XC_NACT0 + (t & 1)] = (unsigned)cnt;
-                lds_store(ctl + XC_LIST, (unsigned)(t + 1));
+                ctl[XC_NACT0 + (t % XS_R)] = (unsigned)cnt;
+                lds_store(ctl + XC_LIST0 + (t & 1), (unsigned)(t + 1));
             }
         }
         return;
@@ -518,7 +565,7 @@ __global__ __launch_bounds__(1024) void icm_xs_kernel(const XsArgs A, const Walk
 
     {
         // =========================================================== MERGERS ===========================================================
-        const int mk = wave - W - 1;                                                  // 0 .. NM-1
+        const int mk = wave - W - NL;                                                 // 0 .. NM-1
         uint32_t *arec = arec0 + mk * ACAP * AREC;
         unsigned *trace = reinterpret_cast<unsigned *>(lds_xs + C::OFF_TRACE) + mk * LSQ_WALK_TRACE;
         for (int e = lane; e < LSQ_WALK_TRACE; e += 64) trace[e] = 0u;
@@ -528,11 +575,13 @@ __global__ __launch_bounds__(1024) void icm_xs_kernel(const XsArgs A, const Walk
             const int j = nodes.j[jn];
             if (mk == 0) {
                 if (!X.wait_lds(XC_WALK0 + (t & 1), (unsigned)(W * (t / 2 + 1)), 30u)) return;
+                XS_STAMP(t, 9);
                 if (lane == 0) *reinterpret_cast<volatile unsigned *>(progb + slice) = (unsigned)(t + 1);      // this CU's partial keys of task t are in L2
             }
             if (!X.wait_prog(progb, G, (unsigned)(t + 1), 31u)) return;
-            const int nact = (int)lds_load(ctl + XC_NACT0 + (t & 1));
-            const unsigned short *list = list0 + (t & 1) * LCAP;
+            if (mk == 0) XS_STAMP(t, 10);
+            const int nact = (int)lds_load(ctl + XC_NACT0 + (t % XS_R));
+            const unsigned short *share = share0 + (t % XS_R) * SCAP;
             const int slo = (int)(((int64_t)nact * slice) / G), shi = (int)(((int64_t)nact * (slice + 1)) / G);      // this CU's share of the task
             const int mlo = slo + (int)(((int64_t)(shi - slo) * mk) / NM), mhi = slo + (int)(((int64_t)(shi - slo) * (mk + 1)) / NM);
             const unsigned long long *pslot = part_g + (size_t)(t % XS_R) * G * (size_t)clen;
@@ -558,7 +607,7 @@ __global__ __launch_bounds__(1024) void icm_xs_kernel(const XsArgs A, const Walk
                 for (int e = 0; e < VPL; ++e) {
                     const int p = p0 + e * 64 + lane;
                     on[e] = p < mhi;
-                    li[e] = list[on[e] ? p : mlo];
+                    li[e] = share[(on[e] ? p : mlo) - slo];
                     const int64_t vi = gb + li[e];
                     vo[e] = 0; rv[e] = 0; qf[e] = 0;
 #pragma unroll
@@ -648,6 +697,7 @@ __global__ __launch_bounds__(1024) void icm_xs_kernel(const XsArgs A, const Walk
                 st_amb += (unsigned)namb;
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // this wave's records and validity words are in L2
+            if (mk == 0) { XS_STAMP(t, 11); XS_NOTE(t, 13, namb); }
             if (lane == 0) lds_add(ctl + XC_MRG0 + (t & 1), 1u);
             if (mk == 0) {
                 if (!X.wait_lds(XC_MRG0 + (t & 1), (unsigned)(NM * (t / 2 + 1)), 32u)) return;
@@ -655,6 +705,7 @@ __global__ __launch_bounds__(1024) void icm_xs_kernel(const XsArgs A, const Walk
                     *reinterpret_cast<volatile unsigned *>(progc + slice) = (unsigned)(t + 1);
                     lds_store(ctl + XC_CDONE, (unsigned)(t + 1));
                 }
+                XS_STAMP(t, 12);
             }
         }
         if (A.active_total) {
@@ -674,9 +725,9 @@ __global__ __launch_bounds__(1024) void icm_xs_kernel(const XsArgs A, const Walk
     }
 }
 
-template <int M, int SLQ>
+template <int M, int SLQ, int NMERGE = 2>
 int launch_xs_t(hipStream_t s, const XsArgs &A0, const WalkNodes &nodes, int64_t n, DevBuf *part, DevBuf *syncb) {
-    using C = XsCfg<M, SLQ>;
+    using C = XsCfg<M, SLQ, NMERGE>;
     XsArgs A = A0;
     int64_t per_group = (n + C::NG - 1) / C::NG;
     per_group = (per_group + 63) / 64 * 64;
@@ -692,13 +743,21 @@ int launch_xs_t(hipStream_t s, const XsArgs &A0, const WalkNodes &nodes, int64_t
     A.sync = syncb->as<XsSync>();
     LSQ_HIP(hipMemsetAsync(A.sync, 0, sizeof(XsSync), s));
     static LdsOptIn optin;
-    LSQ_TRY(optin_lds(optin, &icm_xs_kernel<M, SLQ>, C::LDS_BYTES));
-    hipLaunchKernelGGL((icm_xs_kernel<M, SLQ>), dim3(256), dim3(C::NT), C::LDS_BYTES, s, A, nodes);
+    LSQ_TRY(optin_lds(optin, &icm_xs_kernel<M, SLQ, NMERGE>, C::LDS_BYTES));
+    hipLaunchKernelGGL((icm_xs_kernel<M, SLQ, NMERGE>), dim3(256), dim3(C::NT), C::LDS_BYTES, s, A, nodes);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }
 
 }  // namespace
+
+#ifdef LSQ_TUNING
+// tools only: device buffer of 1024 x 16 u64 that block (group 0, slice 0) of every icm_xs_kernel launch fills with clock stamps (the last launch stays)
+extern "C" __attribute__((visibility("default"))) int lsq_tuning_set_xs_debug(void *buf) {
+    LSQ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_xs_dbg), &buf, sizeof(buf)));
+    return LSQ_OK;
+}
+#endif
 
 // Does schedule 7 apply to (n, m)?  (the caller also requires a 256-CU device)
 bool lsq_icm_xs_applies(int64_t n, int m) {
@@ -731,6 +790,16 @@ int lsq_launch_icm_xs(hipStream_t s, const float *U, const uint16_t *Uq, const u
     A.ref_rec = skip ? ref_rec : nullptr; A.ref_valid = skip ? ref_valid : nullptr;
     A.P = P; A.qflag = qflag; A.part = nullptr; A.sync = nullptr; A.active_total = active_total; A.err = err;
     A.n = n; A.per_group = 0; A.clen = 0; A.Q = 0; A.use_skip = skip; A.SLF = lsq_walk_slice_width(m);
+#ifdef LSQ_TUNING
+    if (m == 8 && LSQ_KNOB("LSQ_XS_NM", 2) != 2) {      // tools only: other splits of the 16 waves
+        const int nm = LSQ_KNOB("LSQ_XS_NM", 2);
+        if (nm == 3) LSQ_TRY((launch_xs_t<8, 32, 3>(s, A, nodes, n, part, syncb)));
+        else if (nm == 4) LSQ_TRY((launch_xs_t<8, 32, 4>(s, A, nodes, n, part, syncb)));
+        else LSQ_TRY((launch_xs_t<8, 32, 6>(s, A, nodes, n, part, syncb)));
+        if (gate_word) *gate_word = &syncb->as<XsSync>()->gate;
+        return LSQ_OK;
+    }
+#endif
     switch (m) {
 #define LSQ_XS_CASE(MM, SLL) case MM: LSQ_TRY((launch_xs_t<MM, SLL>(s, A, nodes, n, part, syncb))); break;
         LSQ_XS_CASE(2, 32) LSQ_XS_CASE(3, 32) LSQ_XS_CASE(4, 32) LSQ_XS_CASE(5, 32) LSQ_XS_CASE(6, 32) LSQ_XS_CASE(7, 32) LSQ_XS_CASE(8, 32)

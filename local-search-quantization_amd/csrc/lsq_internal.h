@@ -145,16 +145,6 @@ int lsq_launch_codes_to_i16(hipStream_t s, const uint8_t *rec, int64_t n, int m,
 // codes); a perturbation that changes a code clears the whole mask.
 int lsq_launch_perturb(hipStream_t s, const uint8_t *src, uint8_t *dst, int64_t n, int m, int npert,
                        uint64_t seed, uint32_t it, uint64_t global_offset, const unsigned short *vsrc, unsigned short *vdst);
-#ifdef LSQ_TUNING      // the earlier schedules (lsq_icm_legacy.hip): tuning build only
-// one ICM node update of node j for all n vectors: Uj = U + j*n*256, T = full table [m][m][256][256]
-int lsq_launch_icm_node(hipStream_t s, const float *Uj, const float *T, uint8_t *rec, int64_t n, int m, int j);
-// fused: for every vector, all `nsweeps` sweeps in `order` with register-resident unaries
-int lsq_launch_icm_fused(hipStream_t s, const float *U, const float *T, uint8_t *rec, int64_t n, int m,
-                         const int32_t *order_host, int nsweeps);
-// LDS-slice schedule: U plane j is slice-major [256/SL][n][SL]; part = [256/SL][n] (min, local idx) scratch
-static inline int lsq_slice_width(int m) { return m <= 10 ? 16 : 8; }
-int lsq_launch_icm_slice(hipStream_t s, const float *Usj, const float *T, uint8_t *rec, float2 *part, int64_t n, int m, int j);
-#endif
 // LDS-walk schedule: one block walks all slices of its vector range; Ts = slice-major pair tables
 int lsq_walk_slice_width(int m);      // 16 for m <= 8 (8 if LSQ_WALK_SL=8 is set: tuning knob), 8 above
 int lsq_launch_tables_to_slices(hipStream_t s, const float *T, float *Ts, int m, int sl);

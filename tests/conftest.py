@@ -12,7 +12,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "tuning: cross-checks of the NON-SHIPPED schedules 0..2 (liblsq_mi355x_tuning.so only); they run only "
+    config.addinivalue_line("markers", "tuning: cross-checks of the NON-SHIPPED schedule 7 (csrc/lsq_icmx.hip, liblsq_mi355x_tuning.so only); they run only "
                                        "with LSQ_TEST_TUNING=1 so that they never count toward the product's green total")
 
 
@@ -27,7 +27,8 @@ def pytest_collection_modifyitems(config, items):
 
 # How the encode is run in the parity tests.  The FIRST entries are the shipped library: its plain defaults (what a caller gets),
 # schedule 6 forced onto every chunk with every block staged and both hand-overs to the f32 walk switched off (the 16-bit filtered walk
-# is then the kernel that produces every code, whatever n and whatever the data), the f32 walk in both launch shapes.  Schedules 0..2 exist in the tuning build only and are marked `tuning`.
+# is then the kernel that produces every code, whatever n and whatever the data), the f32 walk in both launch shapes.  Schedule 7 (the XCD-cooperative
+# kernel of round 4: bit-exact, measured slower, not adopted) exists in the tuning build only and is marked `tuning`.
 def _variant(name, marks=(), **options):
     return pytest.param(options, id=name, marks=list(marks))
 
@@ -38,9 +39,7 @@ ENCODE_VARIANTS = [
     _variant("s6_light", schedule=6, q16_min=0),
     _variant("s4", schedule=4),
     _variant("s3", schedule=3),
-    _variant("legacy2", marks=[pytest.mark.tuning], schedule=2, tuning=1),
-    _variant("legacy0", marks=[pytest.mark.tuning], schedule=0, tuning=1),
-    _variant("legacy1", marks=[pytest.mark.tuning], schedule=1, tuning=1),
+    _variant("xs7", marks=[pytest.mark.tuning], schedule=7, tuning=1, q16_min=0, xs_min=0, filter_probe_div=0, filter_fallback_div=0),
 ]
 
 

@@ -33,7 +33,7 @@ def parity():
         X, K, B0 = make_problem(d, n, m, seed=seed, kind=kind)
         ref, objs_ref = O.encode_icm(X, B0, K, m, 256, ils, J, npert, True, seed)
         for skip in (1, 0):
-            with lsq.Engine(0, schedule=7, skip=skip) as eng:
+            with lsq.Engine(0, schedule=7, skip=skip, tuning=True) as eng:
                 for k, v in (("q16_min", 0), ("xs_min", 0), ("filter_probe_div", 0), ("filter_fallback_div", 0)):
                     eng.set_option(k, v)
                 t0 = time.time()
@@ -54,7 +54,7 @@ def ab(n=1_000_000, m=8, d=128, ils=16):
     res = {}
     codes = {}
     for schedule in (6, 7, 6, 7):
-        with lsq.Engine(0, schedule=schedule, profile=True) as eng:
+        with lsq.Engine(0, schedule=schedule, profile=True, tuning=True) as eng:
             dX = eng.synth_data_u8_dev(1234, n, d)
             dB0 = eng.randinit_dev(7, n, m)
             dK = eng.synth_codebooks_dev(99, m, d)
