@@ -599,7 +599,7 @@ static int xs_begin(lsq_ctx *c) {
 static int xs_verdict(lsq_ctx *c, const unsigned (&xs_err)[2]) {      // after the stream has been synchronised
     c->xs_fallback_launches += (int64_t)xs_err[1];
     if (xs_err[0] != 0u) {        // never silently: a wait inside a schedule-7 launch gave up (a lost block, a protocol fault): this call's codes are invalid
-        lsq_set_error("icm_xs_kernel gave up waiting (code %u): the codes of this call are invalid; option \"schedule\" = 6 avoids the kernel", xs_err[0]);
+        lsq_set_error("the schedule-7 kernel gave up waiting (code %u): the codes of this call are invalid; option \"schedule\" = 6 avoids the kernel", xs_err[0]);
         return LSQ_EHIP;
     }
     return LSQ_OK;
