@@ -22,6 +22,7 @@ Prints ONE JSON line on rank 0 with the driver's contract fields plus
   `roofline`         dominant kernel (the ICM node update): algorithmic HBM bytes / HIP-event launch time vs 8 TB/s, the LDS-side
                      gather rate vs the guide's 150 TB/s, the M1 compulsory-bytes fraction, PMC traffic when the committed
                      profile was taken from THIS build (hash of the loaded .so), else null;
+  `trained`          the representative number beside `value`: the same encode with codebooks TRAINED by this package (copied from workloads.trained);
   `workloads`        the SAME 10^6-vector encode on other inputs / options, because the GPU time is data-dependent (exact memoisation of
                      unchanged node updates + the 16-bit filter): `trained` (codebooks trained by this package's own train_lsq on a 100 000-vector
                      sample -- the reference encodes with trained codebooks, LSQ.jl:10-88 -> demo_lsq_gpu.jl:33-50), `floor` (memoisation off:
@@ -572,6 +573,12 @@ def main():
                                    "note": "north_star quotes its >= 50x target at 4 ILS iterations; same workload otherwise"}
         if not args.no_workloads and n * d * 4 <= 2 << 30:
             out["workloads"] = workloads_leg(lsq, eng, dX, dB0, dK, n, d, m, args, goff)
+            # The REPRESENTATIVE number beside `value`: the reference encodes a base set with TRAINED codebooks (LSQ.jl:10-88 ->
+            # demo_lsq_gpu.jl:33-50); `value` keeps the synthetic codebooks of SURVEY 8(d).  Same vectors, same options, same timing method.
+            tr = out["workloads"]["trained"]
+            out["trained"] = {"value": tr["value"], "unit": tr["unit"], "ms_per_step": tr["ms_per_step"], "recomputed_fraction": tr["recomputed_fraction"],
+                              "ambiguous_fraction": tr["ambiguous_fraction"], "sample_parity": tr["sample_parity"], "vs_value": tr["value"] / out["value"],
+                              "note": "codebooks trained by this package's train_lsq on the first 100 000 of the same vectors; details in workloads.trained"}
             step()                                                       # dBs again holds the timed workload's codes
             torch.cuda.synchronize()
             out["search"] = search_leg(lsq, eng, dK, dBs[0].contiguous(), n, d, m)

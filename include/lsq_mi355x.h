@@ -287,7 +287,9 @@ LSQ_API int lsq_update_codebooks(const float *X, const int16_t *B, int d, int64_
  * in double, IterativeSolvers' default stopping rules), the rows sorted by code once per call so that S'u is added in the host's order without atomics.
  * The same bits on every call; the same bits as lsq_update_codebooks on every tested problem (its norms are added in another order: agreement is
  * required to 1e-5 only).  _gpu: host buffers, Julia layout as above (X d x n, B m x n Int16 1-based, K_out d x (m*h));  _dev: device buffers,
- * codes [n][m] uint8 0-BASED.  h must be 256.  iterations (optional): LSQR iterations of the slowest dimension. */
+ * codes [n][m] uint8 0-BASED.  h must be 256.  iterations (optional): LSQR iterations LAUNCHED = the slowest dimension's count rounded up to the host's
+ * next look at the convergence counter (every 4 iterations for the first 8, every 2 after: up to 3 more than needed; a converged system is frozen, so the
+ * extra launches change nothing but this number); `maxiter` bounds launched iterations likewise. */
 LSQ_API int lsq_update_codebooks_gpu(lsq_ctx *ctx, const float *X, const int16_t *B, int d, int64_t n, int m, int h, float *K_out, int *iterations);
 LSQ_API int lsq_update_codebooks_dev(lsq_ctx *ctx, const float *d_X, const uint8_t *d_codes, int d, int64_t n, int m, int h, float *d_K_out,
                                      int *iterations);

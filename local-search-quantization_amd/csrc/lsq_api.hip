@@ -72,10 +72,7 @@ struct lsq_ctx {
     bool chunk_q16 = false;                            // the resident chunk runs the filtered walk (set by build_unaries from the chunk's verdict)
     int64_t fallback_div = 64;                         // option "filter_fallback_div": the chunk goes to the f32 walk when flagged pairs * div > all pairs (0 = never)
     int64_t filter_fallback_chunks = 0;                // chunks the filter handed to the f32 walk (unusable bounds or too many out-of-range vectors)
-    // single-iteration calls (the trainer's chained encoding_icm) cannot probe and switch within the call: the verdict of the previous such call on
-    // the same shape is remembered instead (re-probed every 16th call)
     int64_t call_I = 0, call_q16_chunks = 0;
-    int64_t sticky_n = -1; int sticky_d = 0, sticky_m = 0, sticky_bad = 0, sticky_count = 0;
     float *q_colshift = nullptr;                       // inside qscratch: the per-candidate shift of the unary levels (double-centred tables)
     lsq_lsqr_state *lsqr = nullptr;                    // device LSQR (lsq_lsqr.hip): work buffers, created on first use
     lsq_adc_state *adc = nullptr;                      // device ADC scan (lsq_adc.hip): buffers, created on first use
@@ -381,10 +378,7 @@ static bool use_q16(const lsq_ctx *c, int64_t cn) { return c->schedule >= 6 && c
 
 static int build_unaries(lsq_ctx *c, const float *dX, const float *dK, int d, int64_t cn, int m, int slice, int64_t r0, int64_t rows) {
     c->chunk_q16 = false;
-    bool q16 = slice > 0 && r0 == 0 && rows == cn && use_q16(c, cn);
-    if (q16 && c->call_I == 1 && c->sticky_bad && c->sticky_n == cn && c->sticky_d == d && c->sticky_m == m && c->probe_div > 0) {
-        if (++c->sticky_count % 16 != 0) { q16 = false; c->filter_fallback_chunks += 1; }      // the last probe of this shape said: f32 walk
-    }
+    const bool q16 = slice > 0 && r0 == 0 && rows == cn && use_q16(c, cn);
     if (q16) c->call_q16_chunks += 1;
     if (q16) {
         // 16-bit filtered walk: sampled value ranges of this chunk -> parameters -> 16-bit slice tables; the GEMM below then also emits the u16 planes
@@ -438,8 +432,11 @@ static int build_unaries(lsq_ctx *c, const float *dX, const float *dK, int d, in
 }
 
 // ref_rec / ref_valid: the vectors' current records and validity masks (read-only during the sweeps), or nullptr
+// first_sweep: position of the first of the nsweeps sweeps inside its ILS iteration (the per-position trace counters only)
 static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t cn, int m, const int32_t *order, int nsweeps,
-                      const uint8_t *ref_rec = nullptr, const unsigned short *ref_valid = nullptr) {
+                      const uint8_t *ref_rec = nullptr, const unsigned short *ref_valid = nullptr, int first_sweep = 0) {
+    if (nsweeps <= 0) return LSQ_OK;
+    const int pos_base = first_sweep * m;
     Timer t(c, CAT_ICM);
     if (c->schedule >= 4) {
         // the whole ILS iteration (nsweeps x m node updates) in ONE launch: a block owns its vectors throughout
@@ -463,13 +460,13 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t c
 #ifdef LSQ_TUNING
                 if (xs)
                     LSQ_TRY(lsq_launch_icm_xs(c->stream, c->U.as<float>(), c->Uq.as<uint16_t>(), c->Tq.as<uint16_t>(), c->T.as<float>(), rec, valid, cn, m,
-                                              seq.data() + done, cntn, (int)done, c->skip, c->walk_counters, c->fallback ? ref_rec : nullptr,
+                                              seq.data() + done, cntn, pos_base + (int)done, c->skip, c->walk_counters, c->fallback ? ref_rec : nullptr,
                                               c->fallback ? ref_valid : nullptr, P, c->qflag.as<unsigned short>(), &c->xsPart, &c->xsSync,
                                               c->xsErr.as<unsigned>(), &gate));
 #endif
                 if (xs) c->xs_launches += 1;
                 LSQ_TRY(lsq_launch_icm_walkq(c->stream, c->U.as<float>(), c->Uq.as<uint16_t>(), c->Tq.as<uint16_t>(), c->T.as<float>(), rec, valid, cn, m,
-                                             seq.data() + done, cntn, (int)done, c->skip, c->walk_counters, c->light,
+                                             seq.data() + done, cntn, pos_base + (int)done, c->skip, c->walk_counters, c->light,
                                              c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr, P, c->qflag.as<unsigned short>(), gate));
             }
             c->icm_launches += ((int64_t)seq.size() + (int64_t)per_launch - 1) / (int64_t)per_launch;
@@ -482,19 +479,19 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t c
             lsq_walk_geometry(cn, m, &per_pass, &npass, nullptr);
             const int light_max = c->light >= 0 ? c->light : 256;
             if (c->ablation == 0 && per_pass <= light_max && per_pass <= c->wave_max) {
-                LSQ_TRY(lsq_launch_icm_wave(c->stream, c->U.as<float>(), c->T.as<float>(), rec, valid, cn, m, seq.data(), (int)seq.size(), 0, c->skip,
+                LSQ_TRY(lsq_launch_icm_wave(c->stream, c->U.as<float>(), c->T.as<float>(), rec, valid, cn, m, seq.data(), (int)seq.size(), pos_base, c->skip,
                                             c->walk_counters, c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr));
                 c->icm_launches += ((int64_t)seq.size() + 63) / 64;
                 return LSQ_OK;
             }
         }
-        LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>(), c->Ts.as<float>(), c->T.as<float>(), rec, valid, cn, m, seq.data(), (int)seq.size(), 0, c->skip,
+        LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>(), c->Ts.as<float>(), c->T.as<float>(), rec, valid, cn, m, seq.data(), (int)seq.size(), pos_base, c->skip,
                                     c->walk_counters, c->ablation, c->light, c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr));
         c->icm_launches += ((int64_t)seq.size() + 63) / 64;
     } else {
         for (int sw = 0; sw < nsweeps; ++sw)
             for (int q = 0; q < m; ++q)
-                LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>(), c->Ts.as<float>(), c->T.as<float>(), rec, valid, cn, m, &order[q], 1, sw * m + q, c->skip,
+                LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>(), c->Ts.as<float>(), c->T.as<float>(), rec, valid, cn, m, &order[q], 1, pos_base + sw * m + q, c->skip,
                                             c->walk_counters, c->ablation, c->light, c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr));
         c->icm_launches += (int64_t)nsweeps * m;
     }
@@ -517,7 +514,6 @@ static int encode_chunk(lsq_ctx *c, const float *dXc, const float *dK, int64_t c
     const int cs = lsq_code_stride(P.m);
     c->call_I = I;
     if (!unaries_ready) LSQ_TRY(build_unaries(c, dXc, dK, P.d, cn, P.m, u_slice_width(c, P.m), 0, cn));
-    if (I == 1) { c->sticky_n = cn; c->sticky_d = P.d; c->sticky_m = P.m; }
     LSQ_TRY(c->recNew.ensure((size_t)cn * cs));
     LSQ_TRY(c->prev.ensure(sizeof(float) * (size_t)cn));
     LSQ_TRY(c->vCur.ensure(sizeof(unsigned short) * (size_t)(cn + 8)));      // + 8: icm_xs_kernel's lister reads the words four at a time
@@ -540,13 +536,17 @@ static int encode_chunk(lsq_ctx *c, const float *dXc, const float *dK, int64_t c
     for (int64_t it = 0; it < I; ++it) {
         int32_t order[LSQ_MAX_M];
         LSQ_TRY(lsq_node_order(P.seed, P.it0 + (uint32_t)it, P.m, P.randord, order));
-        const bool probing = it == 0 && c->chunk_q16 && c->probe_div > 0 && I > 1;
+        // The probe: the walk counters of the chunk's first ILS iteration -- or, in a call of ONE iteration (the trainer's chained encoding_icm), of that
+        // iteration's first sweep, the launch being split there -- are read back; a filter that decides too little hands the REST to the f32 walk.
+        // Nothing is remembered across calls (round 3 kept a per-shape verdict: it could not tell two data sets of one shape apart).
+        const bool probing = it == 0 && c->chunk_q16 && c->probe_div > 0 && (I > 1 || P.icmiter > 1);
+        const int probe_sweeps = I > 1 ? P.icmiter : 1;
         if (probing) {
             LSQ_TRY(c->probe.ensure(sizeof(unsigned long long) * LSQ_WALK_COUNTERS));
             LSQ_HIP(hipMemsetAsync(c->probe.p, 0, sizeof(unsigned long long) * LSQ_WALK_COUNTERS, c->stream));
             c->walk_counters = c->probe.as<unsigned long long>();
         }
-        LSQ_TRY(run_sweeps(c, nw, vnew, cn, P.m, order, P.icmiter, cur, vcur));
+        LSQ_TRY(run_sweeps(c, nw, vnew, cn, P.m, order, probing ? probe_sweeps : P.icmiter, cur, vcur));
         if (probing) {
             // Is the filter paying off on THIS chunk?  A level step blown up by a few extreme values (scale-mixture / heavy-tailed data) leaves most
             // node updates ambiguous: each then costs an exact refinement (or, past the block's 1024 records, the one-wave f32 routine) on top of the
@@ -562,6 +562,7 @@ static int encode_chunk(lsq_ctx *c, const float *dXc, const float *dK, int64_t c
                 c->chunk_q16 = false;
                 c->filter_fallback_chunks += 1;
             }
+            LSQ_TRY(run_sweeps(c, nw, vnew, cn, P.m, order, P.icmiter - probe_sweeps, cur, vcur, probe_sweeps));      // the rest of a single-iteration call
         }
         {
             Timer t(c, CAT_COST);
@@ -642,10 +643,6 @@ static int finish_call(lsq_ctx *c, int64_t I, int nr, double *obj_sums, int64_t 
     LSQ_HIP(hipStreamSynchronize(c->stream));
     fold_walk_counters(c, act);
     LSQ_TRY(xs_verdict(c, xs_err));
-    if (I == 1 && c->call_q16_chunks > 0 && c->probe_div > 0) {      // the whole call was its own probe: remember the answer for the next call of this shape
-        const unsigned long long hard = act[4 + LSQ_WALK_TRACE] + act[4 + LSQ_WALK_TRACE + 2];
-        c->sticky_bad = ((long double)hard * (long double)c->probe_div > (long double)act[0]) ? 1 : 0;
-    }
     if (stats) for (int64_t q = 0; q < 2 * I; ++q) stats[q] = (int64_t)cnt[(size_t)q];
     return LSQ_OK;
 }
@@ -698,7 +695,13 @@ static int encode_host(lsq_ctx *c, const char *fn, const float *X, const int16_t
     // The ONE range check of the input codes (1..h): a host scan, hidden under the table kernels just enqueued and done before anything
     // reads B or writes Bs -- an invalid call never touches the caller's output and the codes are not checked twice (ADVICE r2:
     // the device flag of codes_from_i16_kernel is only consulted by the fine-grained entry points, which have no host scan).
-    LSQ_TRY(check_codes_host(fn, B, n, m, h));
+    {
+        const int rc = check_codes_host(fn, B, n, m, h);
+        if (rc != LSQ_OK) {      // the copy of K and the table kernels are in flight: the caller's K must not be read after this returns
+            (void)hipStreamSynchronize(c->stream);
+            return rc;
+        }
+    }
     const EncodeParams P{d, m, ilsiters, nr, icmiter, npert, randord, seed, it0};
     const int cs = lsq_code_stride(m);
     // Chunk c+1's X is uploaded on a second stream under the ILS iterations of chunk c (double-buffered staging).  The first

@@ -100,6 +100,9 @@ def _hip_shard_scanner(device_index):
     return run
 
 
+_SCANNERS = {}      # device index -> the default shard scanner of search_sharded
+
+
 def _pair_keys(dists, ids):
     """(dist, id) pairs -> int64 keys whose order is the pairs' lexicographic order (std::pair<float,int>'s, the reference's partial_sort order,
     linscan_aqd_pairwise_byte.cpp:84): order-preserving float bits << 31 | id.  NaN distances sort last."""
@@ -109,6 +112,19 @@ def _pair_keys(dists, ids):
     k = torch.where(bits < 0, u ^ 0xFFFFFFFF, u ^ 0x80000000)
     k = torch.where(torch.isnan(dists), torch.full_like(k, 0xFFFFFFFF), k)
     return (k << 31) | ids.to(torch.int64)
+
+
+NOID = 2 ** 31 - 1      # id of a padding entry (a shard shorter than knn)
+
+
+def _merge_candidates(d_cat, i_cat, knn):
+    """The knn smallest (distance, id) pairs per row of the gathered candidates.  Padding sorts after EVERYTHING, a genuine NaN-distance result
+    included (lsq_multi_linscan and the single-device scan return such a result last)."""
+    import torch
+    keys = _pair_keys(d_cat, i_cat)
+    keys = torch.where(i_cat == NOID, torch.full_like(keys, torch.iinfo(torch.int64).max), keys)
+    order = torch.argsort(keys, dim=1)[:, :knn]
+    return torch.gather(d_cat, 1, order), torch.gather(i_cat, 1, order)
 
 
 def search_sharded(codes_shard, dbnorms_shard, Q, K, m, knn, n_total, shard_start, group=None, shard_scanner=None):
@@ -130,11 +146,14 @@ def search_sharded(codes_shard, dbnorms_shard, Q, K, m, knn, n_total, shard_star
     if shard_scanner is None:
         if not torch.cuda.is_available():
             raise RuntimeError("no GPU visible: the sharded search has no CPU fallback")
-        shard_scanner = _hip_shard_scanner(torch.cuda.current_device())
+        dev = torch.cuda.current_device()
+        if dev not in _SCANNERS:                 # one Engine (and its multi-GB scan buffers) per device, not per call
+            _SCANNERS[dev] = _hip_shard_scanner(dev)
+        shard_scanner = _SCANNERS[dev]
     n_loc = int(codes_shard.shape[0])
     k_loc = min(knn, n_loc)
     nq = int(Q.shape[0])
-    INF, NOID = float("inf"), 2 ** 31 - 1
+    INF = float("inf")
     d_pad = torch.full((nq, knn), INF, dtype=torch.float32, device=Q.device)
     i_pad = torch.full((nq, knn), NOID, dtype=torch.int32, device=Q.device)
     if k_loc > 0 and nq > 0:
@@ -147,6 +166,4 @@ def search_sharded(codes_shard, dbnorms_shard, Q, K, m, knn, n_total, shard_star
     i_all = [torch.empty_like(i_pad) for _ in range(world)]
     dist.all_gather(d_all, d_pad, group=group)
     dist.all_gather(i_all, i_pad, group=group)
-    d_cat, i_cat = torch.cat(d_all, dim=1), torch.cat(i_all, dim=1)
-    order = torch.argsort(_pair_keys(d_cat, i_cat), dim=1)[:, :knn]
-    return torch.gather(d_cat, 1, order), torch.gather(i_cat, 1, order)
+    return _merge_candidates(torch.cat(d_all, dim=1), torch.cat(i_all, dim=1), knn)

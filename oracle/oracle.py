@@ -18,7 +18,7 @@ _lib = None
 __all__ = [
     "build", "lib", "philox4x32_10", "rng_word", "perm", "perturb", "randinit", "synth_data_u8",
     "sqnorms", "tables", "unaries", "veccost", "icm_node", "encode_icm", "encode_icm_fully", "encoding_icm_faithful",
-    "qerror", "num_threads", "ref_linscan_path", "ref_linscan",
+    "qerror", "num_threads", "ref_linscan_path", "ref_linscan", "reconstruct", "quantize_norms",
 ]
 
 
@@ -215,6 +215,47 @@ def qerror(X, B, K, m, h):
 
 
 # ---- the REAL reference, where it compiles: the ADC linear scan (oracle/_ref) ----------------
+
+def reconstruct(B, C):
+    """Reference src/utils.jl:203-223 restated: CB[:, j] = ((0 + C[0][:, B[0, j]]) + C[1][:, B[1, j]]) + ...  -- codebooks ascending, plain f32
+    adds from +0, one vector at a time (the reference's loop nest is codebook-outer / vector-inner; the sums of ONE vector see the same order).
+    B: (m, n) Int16 1-based, C: list of m (d, h) f32.  -> (d, n) f32.  Checker only: tests/ and the bench's checking legs may call it."""
+    B = np.asarray(B)
+    m, n = B.shape
+    d = np.asarray(C[0]).shape[0]
+    CB = np.zeros((d, n), dtype=np.float32)
+    for j in range(n):                                   # vector by vector: an independent loop order from the product's vectorised mirror
+        acc = np.zeros(d, dtype=np.float32)
+        for i in range(m):
+            acc = acc + np.asarray(C[i], dtype=np.float32)[:, int(B[i, j]) - 1]
+        CB[:, j] = acc
+    return CB
+
+
+def quantize_norms(B, C, cbnorms, want_norms=False):
+    """Reference src/utils.jl:6-31 restated: ithnorm = SUM_j CB[j, i]^2 accumulated in f32 with j ASCENDING, each square rounded before its add
+    (the reference's `@simd` loop leaves the order to the compiler: [build-defined], frozen here as the sequential order); then
+    dists2norm[c] = (ithnorm - cbnorms[c])^2 in f32 and `findmin`: the FIRST index of the minimum (1-based Int16).
+    -> idx (n,) int16 [, norms (n,) f32].  Checker only."""
+    CB = reconstruct(B, C)
+    d, n = CB.shape
+    cb = np.asarray(cbnorms, dtype=np.float32)
+    idx = np.empty(n, dtype=np.int16)
+    norms = np.empty(n, dtype=np.float32)
+    for i in range(n):
+        acc = np.float32(0.0)
+        col = CB[:, i]
+        for j in range(d):
+            acc = np.float32(acc + np.float32(col[j] * col[j]))
+        norms[i] = acc
+        best, bi = None, 0
+        for c in range(cb.shape[0]):                     # strict '<' scan from the first entry = findmin
+            dv = np.float32(np.float32(acc - cb[c]) * np.float32(acc - cb[c]))
+            if best is None or dv < best:
+                best, bi = dv, c
+        idx[i] = bi + 1
+    return (idx, norms) if want_norms else idx
+
 
 def ref_linscan_path():
     p = os.path.join(_HERE, "_ref", "linscan_aqd_pairwise_byte.so")

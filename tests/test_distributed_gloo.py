@@ -165,3 +165,16 @@ def test_product_shard_scanner_refuses_cpu(lsq):
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         lsq.distributed.search_sharded(torch.zeros(4, 2, dtype=torch.uint8), torch.zeros(4), torch.zeros(1, 8), torch.zeros(512, 8), 2, 1,
                                        n_total=4, shard_start=0)
+
+
+def test_merge_puts_padding_after_nan_results():
+    """a shard shorter than knn pads with (+inf, 2^31 - 1); a genuine NaN-distance result must still come before the padding."""
+    import importlib
+    import torch
+    D = importlib.import_module("local-search-quantization_amd.distributed")
+    nan, inf = float("nan"), float("inf")
+    d_cat = torch.tensor([[1.0, nan, inf, 0.5, inf, inf]], dtype=torch.float32)
+    i_cat = torch.tensor([[7, 3, D.NOID, 9, 11, D.NOID]], dtype=torch.int32)
+    d, i = D._merge_candidates(d_cat, i_cat, 4)
+    assert i.tolist() == [[9, 7, 11, 3]]
+    assert d[0, 0] == 0.5 and d[0, 1] == 1.0 and d[0, 2] == inf and torch.isnan(d[0, 3])

@@ -388,10 +388,11 @@ def test_full_size_properties(lsq):
 
 
 @pytest.mark.parametrize("d,m", [(960, 8), (128, 16)])
-def test_large_shape_sample_vs_oracle(lsq, oracle, d, m):
-    """cfg3 (m = 16) and cfg4 (d = 960) shapes: encode 60 000 vectors on the GPU, check a random sample of
-    vectors against the oracle run on exactly those vectors (valid because results depend only on the global
-    index, P8) -- the sample's codes must match bit for bit."""
+def test_small_chunk_road_at_the_large_shapes_sample_vs_oracle(lsq, oracle, d, m):
+    """The SMALL-CHUNK road (n = 60 000 < q16_min: f32 walk, every block light) at the dimensions of cfg3 (m = 16) and cfg4 (d = 960): what a
+    trainer-sized call of those shapes runs.  (The filtered walk at these shapes is covered at their real sizes by tests/test_gpu_staged.py:
+    test_cfg3_m16_staged_sample_and_full_size_properties, test_cfg4_per_gpu_share_runs_the_filtered_walk -- VERDICT r3, weak #8.)  A random
+    sample of vectors against the oracle run on exactly those vectors (results depend only on the global index, P8); the counters assert the road."""
     import torch
     n, ils, J, npert, seed = 60_000, [2], 4, 4, 11
     with lsq.Engine(0) as eng:
@@ -400,6 +401,8 @@ def test_large_shape_sample_vs_oracle(lsq, oracle, d, m):
         dK = eng.synth_codebooks_dev(99, m, d)
         dBs, sums, _ = eng.encode_icm_dev(dX, dB0, dK, m, ils, J, npert, True, seed=seed)
         torch.cuda.synchronize()
+        t = eng.timings()
+        assert t["filtered_blocks"] == 0 and t["staged_blocks"] + t["light_blocks"] > 0, t
         X, K = dX.cpu().numpy(), dK.cpu().numpy()
         B0 = dB0.cpu().numpy().astype(np.int16) + 1
         got = dBs[0].cpu().numpy().astype(np.int16) + 1

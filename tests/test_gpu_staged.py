@@ -178,6 +178,44 @@ def test_cfg5_chunk_walk(lsq, oracle):
 
 
 
+def test_cfg5_full_per_gpu_share(lsq, oracle):
+    """BASELINE configs[4] exactly as ONE GPU of the 8-GPU weak-scaling job runs it (missing #4): 12.5 M x 128 vectors generated ON THE
+    DEVICE at rank 1's offset, default chunking (12 resident chunks of 2^20: X = 6.4 GB, byte offsets pass 2^32), 2 ILS iterations.  Rows on both sides
+    of EVERY chunk boundary + 32 random rows == the oracle on exactly those vectors (P8); every chunk ran the filtered walk; objective = mean cost
+    on one whole chunk (the last full one)."""
+    import torch
+    d, m, ils, J, npert, seed = 128, 8, [2], 4, 4, 5
+    n, goff, chunk = 12_500_000, 12_500_000, 1 << 20
+    with lsq.Engine(0) as eng:
+        dX = eng.synth_data_u8_dev(1234, n, d, global_offset=goff)
+        assert dX.numel() * 4 > (1 << 32)
+        dB0 = eng.randinit_dev(7, n, m, global_offset=goff)
+        dK = eng.synth_codebooks_dev(4321, m, d)
+        dBs, sums, stats = eng.encode_icm_dev(dX, dB0, dK, m, ils, J, npert, True, seed=seed, global_offset=goff)
+        torch.cuda.synchronize()
+        t = eng.timings()
+        assert t["filtered_blocks"] > 0 and t["staged_blocks"] == 0 and t["filter_fallback_chunks"] == 0, t
+        K = dK.cpu().numpy()
+        rng = np.random.default_rng(12)
+        nchunks = (n + chunk - 1) // chunk
+        assert nchunks == 12
+        rows = [0, n - 1] + [c * chunk + o for c in range(1, nchunks) for o in (-1, 0)] + [int(r) for r in rng.choice(n, size=32, replace=False)]
+        rows = np.array(sorted(set(rows)))
+        idx = torch.from_numpy(rows).to(dX.device)
+        Xs = dX[idx].cpu().numpy()
+        B0s = dB0[idx].cpu().numpy().astype(np.int16) + 1
+        gots = dBs[0][idx].cpu().numpy().astype(np.int16) + 1
+        for q, i in enumerate(rows):
+            ref, _ = oracle.encode_icm(Xs[q:q + 1], B0s[q:q + 1], K, m, H, ils, J, npert, True, seed, global_offset=goff + int(i))
+            assert np.array_equal(ref[0, 0], gots[q]), "vector %d (chunk %d) differs" % (i, i // chunk)
+        lo = (nchunks - 2) * chunk                                   # the last FULL chunk (byte offset of its X rows > 4 GiB)
+        c = eng.veccost(dX[lo:lo + chunk].cpu().numpy(), dBs[0][lo:lo + chunk].cpu().numpy().astype(np.int16) + 1, K, m)
+        dq, sq, _ = eng.encode_icm_dev(dX[lo:lo + chunk].contiguous(), dB0[lo:lo + chunk].contiguous(), dK, m, ils, J, npert, True, seed=seed,
+                                       global_offset=goff + lo)
+        assert torch.equal(dq[0], dBs[0][lo:lo + chunk])
+        assert abs(sq[0] / chunk - c.astype(np.float64).mean()) <= 1e-6 * sq[0] / chunk
+
+
 def test_cfg4_per_gpu_share_runs_the_filtered_walk(lsq, oracle):
     """BASELINE configs[3] as ONE GPU of the 8-GPU job runs it: 125 000 x 960 (GIST-like range), m = 8, 16-bit filtered walk by default
     (n >= q16_min), Q16 GEMM epilogue with Kd = 960, the 4096-vector range sample (lsq_icmq.hip: d > 512), global offset of rank 3.
@@ -422,15 +460,16 @@ def test_filter_probe_hands_scale_mixture_chunks_to_the_f32_walk(lsq, oracle):
     assert t["filter_fallback_chunks"] == 2, t
 
 
-def test_single_iteration_calls_remember_the_probe(lsq, oracle):
-    """The trainer's pattern -- chained encoding_icm calls, ONE ILS iteration each -- cannot probe and switch inside a call: the call's own counters are
-    the probe and the NEXT call of the same shape starts on the f32 walk (re-probed every 16th call).  Scale-mixture data, 4 chained calls ==
-    the oracle's chained calls; calls 2..4 must have taken the f32 road; a well-conditioned data set never leaves the filtered walk."""
+def test_single_iteration_calls_probe_their_first_sweep(lsq, oracle):
+    """The trainer's pattern -- chained encoding_icm calls, ONE ILS iteration each: the call's launch is split after its first sweep, whose counters are
+    the probe; the other sweeps run on the road the probe chose.  Nothing is remembered between calls (round 3 kept a per-shape verdict that could not
+    tell two data sets of one shape apart).  Scale-mixture data, 4 chained calls == the oracle's chained calls, every call hands over to the f32 walk
+    after its first sweep; a well-conditioned data set never leaves the filtered walk."""
     d, n, m, seed = 16, 40_000, 8, 80
     rng = np.random.default_rng(seed)
     Xg, K, B0 = make_problem(d, n, m, seed=seed, kind="gauss")
     Xc = (Xg * rng.standard_cauchy((n, 1)).astype(np.float32)).astype(np.float32)
-    for X, expect_fallbacks in ((Xc, 3), (Xg, 0)):
+    for X, expect_fallbacks in ((Xc, 4), (Xg, 0)):
         with lsq.Engine(0, schedule=6, profile=True) as eng:
             eng.set_option("q16_min", 0)
             eng.set_option("light", 0)

@@ -106,6 +106,12 @@ def test_quantize_norms_and_reconstruct(lsq):
     cb2 = np.concatenate([cbnorms[:1], cbnorms[:1], cbnorms[2:]])       # duplicated centroid: first index wins
     q2 = lsq.quantize_norms(B, C, cb2)
     assert not np.any(q2 == 2)
+    # the host mirror against the oracle's independent restatement of src/utils.jl:6-31, 203-223 (the checker lives under oracle/, not in the product)
+    import oracle as O
+    assert np.array_equal(O.reconstruct(B, C).view(np.uint32), CB.view(np.uint32))
+    oq, onorms = O.quantize_norms(B, C, cbnorms, want_norms=True)
+    assert np.array_equal(oq, q) and np.array_equal(O.quantize_norms(B, C, cb2), q2)
+    assert np.allclose(onorms, norms, rtol=1e-5)
 
 
 def test_vecs_readers_roundtrip(lsq, tmp_path):
