@@ -28,6 +28,8 @@
 // Every spin is bounded (give-up code in sync->abort and in the call's error word, reported by the host as an error).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "lsq_q16.h"
 
 #ifdef LSQ_TUNING
@@ -74,7 +76,7 @@ __device__ inline void lds_store(unsigned *w, unsigned v) { __hip_atomic_store(w
 __device__ inline void lds_add(unsigned *w, unsigned v) { __hip_atomic_fetch_add(w, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // control words of a block (LDS)
-enum { XC_LIST0 = 0, XC_LIST1, XC_NACT0, XC_NACT1, XC_NACT2, XC_NACT3, XC_WALK0, XC_WALK1, XC_TABBAR, XC_MRG0, XC_MRG1, XC_CDONE, XC_ABORT, XC_GROUP, XC_SLICE, XC_WORDS = 16 };
+enum { XC_LIST0 = 0, XC_LIST1, XC_NACT0, XC_NACT1, XC_NACT2, XC_NACT3, XC_WALK0, XC_WALK1, XC_TABBAR, XC_MDONE0, XC_MDONE1, XC_MDONE2, XC_MDONE3, XC_CDONE, XC_ABORT, XC_GROUP, XC_SLICE, XC_WORDS = 24 };
 
 struct XsCtl {
     unsigned *c;            // LDS control words
@@ -483,7 +485,11 @@ __global__ __launch_bounds__(1024) void icm_xs_kernel(const XsArgs A, const Walk
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // this wave's partial keys are in L2
             if (wave == 0) XS_STAMP(t, 2);
-            if (lane == 0) lds_add(ctl + XC_WALK0 + (t & 1), 1u);
+            if (lane == 0) {
+                const unsigned before = __hip_atomic_fetch_add(ctl + XC_WALK0 + (t & 1), 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // the LAST walker of the task tells the group: this CU's partial keys of task t are in L2 (a maximum: stores of two waves may overtake)
+                if (before + 1u == (unsigned)(W * (t / 2 + 1))) { atomicMax(progb + slice, (unsigned)(t + 1)); XS_STAMP(t, 9); }
+            }
         }
         return;
     }
@@ -566,147 +572,155 @@ __global__ __launch_bounds__(1024) void icm_xs_kernel(const XsArgs A, const Walk
     {
         // =========================================================== MERGERS ===========================================================
         const int mk = wave - W - NL;                                                 // 0 .. NM-1
+        // Merger mk owns the tasks t = mk (mod NM) WHOLE (this CU's share of them): NM merges are in flight at once, each several global round
+        // trips long (a round trip on a CU whose walkers stream costs 3 - 5 us), so the mergers keep pace with the walkers by throughput, not latency.
         uint32_t *arec = arec0 + mk * ACAP * AREC;
         unsigned *trace = reinterpret_cast<unsigned *>(lds_xs + C::OFF_TRACE) + mk * LSQ_WALK_TRACE;
         for (int e = lane; e < LSQ_WALK_TRACE; e += 64) trace[e] = 0u;
         unsigned st_nodes = 0, st_tasks = 0, st_amb = 0, st_exact = 0, st_f32 = 0;
-        for (int t = 0; t < ntasks; ++t) {
+        for (int t = mk; t < ntasks; t += NM) {
             const int jn = t / Q;
             const int j = nodes.j[jn];
-            if (mk == 0) {
-                if (!X.wait_lds(XC_WALK0 + (t & 1), (unsigned)(W * (t / 2 + 1)), 30u)) return;
-                XS_STAMP(t, 9);
-                if (lane == 0) *reinterpret_cast<volatile unsigned *>(progb + slice) = (unsigned)(t + 1);      // this CU's partial keys of task t are in L2
-            }
-            if (!X.wait_prog(progb, G, (unsigned)(t + 1), 31u)) return;
-            if (mk == 0) XS_STAMP(t, 10);
+            if (!X.wait_prog(progb, G, (unsigned)(t + 1), 31u)) return;              // every CU's partial keys of task t
+            XS_STAMP(t, 10);
             const int nact = (int)lds_load(ctl + XC_NACT0 + (t % XS_R));
             const unsigned short *share = share0 + (t % XS_R) * SCAP;
             const int slo = (int)(((int64_t)nact * slice) / G), shi = (int)(((int64_t)nact * (slice + 1)) / G);      // this CU's share of the task
-            const int mlo = slo + (int)(((int64_t)(shi - slo) * mk) / NM), mhi = slo + (int)(((int64_t)(shi - slo) * (mk + 1)) / NM);
             const unsigned long long *pslot = part_g + (size_t)(t % XS_R) * G * (size_t)clen;
-            const lsq_q16_node &nd = A.P->node[j];
-            const int window = nd.window;
+            const int window = A.P->node[j].window;
             int namb = 0;
-            st_nodes += (unsigned)(mhi - mlo);
-            if (lane == 0) trace[(nodes.pos0 + jn) & (LSQ_WALK_TRACE - 1)] += (unsigned)(mhi - mlo);
-            if (mk == 0 && slice == 0 && nact > 0) st_tasks += 1u;
-            constexpr int VPL = 2;
-            for (int p0 = mlo; p0 < mhi; p0 += 64 * VPL) {
-                if (namb > ACAP - 64 * VPL) {                                          // room for a whole round of ambiguous vectors
+            st_nodes += (unsigned)(shi - slo);
+            if (lane == 0) trace[(nodes.pos0 + jn) & (LSQ_WALK_TRACE - 1)] += (unsigned)(shi - slo);
+            if (slice == 0 && nact > 0) st_tasks += 1u;
+            // Two register sets (index E is a compile-time constant everywhere: plain registers, no private memory): the loads of the next 64 vectors
+            // are issued BEFORE the stores of the current ones (vmcnt counts both, in order), so a round trip overlaps the previous set's work.
+            bool s_on[2];
+            uint32_t s_li[2], s_rw[2][RW], s_rr[2][RW], s_vo[2], s_rv[2], s_qf[2];
+            unsigned long long s_pk[2][G];
+            auto mload = [&](auto EC, int p0) {
+                constexpr int E = decltype(EC)::value;
+                const int p = p0 + lane;
+                s_on[E] = p < shi;
+                s_li[E] = share[(s_on[E] ? p : slo) - slo];
+                const int64_t vi = gb + s_li[E];
+                s_vo[E] = 0; s_rv[E] = 0; s_qf[E] = 0;
+#pragma unroll
+                for (int w2 = 0; w2 < RW; ++w2) { s_rw[E][w2] = 0; s_rr[E][w2] = 0; }
+#pragma unroll
+                for (int s2 = 0; s2 < G; ++s2) s_pk[E][s2] = ~0ull;
+                if (s_on[E]) {
+#pragma unroll
+                    for (int s2 = 0; s2 < G; ++s2) s_pk[E][s2] = ld_l2(pslot + (size_t)s2 * clen + p);
+                    const unsigned long long *rp = reinterpret_cast<const unsigned long long *>(A.rec + vi * CS);
+#pragma unroll
+                    for (int w2 = 0; w2 < RW; w2 += 2) {
+                        const unsigned long long x = ld_l2(rp + w2 / 2);
+                        s_rw[E][w2] = (uint32_t)x; s_rw[E][w2 + 1] = (uint32_t)(x >> 32);
+                    }
+                    if (A.valid) s_vo[E] = ld_l2(A.valid + vi);
+                    s_qf[E] = A.qflag[vi];
+                    if (have_ref) {
+#pragma unroll
+                        for (int w2 = 0; w2 < RW; ++w2) s_rr[E][w2] = reinterpret_cast<const uint32_t *>(A.ref_rec + vi * CS)[w2];
+                        s_rv[E] = A.ref_valid[vi];
+                    }
+                }
+            };
+            auto mproc = [&](auto EC) {
+                constexpr int E = decltype(EC)::value;
+                if (namb > ACAP - 64) {                                                // room for a whole round of ambiguous vectors
                     st_exact += (unsigned)xs_refine<M, SLQ>(A, j, gb, arec, namb, have_ref);
                     st_amb += (unsigned)namb;
                     namb = 0;
                 }
-                bool on[VPL];
-                uint32_t li[VPL];
-                unsigned long long pk[VPL][G];
-                uint32_t rw[VPL][RW], rr[VPL][RW];
-                unsigned short vo[VPL], rv[VPL], qf[VPL];
+                uint32_t kA = (uint32_t)s_pk[E][0], kB = (uint32_t)(s_pk[E][0] >> 32);
 #pragma unroll
-                for (int e = 0; e < VPL; ++e) {
-                    const int p = p0 + e * 64 + lane;
-                    on[e] = p < mhi;
-                    li[e] = share[(on[e] ? p : mlo) - slo];
-                    const int64_t vi = gb + li[e];
-                    vo[e] = 0; rv[e] = 0; qf[e] = 0;
+                for (int s2 = 1; s2 < G; ++s2) top2_merge(kA, kB, (uint32_t)s_pk[E][s2], (uint32_t)(s_pk[E][s2] >> 32));
+                const int64_t vi = gb + s_li[E];
+                const bool vf32 = s_on[E] && ((s_qf[E] >> j) & 1);                    // a unary of this node fell outside the sampled level range
+                const bool vamb = s_on[E] && !vf32 && ((int)(kB >> 16) - (int)(kA >> 16) <= window);
+                const bool von = s_on[E] && !vamb && !vf32;
+                uint32_t rwl[RW], rrl[RW];
 #pragma unroll
-                    for (int w2 = 0; w2 < RW; ++w2) { rw[e][w2] = 0; rr[e][w2] = 0; }
-#pragma unroll
-                    for (int s2 = 0; s2 < G; ++s2) pk[e][s2] = ~0ull;
-                    if (on[e]) {
-#pragma unroll
-                        for (int s2 = 0; s2 < G; ++s2) pk[e][s2] = ld_l2(pslot + (size_t)s2 * clen + p);
-                        const unsigned long long *rp = reinterpret_cast<const unsigned long long *>(A.rec + vi * CS);
-#pragma unroll
-                        for (int w2 = 0; w2 < RW; w2 += 2) {
-                            const unsigned long long x = ld_l2(rp + w2 / 2);
-                            rw[e][w2] = (uint32_t)x; rw[e][w2 + 1] = (uint32_t)(x >> 32);
-                        }
-                        if (A.valid) vo[e] = ld_l2(A.valid + vi);
-                        qf[e] = A.qflag[vi];
+                for (int w2 = 0; w2 < RW; ++w2) { rwl[w2] = s_rw[E][w2]; rrl[w2] = s_rr[E][w2]; }
+                if (von) {                                                             // second - best > window: the best key IS the exact argmin
+                    const uint8_t c8 = (uint8_t)(kA & 0xffu);
+                    const uint8_t old = (uint8_t)(rwl[j >> 2] >> (8 * (j & 3)));
+                    if (c8 != old) store_code<CS>(A.rec, vi, j, c8, rwl);
+                    if (A.valid) {
+                        unsigned short vm = (c8 != old) ? (unsigned short)(1u << j) : (unsigned short)(s_vo[E] | (1u << j));
                         if (have_ref) {
+                            bool same = true;
 #pragma unroll
-                            for (int w2 = 0; w2 < RW; ++w2) rr[e][w2] = reinterpret_cast<const uint32_t *>(A.ref_rec + vi * CS)[w2];
-                            rv[e] = A.ref_valid[vi];
+                            for (int w2 = 0; w2 < RW; ++w2) {
+                                uint32_t mine = rwl[w2];
+                                if (w2 == (j >> 2)) mine = (mine & ~(0xffu << (8 * (j & 3)))) | ((uint32_t)c8 << (8 * (j & 3)));
+                                same = same && (mine == rrl[w2]);
+                            }
+                            if (same) vm = (unsigned short)(vm | s_rv[E]);
                         }
+                        A.valid[vi] = vm;
                     }
                 }
+                {   // ambiguous: every candidate within the window of the best is evaluated exactly (xs_refine); records appended in lane order
+                    const unsigned long long am = __ballot(vamb);
+                    if (am != 0ull) {
+                        const int slot = namb + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(am >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)am, 0u));
+                        if (vamb) {
+                            uint32_t *ar = arec + slot * AREC;
+                            ar[0] = s_li[E] | ((kA & 0xffu) << 16) | ((kB & 0xffu) << 24);
+                            ar[1] = (kA >> 16) + (uint32_t)window;
 #pragma unroll
-                for (int e = 0; e < VPL; ++e) {
-                    uint32_t kA = (uint32_t)pk[e][0], kB = (uint32_t)(pk[e][0] >> 32);
-#pragma unroll
-                    for (int s2 = 1; s2 < G; ++s2) top2_merge(kA, kB, (uint32_t)pk[e][s2], (uint32_t)(pk[e][s2] >> 32));
-                    const int64_t vi = gb + li[e];
-                    const bool vf32 = on[e] && ((qf[e] >> j) & 1);                    // a unary of this node fell outside the sampled level range
-                    const bool vamb = on[e] && !vf32 && ((int)(kB >> 16) - (int)(kA >> 16) <= window);
-                    const bool von = on[e] && !vamb && !vf32;
-                    if (von) {                                                         // second - best > window: the best key IS the exact argmin
-                        const uint8_t c8 = (uint8_t)(kA & 0xffu);
-                        const uint8_t old = (uint8_t)(rw[e][j >> 2] >> (8 * (j & 3)));
-                        if (c8 != old) store_code<CS>(A.rec, vi, j, c8, rw[e]);
-                        if (A.valid) {
-                            unsigned short vm = (c8 != old) ? (unsigned short)(1u << j) : (unsigned short)(vo[e] | (1u << j));
-                            if (have_ref) {
-                                bool same = true;
-#pragma unroll
-                                for (int w2 = 0; w2 < RW; ++w2) {
-                                    uint32_t mine = rw[e][w2];
-                                    if (w2 == (j >> 2)) mine = (mine & ~(0xffu << (8 * (j & 3)))) | ((uint32_t)c8 << (8 * (j & 3)));
-                                    same = same && (mine == rr[e][w2]);
-                                }
-                                if (same) vm = (unsigned short)(vm | rv[e]);
-                            }
-                            A.valid[vi] = vm;
+                            for (int w2 = 0; w2 < RW; ++w2) { ar[2 + w2] = rwl[w2]; ar[3 + RW + w2] = rrl[w2]; }
+                            ar[2 + RW] = s_vo[E] | (s_rv[E] << 16);
                         }
-                    }
-                    {   // ambiguous: every candidate within the window of the best is evaluated exactly (xs_refine); records appended in lane order
-                        const unsigned long long am = __ballot(vamb);
-                        if (am != 0ull) {
-                            const int slot = namb + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(am >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)am, 0u));
-                            if (vamb) {
-                                uint32_t *ar = arec + slot * AREC;
-                                ar[0] = li[e] | ((kA & 0xffu) << 16) | ((kB & 0xffu) << 24);
-                                ar[1] = (kA >> 16) + (uint32_t)window;
-#pragma unroll
-                                for (int w2 = 0; w2 < RW; ++w2) { ar[2 + w2] = rw[e][w2]; ar[3 + RW + w2] = rr[e][w2]; }
-                                ar[2 + RW] = (uint32_t)vo[e] | ((uint32_t)rv[e] << 16);
-                            }
-                            namb += __builtin_popcountll(am);
-                        }
-                    }
-                    unsigned long long fm = __ballot(vf32);                            // outside the level range: the whole wave, full f32, one vector at a time
-                    while (fm != 0ull) {
-                        const int L = __builtin_ctzll(fm);
-                        fm &= fm - 1ull;
-                        uint32_t urw[RW], urr[RW];
-#pragma unroll
-                        for (int w2 = 0; w2 < RW; ++w2) {
-                            urw[w2] = (uint32_t)__builtin_amdgcn_readlane((int)rw[e][w2], L);
-                            urr[w2] = (uint32_t)__builtin_amdgcn_readlane((int)rr[e][w2], L);
-                        }
-                        const uint32_t uli = (uint32_t)__builtin_amdgcn_readlane((int)li[e], L);
-                        const uint32_t uvo = (uint32_t)__builtin_amdgcn_readlane((int)vo[e], L), urv = (uint32_t)__builtin_amdgcn_readlane((int)rv[e], L);
-                        xs_f32_update<M, CS>(A, j, gb + uli, urw, uvo, urr, urv, have_ref, lane);
-                        st_f32 += 1u;
+                        namb += __builtin_popcountll(am);
                     }
                 }
+                unsigned long long fm = __ballot(vf32);                                // outside the level range: the whole wave, full f32, one vector at a time
+                while (fm != 0ull) {
+                    const int L = __builtin_ctzll(fm);
+                    fm &= fm - 1ull;
+                    uint32_t urw[RW], urr[RW];
+#pragma unroll
+                    for (int w2 = 0; w2 < RW; ++w2) {
+                        urw[w2] = (uint32_t)__builtin_amdgcn_readlane((int)rwl[w2], L);
+                        urr[w2] = (uint32_t)__builtin_amdgcn_readlane((int)rrl[w2], L);
+                    }
+                    const uint32_t uli = (uint32_t)__builtin_amdgcn_readlane((int)s_li[E], L);
+                    const uint32_t uvo = (uint32_t)__builtin_amdgcn_readlane((int)s_vo[E], L), urv = (uint32_t)__builtin_amdgcn_readlane((int)s_rv[E], L);
+                    xs_f32_update<M, CS>(A, j, gb + uli, urw, uvo, urr, urv, have_ref, lane);
+                    st_f32 += 1u;
+                }
+            };
+            using E0 = std::integral_constant<int, 0>;
+            using E1 = std::integral_constant<int, 1>;
+            mload(E0{}, slo);
+            for (int p0 = slo; p0 < shi; p0 += 128) {
+                mload(E1{}, p0 + 64);
+                mproc(E0{});
+                mload(E0{}, p0 + 128);
+                mproc(E1{});
             }
             if (namb > 0) {
                 st_exact += (unsigned)xs_refine<M, SLQ>(A, j, gb, arec, namb, have_ref);
                 st_amb += (unsigned)namb;
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // this wave's records and validity words are in L2
-            if (mk == 0) { XS_STAMP(t, 11); XS_NOTE(t, 13, namb); }
-            if (lane == 0) lds_add(ctl + XC_MRG0 + (t & 1), 1u);
-            if (mk == 0) {
-                if (!X.wait_lds(XC_MRG0 + (t & 1), (unsigned)(NM * (t / 2 + 1)), 32u)) return;
-                if (lane == 0) {
-                    *reinterpret_cast<volatile unsigned *>(progc + slice) = (unsigned)(t + 1);
-                    lds_store(ctl + XC_CDONE, (unsigned)(t + 1));
+            XS_STAMP(t, 11); XS_NOTE(t, 13, namb);
+            if (lane == 0) {
+                // merges finish out of order: publish the contiguous prefix.  Store my flag, THEN read the others' (the LDS executes a wave's
+                // operations in order and everybody's in one sequence: of two mergers finishing together at least one sees both flags)
+                lds_store(ctl + XC_MDONE0 + (t % XS_R), (unsigned)(t + 1));
+                unsigned c = lds_load(ctl + XC_CDONE);
+                const unsigned c0 = c;
+                while (c < (unsigned)ntasks && lds_load(ctl + XC_MDONE0 + (c % XS_R)) == c + 1u) ++c;
+                if (c > c0) {
+                    __hip_atomic_fetch_max(ctl + XC_CDONE, c, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    atomicMax(progc + slice, c);
                 }
-                XS_STAMP(t, 12);
             }
+            XS_STAMP(t, 12);
         }
         if (A.active_total) {
             // st_exact is per lane (16-lane groups count their own survivors); everything else is wave-uniform
