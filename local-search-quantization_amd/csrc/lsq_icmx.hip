@@ -494,6 +494,7 @@ __global__ __launch_bounds__(1024) void icm_xs_kernel(const XsArgs A, const Walk
         return;
     }
 
+    __builtin_amdgcn_s_setprio(3);      // listers and mergers: little work on the critical path -- ahead of the walkers in the SIMD's arbitration
     if (wave < W + NL) {
         // =========================================================== LISTERS ===========================================================
         // Lister l owns list buffer l and the tasks t = l (mod 2).  It scans the cohort's validity words -- 16 bytes (8 vectors) per lane and load,
