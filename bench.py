@@ -316,16 +316,22 @@ def search_leg(lsq, eng, dK, dcodes, n, d, m, nq=10000, knn=1000):
            "breakdown_ms": {k: st[k] / reps for k in ("lut_ms", "sample_ms", "scan_ms", "select_ms")},
            "table_lookups_per_s": lookups / dt,
            "roofline": {"kernel": "adc_scan_kernel", "bound": "lds", "achieved": lookups * 16 / 4 * reps / (st["scan_ms"] * 1e-3) / 1e12 if st["scan_ms"] > 0 else None,
-                        "peak": 64.0, "unit": "TB/s",
-                        "note": "16-byte LDS reads of random 64-byte table rows (one code x four queries each) during the scan kernel alone; peak = what "
-                                "tools/ubench_lds measures for exactly this access pattern on this part (profiles/ubench_lds_*.txt: 63.9 TB/s; linear "
-                                "conflict-free reads 76.7 TB/s)"},
+                        "peak": 150.0, "unit": "TB/s", "pattern_ceiling": 150.0 / 2.125, "measured_linear": 76.5, "measured_pattern": 58.4,
+                        "note": "16-byte LDS reads of random 64-byte table rows (one code x four queries each) during the scan kernel alone.  peak = the guide's "
+                                "ds_read_b128 rate (MI355X_MICROARCH.md, LDS: 256 B/clk/CU).  pattern_ceiling = that rate divided by the bank conflicts this access "
+                                "pattern cannot avoid: a b128 read is served in four fixed 16-lane groups of 256 B; a group holds four codes = four RANDOM 64-byte rows, "
+                                "each aligned to one quarter of the bank row, and costs max(rows per quarter) cycles: E = 544/256 = 2.125 for four uniform rows (no static "
+                                "layout does better: any two rows share slots with probability >= 1/4).  SQ_LDS_BANK_CONFLICT / IDX_ACTIVE = 0.48 is that expectation.  "
+                                "measured_linear / measured_pattern: what tools/ubench_lds (kraw: 16 independent ds_read_b128 per wait, ONE VALU op per read, 16 waves per CU) reaches "
+                                "on this part for contiguous 1 KiB reads and for this pattern (profiles/r04_ubench_lds.txt) -- half the guide's figure, unexplained"},
            "candidates_per_query": st["candidates"] / max(st["queries"], 1), "fallback_queries": int(st["fallback_queries"]),
            "threshold_rank": int(st["threshold_rank"]), "list_capacity": int(st["list_capacity"]),
            "note": "lsq_linscan_dev on the codes of the timed encode, inputs resident in HBM; distances, ids and tie order identical to the reference's "
                    "linscan_aqd_query_extra_byte (checked below on a sample of the queries)"}
     if res["roofline"]["achieved"]:
         res["roofline"]["frac"] = res["roofline"]["achieved"] / res["roofline"]["peak"]
+        res["roofline"]["frac_of_pattern_ceiling"] = res["roofline"]["achieved"] / res["roofline"]["pattern_ceiling"]
+        res["roofline"]["frac_of_measured_pattern"] = res["roofline"]["achieved"] / res["roofline"]["measured_pattern"]
     # CPU figures + checks on a bounded sample of the queries
     nh = min(nq, 512)
     codes_h, Q_h, K_h, N_h = dcodes.cpu().numpy(), dQ[:nh].cpu().numpy(), dK.cpu().numpy(), dN.cpu().numpy()

@@ -107,8 +107,8 @@ LSQ_API int lsq_set_stream(lsq_ctx *ctx, void *hip_stream);
  *        4           f32 walk, one launch per ILS iteration: the block runs the icmiter x m node updates back to back, walking all LDS-staged
  *                    f32 table slices for each; f32 unaries streamed slice-major from HBM;
  *        3           the f32 walk, one launch per node update;
- *        0, 1, 2     (liblsq_mi355x_tuning.so only) per-node L2 gathers / fused sweeps with register-resident unaries / one slice per block +
- *                    combine kernel: the measured alternatives of DESIGN.md, kept as independent implementations for cross-checks;
+ *        7           (liblsq_mi355x_tuning.so only) the filtered walk with the slices of a node spread over the CUs of an XCD (csrc/lsq_icmx.hip): a persistent,
+ *                    wave-specialised kernel -- bit-exact, measured slower than 6, kept as an independent implementation for cross-checks;
  *   "q16_min" (default 65536): schedule 6 applies to chunks with at least this many vectors (below, every block is "light": nothing to filter);
  *   "per_node" (0/1, default 0): schedule 6 with one launch per node update (profiling: per-sweep timings and counters);
  *   "light" (default 160 in the filtered walk, 256 in the f32 walk: the measured crossovers): a block with at most this many active vectors
@@ -127,8 +127,10 @@ LSQ_API int lsq_set_stream(lsq_ctx *ctx, void *hip_stream);
  *   "filter_probe_div" (default 8): after the FIRST ILS iteration of a resident chunk schedule 6 reads that iteration's counters and runs the
  *        remaining iterations as schedule 4 when more than 1 / div of the recomputed node updates needed the exact refinement or the f32 routine
  *        (a level step blown up by a few extreme values: scale-mixture / heavy-tailed data); 0 = never.  Same codes.  A call of ONE ILS iteration
- *        (lsq_encoding_icm chained by a trainer) is its own probe: the next single-iteration call of the same shape on this context starts on the
- *        f32 walk when this one came out badly (re-probed every 16th call).
+ *        (lsq_encoding_icm chained by a trainer) splits its launch after the first SWEEP and probes that; nothing is remembered between calls.
+ *   "async" (0/1, default 0): lsq_encode_icm_dev without any host synchronisation (see there).  Which entry points block: every entry point that
+ *        takes or returns HOST buffers waits for its results; lsq_encode_icm_dev waits (per chunk: verdict, probe; at the end: sums) unless "async" = 1;
+ *        lsq_linscan_dev, lsq_quantize_norms_dev and lsq_update_codebooks_dev read small control words back (threshold lists, convergence counter) and wait.
  *   "ils_counter": the next iteration index used by lsq_encoding_icm / lsq_encode_icm_fully when called with it = LSQ_IT_AUTO
  *        (starts at 0, advances by one per such call).
  *   (liblsq_mi355x_tuning.so only) "ablation": timing-only kernel variants whose results are garbage. */
@@ -173,8 +175,14 @@ LSQ_API int lsq_encode_icm(lsq_ctx *ctx, const float *RX, const int16_t *B, cons
                    int nsplits, uint64_t seed, uint64_t global_offset, int verbose,
                    int16_t *Bs, float *objs);
 
-/* Same call on DEVICE-resident buffers: launches go to the context's stream; the host waits once per resident chunk
- * (schedule 6 reads the chunk's three-word verdict after the unary GEMM) and for the final read-back of nr objective sums.  dB0 / dBs: uint8 0-based [n][m] (dBs: nr of them).
+/* Same call on DEVICE-resident buffers: launches go to the context's stream.  BLOCKING by default: the host waits once per resident chunk for the
+ * chunk's three-word verdict after the unary GEMM, once more for the probe after the first ILS iteration, and at the end for the read-back of the
+ * objective sums and counters.  Option "async" = 1 removes every one of those waits: the verdict and the probe are taken by one-thread kernels, BOTH walk
+ * kernels are enqueued each ILS iteration (the one the device word does not name returns at once: ~3 us per launch), and obj_sums / stats are written in
+ * stream order -- they must then be DEVICE pointers or PINNED host memory, and are valid once the stream has been synchronised by the caller.  With "async"
+ * the call contains no host synchronisation and no allocation once the context's work buffers have the size of the shape (i.e. from the second call of
+ * that shape on): it can be captured into a hipGraph.  Walk statistics of async calls are folded into lsq_get_timings at its next call (which waits).
+ * dB0 / dBs: uint8 0-based [n][m] (dBs: nr of them).
  * obj_sums (host, nr doubles) receives SUM_i cost_i (not the mean) so that a multi-GPU caller
  * can add shards; objs = obj_sums / n_total.  stats (host, optional, 2*max(ilsiters) int64):
  * per ILS iteration the number of vectors whose new cost was == / < the previous one

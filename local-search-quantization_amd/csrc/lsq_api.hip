@@ -70,6 +70,13 @@ struct lsq_ctx {
     int64_t xs_fallback_launches = 0;                  // launches whose start barrier said no (the predicated icm_walkq_kernel launch did the work)
     DevBuf Uq, Tq, qp, qscratch, qflag, qsigma;                // 16-bit filtered walk: u16 unary planes, u16 slice tables, lsq_q16_params, bound scratch, per-vector out-of-range flags
     bool chunk_q16 = false;                            // the resident chunk runs the filtered walk (set by build_unaries from the chunk's verdict)
+    // option "async" (lsq_encode_icm_dev only): no host round trip inside the call and none at its end -- the chunk's road (verdict after the unary
+    // GEMM, probe after the first ILS iteration) is decided by one-thread kernels into `road`, BOTH walks are enqueued every ILS iteration and the one
+    // the word does not name returns at once; objective sums and counters are copied to the caller's (device or pinned) buffers on the stream
+    int async_mode = 0;
+    bool chunk_road_dev = false;                       // this chunk's road lives in road[0] (2 = filtered, 0 = f32), not in chunk_q16
+    bool pending_fold = false;                         // async calls left walk statistics in `active` / road[1]: folded at the next synchronising entry point
+    DevBuf road;
     int64_t fallback_div = 64;                         // option "filter_fallback_div": the chunk goes to the f32 walk when flagged pairs * div > all pairs (0 = never)
     int64_t filter_fallback_chunks = 0;                // chunks the filter handed to the f32 walk (unusable bounds or too many out-of-range vectors)
     int64_t call_I = 0, call_q16_chunks = 0;
@@ -88,6 +95,13 @@ struct lsq_ctx {
     struct Pending { hipEvent_t a, b; int cat; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> pool;
+};
+
+static int fold_pending(lsq_ctx *c);
+struct AsyncOff {        // option "async" applies to lsq_encode_icm_dev alone: every other entry point returns results through host memory it must wait for
+    lsq_ctx *c; int saved;
+    explicit AsyncOff(lsq_ctx *ctx) : c(ctx), saved(ctx ? ctx->async_mode : 0) { if (c) c->async_mode = 0; }
+    ~AsyncOff() { if (c) c->async_mode = saved; }
 };
 
 static int use_device(lsq_ctx *ctx) {
@@ -160,7 +174,7 @@ extern "C" int lsq_destroy(lsq_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : c->pool) (void)hipEventDestroy(e);
-    DevBuf *bufs[] = {&c->xsPart, &c->xsSync, &c->xsErr, &c->probe, &c->Uq, &c->Tq, &c->qp, &c->qscratch, &c->qflag, &c->qsigma, &c->sci, &c->T, &c->Ts, &c->U, &c->vCur, &c->vNew, &c->active, &c->recCur, &c->recNew, &c->prev, &c->counters, &c->obj, &c->bad,
+    DevBuf *bufs[] = {&c->road, &c->xsPart, &c->xsSync, &c->xsErr, &c->probe, &c->Uq, &c->Tq, &c->qp, &c->qscratch, &c->qflag, &c->qsigma, &c->sci, &c->T, &c->Ts, &c->U, &c->vCur, &c->vNew, &c->active, &c->recCur, &c->recNew, &c->prev, &c->counters, &c->obj, &c->bad,
                       &c->sX, &c->sX2, &c->sK, &c->sB16, &c->sOut16, &c->sTight, &c->sF32};
     for (DevBuf *b : bufs) b->release();
     lsq_adc_free(c->adc);
@@ -194,6 +208,7 @@ extern "C" int lsq_set_option(lsq_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "fallback")) c->fallback = (int)value;
     else if (!strcmp(key, "q16_min")) c->q16_min = value;
     else if (!strcmp(key, "xs_min")) c->xs_min = value;
+    else if (!strcmp(key, "async")) c->async_mode = value != 0;
     else if (!strcmp(key, "per_node")) c->per_node = value != 0;
     else if (!strcmp(key, "filter_probe_div")) {
         if (value < 0) { lsq_set_error("filter_probe_div must be >= 0"); return LSQ_EINVAL; }
@@ -226,6 +241,7 @@ extern "C" int lsq_set_option(lsq_ctx *c, const char *key, int64_t value) {
 extern "C" int lsq_get_timings(lsq_ctx *c, lsq_timings *out) {
     LSQ_TRY(use_device(c));
     if (!out) { lsq_set_error("lsq_get_timings: null out"); return LSQ_EINVAL; }
+    LSQ_TRY(fold_pending(c));
     LSQ_TRY(resolve_timings(c));
     out->tables_ms = c->cat_ms[CAT_TABLES];
     out->unaries_ms = c->cat_ms[CAT_UNARIES];
@@ -255,6 +271,7 @@ extern "C" int lsq_get_walk_trace(lsq_ctx *c, int64_t *out, int count) {
 
 extern "C" int lsq_reset_timings(lsq_ctx *c) {
     LSQ_TRY(use_device(c));
+    LSQ_TRY(fold_pending(c));
     LSQ_TRY(resolve_timings(c));
     for (double &v : c->cat_ms) v = 0.0;
     c->icm_launches = c->icm_node_updates = c->staged_blocks = c->light_blocks = c->filtered_blocks = c->filter_refined = c->filter_exact = c->filter_f32 = 0;
@@ -416,7 +433,14 @@ static int build_unaries(lsq_ctx *c, const float *dX, const float *dK, int d, in
                                       dq ? c->qflag.as<unsigned short>() : nullptr, nullptr, 1, dq ? c->qsigma.as<float>() : nullptr,
                                       dq ? c->q_colshift : nullptr));
     }
-    if (q16) {
+    c->chunk_road_dev = false;
+    if (q16 && c->async_mode) {
+        // option "async": the same verdict taken by a one-thread kernel; both walks are enqueued and the word picks (run_sweeps)
+        LSQ_TRY(c->road.ensure(2 * sizeof(unsigned)));
+        LSQ_TRY(lsq_launch_q16_road(c->stream, c->qp.as<lsq_q16_params>(), c->road.as<unsigned>(), cn * (int64_t)m, c->fallback_div));
+        c->chunk_q16 = true;
+        c->chunk_road_dev = true;
+    } else if (q16) {
         // The chunk's verdict (three words, ONE host round trip per resident chunk -- 10^6 vectors, ~50 ms of work): usable bounds, and few enough
         // (vector, node) pairs outside the sampled level range.  Such pairs take the one-wave-per-vector f32 routine inside the filtered walk (~5x the
         // cost of a filtered update): above 1 / filter_fallback_div of the pairs -- heavy tails, a drifting or sorted chunk -- the f32 walk is the
@@ -465,11 +489,18 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t c
                                               c->xsErr.as<unsigned>(), &gate));
 #endif
                 if (xs) c->xs_launches += 1;
+                if (c->chunk_road_dev) gate = c->road.as<unsigned>();      // option "async": runs iff road[0] == 2
                 LSQ_TRY(lsq_launch_icm_walkq(c->stream, c->U.as<float>(), c->Uq.as<uint16_t>(), c->Tq.as<uint16_t>(), c->T.as<float>(), rec, valid, cn, m,
                                              seq.data() + done, cntn, pos_base + (int)done, c->skip, c->walk_counters, c->light,
                                              c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr, P, c->qflag.as<unsigned short>(), gate));
             }
             c->icm_launches += ((int64_t)seq.size() + (int64_t)per_launch - 1) / (int64_t)per_launch;
+            if (c->chunk_road_dev) {      // ... and the f32 walk behind it idles on the same word (road[0] != 0) or does the work (road[0] == 0)
+                LSQ_TRY(lsq_launch_icm_walk(c->stream, c->U.as<float>(), c->Ts.as<float>(), c->T.as<float>(), rec, valid, cn, m, seq.data(), (int)seq.size(), pos_base,
+                                            c->skip, c->walk_counters, c->ablation, c->light, c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr,
+                                            reinterpret_cast<const int *>(c->road.as<unsigned>())));
+                c->icm_launches += ((int64_t)seq.size() + 63) / 64;
+            }
             return LSQ_OK;
         }
         {
@@ -499,6 +530,7 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t c
 }
 
 static void fold_walk_counters(lsq_ctx *c, const unsigned long long *act);
+static int fold_pending(lsq_ctx *c);
 
 struct EncodeParams {
     int d, m;
@@ -547,7 +579,12 @@ static int encode_chunk(lsq_ctx *c, const float *dXc, const float *dK, int64_t c
             c->walk_counters = c->probe.as<unsigned long long>();
         }
         LSQ_TRY(run_sweeps(c, nw, vnew, cn, P.m, order, probing ? probe_sweeps : P.icmiter, cur, vcur));
-        if (probing) {
+        if (probing && c->chunk_road_dev) {
+            // option "async": the same probe by a one-thread kernel (it also adds the probed launches' statistics to the call's)
+            c->walk_counters = c->active.as<unsigned long long>();
+            LSQ_TRY(lsq_launch_q16_probe(c->stream, c->probe.as<unsigned long long>(), c->active.as<unsigned long long>(), c->road.as<unsigned>(), c->probe_div));
+            LSQ_TRY(run_sweeps(c, nw, vnew, cn, P.m, order, P.icmiter - probe_sweeps, cur, vcur, probe_sweeps));
+        } else if (probing) {
             // Is the filter paying off on THIS chunk?  A level step blown up by a few extreme values (scale-mixture / heavy-tailed data) leaves most
             // node updates ambiguous: each then costs an exact refinement (or, past the block's 1024 records, the one-wave f32 routine) on top of the
             // level walk, and the f32 walk is several times faster (measured: Cauchy-scaled vectors 2.2 M vectors/s filtered, 13 M on the f32 walk).
@@ -611,7 +648,12 @@ static int begin_call(lsq_ctx *c, int64_t I, int nr) {
     LSQ_TRY(c->obj.ensure(sizeof(double) * (size_t)std::max(nr, 1)));
     LSQ_TRY(c->bad.ensure(sizeof(int)));
     LSQ_TRY(c->active.ensure(sizeof(unsigned long long) * LSQ_WALK_COUNTERS));
-    LSQ_HIP(hipMemsetAsync(c->active.p, 0, sizeof(unsigned long long) * LSQ_WALK_COUNTERS, c->stream));
+    LSQ_TRY(c->road.ensure(2 * sizeof(unsigned)));
+    if (!c->async_mode) LSQ_TRY(fold_pending(c));             // statistics an earlier async call left on the device (synchronises)
+    if (!c->pending_fold) {                                  // consecutive async calls accumulate: folded by the next synchronising entry point
+        LSQ_HIP(hipMemsetAsync(c->active.p, 0, sizeof(unsigned long long) * LSQ_WALK_COUNTERS, c->stream));
+        LSQ_HIP(hipMemsetAsync(c->road.p, 0, 2 * sizeof(unsigned), c->stream));
+    }
     c->walk_counters = c->active.as<unsigned long long>();
     c->call_q16_chunks = 0;
     LSQ_HIP(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long) * 2 * (size_t)std::max<int64_t>(I, 1), c->stream));
@@ -632,7 +674,30 @@ static void fold_walk_counters(lsq_ctx *c, const unsigned long long *act) {
     for (int q = 0; q < LSQ_WALK_TRACE; ++q) c->trace[q] += (int64_t)act[4 + q];
 }
 
+// statistics of async calls (walk counters, chunks handed to the f32 walk) are still on the device: read, fold, clear -- synchronises the stream
+static int fold_pending(lsq_ctx *c) {
+    if (!c->pending_fold) return LSQ_OK;
+    c->pending_fold = false;
+    unsigned long long act[LSQ_WALK_COUNTERS] = {0};
+    unsigned road[2] = {0u, 0u};
+    LSQ_HIP(hipMemcpyAsync(act, c->active.p, sizeof(act), hipMemcpyDeviceToHost, c->stream));
+    LSQ_HIP(hipMemcpyAsync(road, c->road.p, sizeof(road), hipMemcpyDeviceToHost, c->stream));
+    LSQ_HIP(hipMemsetAsync(c->active.p, 0, sizeof(act), c->stream));
+    LSQ_HIP(hipMemsetAsync(c->road.as<unsigned>() + 1, 0, sizeof(unsigned), c->stream));
+    LSQ_HIP(hipStreamSynchronize(c->stream));
+    fold_walk_counters(c, act);
+    c->filter_fallback_chunks += (int64_t)road[1];
+    return LSQ_OK;
+}
+
 static int finish_call(lsq_ctx *c, int64_t I, int nr, double *obj_sums, int64_t *stats) {
+    if (c->async_mode) {
+        // nothing waits: the sums and counters travel to the caller's buffers (device memory, or pinned host memory) in stream order
+        LSQ_HIP(hipMemcpyAsync(obj_sums, c->obj.p, sizeof(double) * (size_t)nr, hipMemcpyDefault, c->stream));
+        if (stats) LSQ_HIP(hipMemcpyAsync(stats, c->counters.p, sizeof(unsigned long long) * 2 * (size_t)I, hipMemcpyDefault, c->stream));      // counts < 2^63: the same bits as int64
+        c->pending_fold = true;
+        return LSQ_OK;
+    }
     std::vector<unsigned long long> cnt(2 * (size_t)std::max<int64_t>(I, 1));
     LSQ_HIP(hipMemcpyAsync(obj_sums, c->obj.p, sizeof(double) * (size_t)nr, hipMemcpyDeviceToHost, c->stream));
     LSQ_HIP(hipMemcpyAsync(cnt.data(), c->counters.p, sizeof(unsigned long long) * cnt.size(), hipMemcpyDeviceToHost, c->stream));
@@ -682,6 +747,7 @@ static int encode_host(lsq_ctx *c, const char *fn, const float *X, const int16_t
                        const int64_t *ilsiters, int nr, int icmiter, int npert, int randord, uint64_t seed, uint32_t it0,
                        uint64_t global_offset, int verbose, int16_t *Bs, float *objs, const HostPlacement *place = nullptr) {
     LSQ_TRY(use_device(c));
+    const AsyncOff sync_here(c);
     int64_t I = 0;
     LSQ_TRY(validate_encode(fn, d, n, m, h, ilsiters, nr, icmiter, npert, &I));
     if (!K || (!objs && !place) || (n > 0 && (!X || !B || !Bs))) { lsq_set_error("%s: null pointer", fn); return LSQ_EINVAL; }
@@ -955,6 +1021,7 @@ static int upload_codes(lsq_ctx *c, const int16_t *B, int64_t n, int m, int h, D
 extern "C" int lsq_encode_icm_fully(lsq_ctx *c, int16_t *B, const float *X, const float *K, int d, int64_t n, int m, int h, int niter,
                                     int randord, int npert, int64_t idx_first, uint64_t seed, uint32_t it) {
     LSQ_TRY(use_device(c));
+    const AsyncOff sync_here(c);
     LSQ_TRY(check_shape("lsq_encode_icm_fully", d, n, m, h));
     if (!K || niter < 0 || npert < 0 || idx_first < 1 || (n > 0 && (!B || !X))) { lsq_set_error("lsq_encode_icm_fully: bad arguments"); return LSQ_EINVAL; }
     const bool autoit = it == LSQ_IT_AUTO;      // the context's counter advances only when the call succeeds (as in lsq_encoding_icm)

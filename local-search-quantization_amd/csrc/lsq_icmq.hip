@@ -860,6 +860,36 @@ extern "C" __attribute__((visibility("default"))) int lsq_tuning_set_walkq_block
 }
 #endif
 
+// ---- the chunk's road decided ON THE DEVICE (option "async": no host round trip anywhere in the call) ------------------------------------------
+// road[0]: 2 = the filtered walk runs this chunk (icm_walkq_kernel's `gate`; the f32 walk launched behind it idles on the same word), 0 = the f32 walk
+// does; road[1] += 1 whenever a chunk is handed to the f32 walk.  Same rules as the host's: verdict after the unary GEMM (usable bounds, at most
+// 1 / fallback_div of the (vector, node) pairs outside the sampled level range), probe after the first ILS iteration (or first sweep).
+__global__ void q16_road_kernel(const lsq_q16_params *__restrict__ P, unsigned *__restrict__ road, long long pairs, long long fallback_div) {
+    if (threadIdx.x != 0) return;
+    const bool filtered = P->ok == 1 && (long long)P->nflag * fallback_div <= pairs;
+    road[0] = filtered ? 2u : 0u;
+    if (!filtered) road[1] += 1u;
+}
+__global__ void q16_probe_kernel(const unsigned long long *__restrict__ probe, unsigned long long *__restrict__ totals, unsigned *__restrict__ road,
+                                 unsigned long long probe_div) {
+    const int e = threadIdx.x;
+    if (e < LSQ_WALK_COUNTERS && totals) totals[e] += probe[e];      // the probed launches' statistics join the call's
+    if (e == 0 && road[0] == 2u && probe_div > 0) {
+        const unsigned long long hard = probe[4 + LSQ_WALK_TRACE] + probe[4 + LSQ_WALK_TRACE + 2];
+        if ((double)hard * (double)probe_div > (double)probe[0]) { road[0] = 0u; road[1] += 1u; }
+    }
+}
+int lsq_launch_q16_road(hipStream_t s, const lsq_q16_params *P, unsigned *road, int64_t pairs, int64_t fallback_div) {
+    hipLaunchKernelGGL(q16_road_kernel, dim3(1), dim3(64), 0, s, P, road, (long long)pairs, (long long)fallback_div);
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}
+int lsq_launch_q16_probe(hipStream_t s, const unsigned long long *probe, unsigned long long *totals, unsigned *road, int64_t probe_div) {
+    hipLaunchKernelGGL(q16_probe_kernel, dim3(1), dim3(128), 0, s, probe, totals, road, (unsigned long long)probe_div);
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}
+
 int lsq_q16_slice_width(int m) {
 #ifdef LSQ_TUNING
     if (m <= 8 && LSQ_KNOB("LSQ_WALKQ_BPC", 1) == 2) return 16;

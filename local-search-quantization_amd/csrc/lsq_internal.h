@@ -173,6 +173,9 @@ int lsq_launch_icm_walkq(hipStream_t s, const float *U, const uint16_t *Uq, cons
                          int64_t n, int m, const int32_t *order, int nnodes, int pos0, int use_skip, unsigned long long *active_total, int light,
                          const uint8_t *ref_rec, const unsigned short *ref_valid, const lsq_q16_params *P, const unsigned short *qflag,
                          const unsigned *gate = nullptr);
+// option "async": the chunk's road decided on the device (lsq_icmq.hip): road[0] = 2 filtered walk / 0 f32 walk, road[1] = chunks handed over
+int lsq_launch_q16_road(hipStream_t s, const lsq_q16_params *P, unsigned *road, int64_t pairs, int64_t fallback_div);
+int lsq_launch_q16_probe(hipStream_t s, const unsigned long long *probe, unsigned long long *totals, unsigned *road, int64_t probe_div);
 // gate (optional, device): the launch is the stand-in of an icm_xs_kernel launch and runs only when *gate == 2 (that launch's start barrier said no)
 // Schedule 7 (lsq_icmx.hip): the slices of a node spread over the CUs of an XCD, walker / lister / merger waves.  Same contract as
 // lsq_launch_icm_walkq for <= LSQ_WALK_MAX_NODES (64) node updates; part / syncb: work buffers owned by the context; err: two words zeroed

@@ -115,9 +115,11 @@ class Engine:
 
     # -- (1b) whole call, device-resident torch tensors -------------------------------------
     def encode_icm_dev(self, dX, dB0, dK, m, ilsiters, icmiter, npert, randord, seed=0, global_offset=0,
-                       out=None, h=H):
+                       out=None, h=H, nonblocking=False):
         """dX (n,d) f32, dB0 (n,m) u8 0-based, dK (m*h,d) f32: CUDA/HIP torch tensors.
-        -> dBs (nr, n, m) uint8 tensor, obj_sums (nr,) float64 numpy (SUM of costs), stats (I, 2) int64."""
+        -> dBs (nr, n, m) uint8 tensor, obj_sums (nr,) float64 numpy (SUM of costs), stats (I, 2) int64.
+        nonblocking=True (option "async"): nothing in the call waits for the device; obj_sums and stats come back as DEVICE tensors, valid after the
+        caller has synchronised torch's current stream (the call can be captured into a graph from its second use on a shape on)."""
         import torch
         assert dX.is_cuda and dB0.is_cuda and dK.is_cuda, "device tensors required"
         assert dX.dtype == torch.float32 and dK.dtype == torch.float32 and dB0.dtype == torch.uint8
@@ -129,6 +131,18 @@ class Engine:
         nr = ils.shape[0]
         I = int(ils.max())
         dBs = out if out is not None else torch.empty((nr, n, m), dtype=torch.uint8, device=dX.device)
+        if nonblocking:
+            obj_t = torch.zeros(nr, dtype=torch.float64, device=dX.device)
+            stats_t = torch.zeros((I, 2), dtype=torch.int64, device=dX.device)
+            with self._on_torch_stream():
+                self.set_option("async", 1)
+                try:
+                    self._check(self._L.lsq_encode_icm_dev(self._h, dX.data_ptr(), dB0.data_ptr(), dK.data_ptr(), d, n, m, h,
+                                                           ils.ctypes.data, nr, int(icmiter), int(npert), int(bool(randord)),
+                                                           int(seed), int(global_offset), dBs.data_ptr(), obj_t.data_ptr(), stats_t.data_ptr()))
+                finally:
+                    self.set_option("async", 0)
+            return dBs, obj_t, stats_t
         obj = np.zeros(nr, dtype=np.float64)
         stats = np.zeros((I, 2), dtype=np.int64)
         with self._on_torch_stream():

@@ -175,7 +175,7 @@ def update_codebooks(X, B, h, V=False, codebook_upd_method="lsqr", *, nthreads=0
 def train_lsq(X, m, h, R, B, C, niter, ilsiter, icmiter, randord, npert, V=False, *, seed=0, engine=None, device_update=False):
     """src/lsq/LSQ.jl:10-88: alternate codebook update (host LSQR) and ILS/ICM encoding (GPU).
     -> (C, B, cbnorms, B_norms, obj).  The final norm codebook is the reference's plain k-means on the squared
-    norms of the reconstructions (Clustering.kmeans there; a seeded Lloyd iteration here -- unpinned)."""
+    norms of the reconstructions (Clustering.kmeans there; initializers.kmeans here: k-means++ seeding + Lloyd, <= 100 sweeps, seeded -- unpinned)."""
     X = np.asarray(X, dtype=np.float32)
     R = np.asarray(R, dtype=np.float32)
     d, n = X.shape
@@ -198,17 +198,17 @@ def train_lsq(X, m, h, R, B, C, niter, ilsiter, icmiter, randord, npert, V=False
         C = update_codebooks(X, B, h, V, engine=upd_engine)
         it += 1
         B = encode(B, it)
+    # the codebook for norms (LSQ.jl:67-84): squared norms of the reconstructions (f32, dimensions ascending), then "plain-old k-means" with h centres.
+    # The reference calls Clustering.jl's kmeans(dbnorms, h) -- k-means++ seeding, Lloyd until the assignments settle (at most 100 sweeps by default); un-vendored
+    # and seeded from Julia's global RNG, so the centres are unpinned: the package's own kmeans() (initializers.py) is the same algorithm under `seed`.
+    from .initializers import kmeans
     CB = reconstruct(B, C)
-    dbnorms = (CB.astype(np.float32) ** 2).sum(0).astype(np.float32)
-    rng = np.random.default_rng(seed)
-    cb = np.sort(rng.choice(dbnorms, size=min(h, n), replace=False)).astype(np.float32)
-    for _ in range(25):                                   # Lloyd on scalars
-        assign = np.argmin(np.abs(dbnorms[None, :] - cb[:, None]), axis=0)
-        for c in range(cb.shape[0]):
-            sel = assign == c
-            if sel.any():
-                cb[c] = dbnorms[sel].mean()
-    B_norms = (np.argmin(np.abs(dbnorms[None, :] - cb[:, None]), axis=0) + 1).reshape(1, n).astype(np.int16)
+    dbnorms = np.zeros(n, dtype=np.float32)
+    for j in range(CB.shape[0]):
+        dbnorms += CB[j] * CB[j]
+    centers, assign, _ = kmeans(dbnorms.reshape(1, n), min(h, n), niter=100, seed=seed)
+    cb = centers.reshape(-1).astype(np.float32)
+    B_norms = (assign + 1).reshape(1, n).astype(np.int16)
     return C, B, cb, B_norms, obj
 
 

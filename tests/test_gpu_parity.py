@@ -477,3 +477,45 @@ def test_single_process_multi_gpu_handle(lsq, oracle):
         Bs, objs = mg.encode_icm(X[:2], B0[:2], K, m, [1], J, npert, True, seed=seed)
         ref, _ = oracle.encode_icm(X[:2], B0[:2], K, m, H, [1], J, npert, True, seed)
         assert np.array_equal(Bs, ref)
+
+
+def test_async_call_matches_the_blocking_call_and_can_be_captured(lsq):
+    """Option "async" (VERDICT r3, weak #9): lsq_encode_icm_dev with NO host synchronisation -- the chunk's verdict and probe are taken on the device,
+    both walks are enqueued, sums and counters land in device tensors in stream order.  (a) Same codes, sums and counters as the blocking call on a
+    well-conditioned chunk (filtered walk) AND on a scale-mixture chunk that the probe hands to the f32 walk; (b) the statistics reach lsq_get_timings
+    at its next call; (c) the call can be captured into a graph on torch's stream and replayed."""
+    import torch
+    d, n, m, ils, J, npert, seed = 32, 70_000, 8, [1, 3], 3, 4, 21
+    with lsq.Engine(0) as eng:
+        dX = eng.synth_data_u8_dev(5, n, d)
+        dB0 = eng.randinit_dev(6, n, m)
+        dK = eng.synth_codebooks_dev(7, m, d)
+        g = torch.Generator(device=dX.device)
+        g.manual_seed(3)
+        dXc = (dX * torch.empty((n, 1), dtype=torch.float32, device=dX.device).cauchy_(generator=g)).contiguous()
+        for X, expect_fallback in ((dX, 0), (dXc, 1)):
+            ref, sums, stats = eng.encode_icm_dev(X, dB0, dK, m, ils, J, npert, True, seed=seed)
+            t_ref = eng.timings()
+            eng.reset_timings()
+            got, sums_t, stats_t = eng.encode_icm_dev(X, dB0, dK, m, ils, J, npert, True, seed=seed, nonblocking=True)
+            torch.cuda.synchronize()
+            assert torch.equal(got, ref)
+            # (the objective is a sum of f64 partial sums added in arrival order: equal up to the last bits)
+            assert np.allclose(sums_t.cpu().numpy(), sums, rtol=1e-12, atol=0) and np.array_equal(stats_t.cpu().numpy(), stats)
+            t = eng.timings()
+            assert t["icm_node_updates"] == t_ref["icm_node_updates"] and t["filter_fallback_chunks"] == expect_fallback == t_ref["filter_fallback_chunks"], (t, t_ref)
+            eng.reset_timings()
+        # (c) graph capture on a side stream: the warm-up above sized every work buffer for this shape
+        side = torch.cuda.Stream()
+        out = torch.zeros((len(ils), n, m), dtype=torch.uint8, device=dX.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            eng.encode_icm_dev(dX, dB0, dK, m, ils, J, npert, True, seed=seed, out=out, nonblocking=True)      # warm-up on the capture stream
+            side.synchronize()
+            with torch.cuda.graph(graph, stream=side):
+                _, gs, gst = eng.encode_icm_dev(dX, dB0, dK, m, ils, J, npert, True, seed=seed, out=out, nonblocking=True)
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        ref, sums, stats = eng.encode_icm_dev(dX, dB0, dK, m, ils, J, npert, True, seed=seed)
+        assert torch.equal(out, ref) and np.allclose(gs.cpu().numpy(), sums, rtol=1e-12, atol=0) and np.array_equal(gst.cpu().numpy(), stats)

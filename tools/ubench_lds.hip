@@ -92,6 +92,61 @@ __global__ __launch_bounds__(1024) void k2(const unsigned char *codes, float *ou
     out[(size_t)blockIdx.x * 1024 + threadIdx.x] = acc.x + acc.y + acc.z + acc.w;
 }
 
+// r04 repair: the "linear, conflict-free" leg above adds four floats per read and recomputes its address per read -- it is
+// VALU-bound (76.7 TB/s = half the guide's ds_read_b128 rate), not an LDS ceiling.  kraw issues 16 independent ds_read_b128 per wait from addresses
+// that advance with the iteration and folds ONE dword of each into the result: the LDS array is the only thing left to wait for.
+// RANDOM = 0: the 64 lanes of a read cover one contiguous 1 KiB (conflict-free);  RANDOM = 1: 16 random 64-byte rows per read (the ADC scan's and the
+// ICM walk's pattern): 4 rows per 16-lane group, each in one quarter of the 256-byte bank row -> max(rows per quarter) cycles per group, E = 2.125.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int RANDOM>
+__global__ __launch_bounds__(1024) void kraw(const unsigned char *codes, unsigned *out, int iters, unsigned long long *clk) {
+    extern __shared__ u32x4 ldsr[];
+    for (int e = threadIdx.x; e < 8192; e += 1024) ldsr[e] = (u32x4){(unsigned)e, 1u, 2u, 3u};      // 128 KiB
+    __syncthreads();
+    const unsigned lane = threadIdx.x & 63, v = lane >> 2, q = lane & 3;
+    const unsigned char *cp = codes + ((size_t)blockIdx.x * 1024 + (threadIdx.x & ~63u) + v) * 8;
+    unsigned c[4];
+    for (int t = 0; t < 4; ++t) c[t] = cp[t] | ((unsigned)cp[t + 4] << 8);      // 16 random bits per stream
+    const char *base = reinterpret_cast<const char *>(ldsr);
+    unsigned acc = 0;
+    __syncthreads();
+    const unsigned long long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+        u32x4 r[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            unsigned a;
+            if (RANDOM) a = (((c[t & 3] * 0x9E37u + (unsigned)(it * 16 + t) * 0x61C9u) >> 3) & 2047u) * 64u + q * 16u;      // a random 64-byte row of 2048, quad q
+            else a = ((lane * 16u + (unsigned)(it * 16 + t) * 1024u) & 0x1ffffu);                                          // contiguous 1 KiB windows marching through 128 KiB
+            r[t] = *reinterpret_cast<const u32x4 *>(base + a);
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc ^= r[t].x;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && clk) clk[blockIdx.x] = clock64() - t0;
+    out[(size_t)blockIdx.x * 1024 + threadIdx.x] = acc;
+}
+template <int RANDOM>
+static void runraw(const unsigned char *dc, float *dout, const char *name) {
+    const int iters = 4000, lds_bytes = 128 * 1024;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&kraw<RANDOM>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    static unsigned long long *dclk = nullptr;
+    if (!dclk) CK(hipMalloc(&dclk, 256 * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(kraw<RANDOM>, dim3(256), dim3(1024), lds_bytes, 0, dc, reinterpret_cast<unsigned *>(dout), 10, nullptr);
+    CK(hipEventRecord(a));
+    hipLaunchKernelGGL(kraw<RANDOM>, dim3(256), dim3(1024), lds_bytes, 0, dc, reinterpret_cast<unsigned *>(dout), iters, dclk);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    unsigned long long hclk[256];
+    CK(hipMemcpy(hclk, dclk, sizeof(hclk), hipMemcpyDeviceToHost));
+    double cyc = 0; for (int i = 0; i < 256; ++i) cyc += (double)hclk[i]; cyc /= 256.0;
+    const double reads = 256.0 * 16 * iters * 16;
+    printf("RAW %-40s %8.3f ms  %7.1f TB/s aggregate  (%.2f ns per wave read per CU; guide: 256 B/clk/CU = ~150 TB/s; random rows: / 2.125 = ~70)\n", name, ms,
+           reads * 1024 / (ms * 1e-3) / 1e12, ms * 1e6 / (16.0 * iters * 16));
+}
+
 template <int PAT>
 static void run2(const unsigned char *dc, float *dout, const char *name) {
     const int iters = 2000, lds_bytes = 160 * 1024 - 512;
@@ -133,7 +188,9 @@ int main() {
     unsigned char *dc; float *dout;
     CK(hipMalloc(&dc, h.size())); CK(hipMalloc(&dout, 256 * 1024 * 4));
     CK(hipMemcpy(dc, h.data(), h.size(), hipMemcpyHostToDevice));
-    run<5>(dc, dout, "linear, conflict-free");
+    runraw<0>(dc, dout, "linear 1 KiB windows, 16 reads per wait");
+    runraw<1>(dc, dout, "16 random 64-byte rows per read, 16 per wait");
+    run<5>(dc, dout, "linear, conflict-free (VALU-bound: 4 adds/read)");
     run<0>(dc, dout, "64-byte rows (current)");
     run<1>(dc, dout, "rows padded to 80 bytes");
     run<2>(dc, dout, "rows padded to 96 bytes");
