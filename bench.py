@@ -566,6 +566,18 @@ def main():
                                          "download of the int16 codes; best of 2 calls; never reported as `value`" % (n * d * 4 / 1e6)}
             out["end_to_end"]["same_codes_as_device_path"] = same
             del Xh, Bh
+        # the non-blocking form of the same call (option "async": no host synchronisation inside the call; both walks enqueued per ILS iteration, the idle one
+        # returns at once): what a caller that pipelines work on the stream pays for it
+        step_nb = lambda: eng.encode_icm_dev(dX, dB0, dK, m, [args.ils], args.icmiter, args.npert, True, seed=42, global_offset=goff, out=dBs, nonblocking=True)
+        step_nb()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            _, nb_sums, _ = step_nb()
+        torch.cuda.synchronize()
+        nb_dt = (time.perf_counter() - t0) / args.steps
+        out["nonblocking_call"] = {"value": n / nb_dt, "unit": "vectors/s", "ms_per_step": nb_dt * 1e3, "same_objective": bool(abs(float(nb_sums[0].item()) - float(sums[0])) <= 1e-9 * abs(float(sums[0]))),
+                                   "note": "lsq_encode_icm_dev with option async = 1: verdict and probe decided on the device, sums / counters written in stream order"}
         # north_star's own operating point: 4 ILS iterations
         ns_ils = 4
         step(ns_ils)
