@@ -51,7 +51,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (~6.3 TB/s achievable)
 HBM_ACHIEVABLE_GBS = 6300.0
 LDS_PEAK_GBS = 150000.0        # same guide, section LDS: ds_read_b64/b128 aggregate with every CU streaming
-PMC_GLOB = "r0[23]*_pmc_per_kernel.json"      # committed PMC passes; `traffic` is read from the newest one whose build hash matches
+PMC_GLOB = "r[0-9][0-9]*_pmc_per_kernel.json"      # committed PMC passes; `traffic` is read from the newest one whose build hash matches
 
 
 def parse():
