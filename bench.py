@@ -77,6 +77,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra-legs", action="store_true", help="skip sample_parity / north_star_point / end_to_end / the busy tail")
     p.add_argument("--no-sample-parity", action="store_true", help="skip the oracle re-encode of 512 vectors of the timed output (profiling runs)")
+    p.add_argument("--trained-codebooks", action="store_true",
+                   help="time the MAIN loop on codebooks trained by this package's train_lsq on the first 100 000 vectors (the representative workload: "
+                        "profiling runs key their PMC files on it); default: SURVEY 8(d)'s synthetic codebooks, the trained ones appear as `trained`")
     p.add_argument("--no-workloads", action="store_true", help="skip the `workloads` leg (trained codebooks / no-memoisation floor / heavy tails)")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget for the cfg2 sample")
     p.add_argument("--min-gpu-seconds", type=float, default=6.0,
@@ -177,7 +180,9 @@ def workload_key(argv):
     keep, shape = [], ("--vectors", "--scaling", "--total", "--dim", "--codebooks", "--ils", "--icmiter", "--npert", "--schedule", "--skip", "--option", "--chunk")
     it = iter(argv)
     for a in it:
-        if a in shape:
+        if a == "--trained-codebooks":
+            keep.append(a)
+        elif a in shape:
             keep.append(a + "=" + next(it, ""))
         elif any(a.startswith(k + "=") for k in shape):
             keep.append(a)
@@ -211,6 +216,22 @@ def pmc_traffic(lib_sha):
         best = {"bytes_per_icm_launch": tot / max(disp, 1), "icm_launches_profiled": disp, "source": "profiles/" + os.path.basename(f),
                 "workload": pmc.get("_build", {}).get("bench_args", "")}
     return best
+
+
+def train_codebooks(lsq, eng, dX, dB0, n, d, m, args):
+    """Codebooks of the representative workload: this package's train_lsq (8 iterations x 4 ILS, random initial codes) on the first 100 000 vectors.
+    -> (K host (m*h, d), K device, objective per iteration, seconds)"""
+    import torch
+    h = 256
+    ns = min(n, 100_000)
+    t0 = time.perf_counter()
+    Xs = dX[:ns].cpu().numpy()
+    Bs0 = dB0[:ns].cpu().numpy().astype(np.int16) + 1
+    with lsq.Engine(eng.device) as e2:
+        C, _, _, _, obj = lsq.train_lsq(np.ascontiguousarray(Xs.T), m, h, np.eye(d, dtype=np.float32), np.ascontiguousarray(Bs0.T), None,
+                                        8, 4, args.icmiter, True, args.npert, False, seed=42, engine=e2)
+    Ktr = np.ascontiguousarray(np.concatenate([np.asarray(Cj, dtype=np.float32).T for Cj in C], axis=0))
+    return Ktr, torch.from_numpy(Ktr).to(dX.device), obj, time.perf_counter() - t0
 
 
 def workloads_leg(lsq, eng, dX, dB0, dK, n, d, m, args, goff):
@@ -255,15 +276,7 @@ def workloads_leg(lsq, eng, dX, dB0, dK, n, d, m, args, goff):
 
     # ---- trained codebooks: this package's own train_lsq (host LSQR codebook update + GPU encode) on the first 100 000 vectors
     ns = min(n, 100_000)
-    t0 = time.perf_counter()
-    Xs = dX[:ns].cpu().numpy()
-    Bs0 = dB0[:ns].cpu().numpy().astype(np.int16) + 1
-    with lsq.Engine(eng.device) as e2:
-        C, Btr, _, _, obj = lsq.train_lsq(np.ascontiguousarray(Xs.T), m, h, np.eye(d, dtype=np.float32), np.ascontiguousarray(Bs0.T), None,
-                                          8, 4, args.icmiter, True, args.npert, False, seed=42, engine=e2)
-    Ktr = np.ascontiguousarray(np.concatenate([np.asarray(Cj, dtype=np.float32).T for Cj in C], axis=0))
-    dKtr = torch.from_numpy(Ktr).to(dX.device)
-    train_s = time.perf_counter() - t0
+    Ktr, dKtr, obj, train_s = train_codebooks(lsq, eng, dX, dB0, n, d, m, args)
     out["trained"], btr = timed(dX, dKtr, {}, "codebooks = train_lsq(first %d vectors of the same data, random initial codes, 8 iterations x 4 ILS): "
                                 "trained in %.1f s (not timed); default options" % (ns, train_s))
     out["trained"]["train_objective_first_last"] = [float(obj[0]), float(obj[-1])]
@@ -420,6 +433,9 @@ def main():
     dK = eng.synth_codebooks_dev(4321, m, d) if rank == 0 else torch.zeros((m * h, d), dtype=torch.float32, device=dX.device)
     if d == 960 and rank == 0:
         dK.mul_(0.3 / 255.0)
+    if args.trained_codebooks and world == 1:
+        _, dK, _, _ = train_codebooks(lsq, eng, dX, dB0, n, d, m, args)
+        data_tag += "; codebooks TRAINED by this package's train_lsq on the first 100 000 vectors (--trained-codebooks)"
     dBs = torch.empty((1, n, m), dtype=torch.uint8, device=dX.device)
     torch.cuda.synchronize()
 
