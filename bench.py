@@ -221,16 +221,26 @@ def pmc_traffic(lib_sha):
 def train_codebooks(lsq, eng, dX, dB0, n, d, m, args):
     """Codebooks of the representative workload: this package's train_lsq (8 iterations x 4 ILS, random initial codes) on the first 100 000 vectors.
     -> (K host (m*h, d), K device, objective per iteration, seconds)"""
+    import tempfile
     import torch
     h = 256
     ns = min(n, 100_000)
     t0 = time.perf_counter()
+    # profiling runs are several processes on one box: the codebooks are trained once and cached, so that the profiled processes contain no training launches
+    cache = os.path.join(tempfile.gettempdir(), "lsq_bench_trained_K_%d_%d_%d_%d_%d.npz" % (ns, d, m, args.icmiter, args.npert))
+    if os.path.exists(cache):
+        z = np.load(cache)
+        return z["K"], torch.from_numpy(z["K"]).to(dX.device), z["obj"], 0.0
     Xs = dX[:ns].cpu().numpy()
     Bs0 = dB0[:ns].cpu().numpy().astype(np.int16) + 1
     with lsq.Engine(eng.device) as e2:
         C, _, _, _, obj = lsq.train_lsq(np.ascontiguousarray(Xs.T), m, h, np.eye(d, dtype=np.float32), np.ascontiguousarray(Bs0.T), None,
                                         8, 4, args.icmiter, True, args.npert, False, seed=42, engine=e2)
     Ktr = np.ascontiguousarray(np.concatenate([np.asarray(Cj, dtype=np.float32).T for Cj in C], axis=0))
+    try:
+        np.savez(cache, K=Ktr, obj=np.asarray(obj))
+    except OSError:
+        pass
     return Ktr, torch.from_numpy(Ktr).to(dX.device), obj, time.perf_counter() - t0
 
 
