@@ -12,10 +12,11 @@
 //            (vector, slice), written to a ring in the XCD's L2.
 //   MERGE    after all G CUs have published their partials of a task, each CU merges 1/G of the active vectors: G partials -> the two smallest keys
 //            of the node update -> decide / apply / exact refinement exactly as icm_walkq_kernel does.
-//   ROLES    no phase ever holds the block: of a block's 16 waves W are WALKERS (the slice walk, nothing else: their HBM stream never stops for
-//            bookkeeping), one is the LISTER (builds the list of active vectors of the next task from the validity words) and NM are MERGERS.  They
-//            hand tasks to each other through LDS counters; the latency-bound work (validity scan, decide, refinement's random HBM round trip)
-//            overlaps the walk of the next task instead of preceding / following it.
+//   ROLES    no phase ever holds the block: of a block's 16 waves W = 12 are WALKERS (the slice walk, nothing else), two are LISTERS (lister l builds the
+//            active lists of the tasks t = l mod 2 from the validity words: 16 bytes per lane and load, 16 loads in flight, bit tricks instead of a scan) and
+//            NM = 2 are MERGERS, each owning WHOLE tasks (t = k mod NM) with two register sets so that the loads of the next 64 vectors are issued before the
+//            stores of the current ones.  They hand tasks to each other through LDS counters; progress between CUs is two words per CU (partial keys
+//            published: atomic max by the LAST walker of a task; results applied: the contiguous prefix of finished merges), polled with sc1 loads.
 //   TASKS    a group's range is cut into Q cohorts (<= LCAP active vectors each; at least two, so that the merge of one overlaps the walk of the
 //            other); task t = (node t / Q, cohort t % Q).  Dependencies: the walk of (node, cohort) needs the merge of (previous node, cohort) by
 //            ALL CUs of the group; nothing ever crosses a group, let alone an XCD.
@@ -26,6 +27,10 @@
 //            kernel needs); if that fails within ~0.1 s NOTHING has been touched, sync->gate = 2, and the filtered walk kernel that the host enqueues
 //            right behind this launch (predicated on that word) does the launch's work instead.
 // Every spin is bounded (give-up code in sync->abort and in the call's error word, reported by the host as an error).
+//
+// MEASURED (round 4): bit-exact, and slower than icm_walkq_kernel -- 53.5 vs 41.6 ms of ICM per cfg2 step in the same build.  The walkers' own time sums
+// to what icm_walkq_kernel's slice loops take; the lists, the partial keys' trip through L2 and the merges cost as many issue slots as the phases they replace, and
+// every dependent global round trip on a CU whose walkers keep the memory pipe full costs 3 - 5 us.  Kept in the tuning build as an independent implementation.
 #include <stdlib.h>
 
 #include <type_traits>
