@@ -41,8 +41,11 @@ for t in range(ncases):
     B0 = O.randinit(3000 + t, n, m, H)
     ils, J, npert = [int(rng.integers(1, 3))], int(rng.integers(1, 4)), int(rng.integers(0, m + 1))
     ref, objs_ref = O.encode_icm(X, B0, K, m, H, ils, J, npert, True, 11 * t + 3)
-    with lsq.Engine(0, schedule=6) as eng:
+    sched = int(os.environ.get("LSQ_FUZZ_SCHEDULE", "6"))      # 7: the XCD-cooperative kernel of the tuning build (csrc/lsq_icmx.hip)
+    with lsq.Engine(0, schedule=sched, tuning=(sched == 7)) as eng:
         eng.set_option("q16_min", 0); eng.set_option("light", 0); eng.set_option("filter_probe_div", 0); eng.set_option("filter_fallback_div", 0)
+        if sched == 7:
+            eng.set_option("xs_min", 0)
         Bs, objs = eng.encode_icm(X, B0, K, m, ils, J, npert, True, seed=11 * t + 3)
         tm = eng.timings()
     ok = np.array_equal(Bs, ref)
