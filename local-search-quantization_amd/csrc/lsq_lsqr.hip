@@ -63,7 +63,32 @@ __global__ __launch_bounds__(256) void lsqr_u_update(const float *__restrict__ X
     double acc = 0.0;
     if (t < d && !(S.done[t])) {
         const float alpha = S.alpha[t], ib = S.ib[t];
-        for (int64_t i = r0; i < r0 + RS && i < n; ++i) {
+        const int64_t r1 = (r0 + RS < n) ? r0 + RS : n;
+        int64_t i = r0;
+        constexpr int G = 8;                                       // rows in flight: their loads are issued together, the sums keep the row order
+        for (; i + G <= r1; i += G) {
+            float u[G];
+            if (init) {
+#pragma unroll
+                for (int q = 0; q < G; ++q) u[q] = X[(i + q) * d + t];
+            } else {
+                float old[G], sv[G];
+#pragma unroll
+                for (int q = 0; q < G; ++q) { old[q] = U[(i + q) * d + t]; sv[q] = 0.0f; }
+                for (int j = 0; j < m; ++j) {                      // codebooks ascending within every row, as the host adds them
+                    float g[G];
+#pragma unroll
+                    for (int q = 0; q < G; ++q) g[q] = V[((int64_t)j * LSQ_H + codes[(i + q) * m + j]) * d + t];
+#pragma unroll
+                    for (int q = 0; q < G; ++q) sv[q] += g[q];
+                }
+#pragma unroll
+                for (int q = 0; q < G; ++q) u[q] = -alpha * (old[q] * ib) + sv[q];
+            }
+#pragma unroll
+            for (int q = 0; q < G; ++q) { U[(i + q) * d + t] = u[q]; acc += (double)u[q] * (double)u[q]; }
+        }
+        for (; i < r1; ++i) {
             float u;
             if (init) u = X[i * d + t];
             else {
