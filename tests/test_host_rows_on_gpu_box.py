@@ -69,7 +69,7 @@ def test_quantize_norms_device_equals_the_oracle(lsq, oracle, d, n, m, ncb):
 
 
 # ---- row 8(f)-3 on the device: lsq_update_codebooks_gpu / _dev against the host solver and scipy -----------------------------------------
-@pytest.mark.parametrize("d,n,m,noise", [(12, 4000, 4, 0.01), (128, 20_000, 8, 0.05), (7, 999, 3, 0.0), (33, 120_000, 8, 0.05)])
+@pytest.mark.parametrize("d,n,m,noise", [(12, 4000, 4, 0.01), (128, 20_000, 8, 0.05), (7, 999, 3, 0.0), (33, 120_000, 8, 0.05), (3, 13, 2, 0.02), (65, 1031, 8, 0.05)])
 def test_update_codebooks_device_agrees_with_host_and_scipy(lsq, d, n, m, noise):
     import scipy.sparse as sp
     import scipy.sparse.linalg as spl
