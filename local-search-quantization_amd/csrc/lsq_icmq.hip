@@ -735,40 +735,60 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
                 int64_t vi[EPD];
                 uint32_t vcode[EPD], vkey[EPD], vlim[EPD];
                 bool von[EPD], vamb[EPD], vf32[EPD];
-#pragma unroll
-                for (int e = 0; e < EPD; ++e) {
-                    const int ci = (int)threadIdx.x + e * NT;
-                    von[e] = false; vamb[e] = false; vf32[e] = false; vi[e] = lo; vcode[e] = 0; vkey[e] = 0; vlim[e] = 0;
-                    if (ci < nact) {
-                        const uint32_t kA = bestA[ci], kB = bestB[ci];
-                        vi[e] = lo + list[ci];
-                        vcode[e] = kA & 0xffffu;
-                        vkey[e] = (uint32_t)ci | ((kA & 0xffu) << 16) | ((kB & 0xffu) << 24);
-                        vlim[e] = (kA >> 16) + (uint32_t)window;
-                        vf32[e] = (qflag[vi[e]] >> j) & 1;             // a unary of this node fell outside the sampled level range: its levels mean nothing
-                        vamb[e] = !vf32[e] && ((int)(kB >> 16) - (int)(kA >> 16) <= window);
-                        von[e] = !vamb[e] && !vf32[e];
-                    }
-                }
-                // every load of the thread's vectors before its first store (one global round trip); ambiguous vectors only need their record
+                // m <= 8: every global load of the thread's vectors is issued before the first use (ONE round trip: the loads do not wait for the flag
+                // word that says whether the vector is decided, ambiguous or out of the level range) and before the first store.  m > 8 (16-byte
+                // records, twice the registers) keeps the two-trip order: flags first, then only what the vector's class needs -- measured faster there
+                constexpr bool ONE_TRIP = (M <= 8);
                 uint32_t rw[EPD][RW], rr[EPD][RW];
-                unsigned short vo[EPD], rv[EPD];
+                unsigned short vo[EPD], rv[EPD], fl[EPD];
+                uint32_t kA[EPD], kB[EPD];
                 const bool have_ref = ref_rec && ref_valid;
 #pragma unroll
                 for (int e = 0; e < EPD; ++e) {
-                    vo[e] = 0; rv[e] = 0;
+                    const int ci = (int)threadIdx.x + e * NT;
+                    vi[e] = lo; kA[e] = 0; kB[e] = 0; vo[e] = 0; rv[e] = 0; fl[e] = 0;
 #pragma unroll
                     for (int w2 = 0; w2 < RW; ++w2) { rw[e][w2] = 0; rr[e][w2] = 0; }
-                    if (von[e] || vamb[e]) {
+                    if (ci < nact) {
+                        kA[e] = bestA[ci]; kB[e] = bestB[ci];
+                        vi[e] = lo + list[ci];
+                        fl[e] = qflag[vi[e]];
+                        if constexpr (ONE_TRIP) {
 #pragma unroll
-                        for (int w2 = 0; w2 < RW; ++w2) rw[e][w2] = reinterpret_cast<const uint32_t *>(rec + vi[e] * CS)[w2];
+                            for (int w2 = 0; w2 < RW; ++w2) rw[e][w2] = reinterpret_cast<const uint32_t *>(rec + vi[e] * CS)[w2];
+                            if (valid) vo[e] = valid[vi[e]];
+                            if (have_ref) {
+#pragma unroll
+                                for (int w2 = 0; w2 < RW; ++w2) rr[e][w2] = reinterpret_cast<const uint32_t *>(ref_rec + vi[e] * CS)[w2];
+                                rv[e] = ref_valid[vi[e]];
+                            }
+                        }
                     }
-                    if (von[e]) {
-                        if (valid) vo[e] = valid[vi[e]];
-                        if (have_ref) {
+                }
 #pragma unroll
-                            for (int w2 = 0; w2 < RW; ++w2) rr[e][w2] = reinterpret_cast<const uint32_t *>(ref_rec + vi[e] * CS)[w2];
-                            rv[e] = ref_valid[vi[e]];
+                for (int e = 0; e < EPD; ++e) {
+                    const int ci = (int)threadIdx.x + e * NT;
+                    von[e] = false; vamb[e] = false; vf32[e] = false; vcode[e] = 0; vkey[e] = 0; vlim[e] = 0;
+                    if (ci < nact) {
+                        vcode[e] = kA[e] & 0xffffu;
+                        vkey[e] = (uint32_t)ci | ((kA[e] & 0xffu) << 16) | ((kB[e] & 0xffu) << 24);
+                        vlim[e] = (kA[e] >> 16) + (uint32_t)window;
+                        vf32[e] = (fl[e] >> j) & 1;                    // a unary of this node fell outside the sampled level range: its levels mean nothing
+                        vamb[e] = !vf32[e] && ((int)(kB[e] >> 16) - (int)(kA[e] >> 16) <= window);
+                        von[e] = !vamb[e] && !vf32[e];
+                    }
+                    if constexpr (!ONE_TRIP) {                         // ambiguous vectors only need their record
+                        if (von[e] || vamb[e]) {
+#pragma unroll
+                            for (int w2 = 0; w2 < RW; ++w2) rw[e][w2] = reinterpret_cast<const uint32_t *>(rec + vi[e] * CS)[w2];
+                        }
+                        if (von[e]) {
+                            if (valid) vo[e] = valid[vi[e]];
+                            if (have_ref) {
+#pragma unroll
+                                for (int w2 = 0; w2 < RW; ++w2) rr[e][w2] = reinterpret_cast<const uint32_t *>(ref_rec + vi[e] * CS)[w2];
+                                rv[e] = ref_valid[vi[e]];
+                            }
                         }
                     }
                 }
