@@ -14,7 +14,7 @@ from .engine import Engine, MultiEngine, randinit as randinit_rows, node_order, 
 from .reference_api import (  # noqa: F401
     encode_icm_cuda, encoding_icm, encode_icm_fully, get_unaries, get_binaries, veccost, qerror,
     randinit, splitarray, default_engine, linscan_lsq, eval_recall, quantize_norms, reconstruct,
-    fvecs_read, ivecs_read, bvecs_read, update_codebooks, train_lsq,
+    fvecs_read, ivecs_read, bvecs_read, update_codebooks, train_lsq, train_lsq_dev,
 )
 from .initializers import (  # noqa: F401
     train_pq, quantize_pq, train_opq, quantize_opq, train_chainq, encoding_viterbi, update_codebooks_chain, get_cbdims_chain,
@@ -24,6 +24,6 @@ from . import distributed  # noqa: F401
 __all__ = [
     "Engine", "MultiEngine", "encode_icm_cuda", "encoding_icm", "encode_icm_fully", "get_unaries", "get_binaries",
     "veccost", "qerror", "randinit", "splitarray", "node_order", "device_count", "distributed", "linscan_lsq", "eval_recall",
-    "quantize_norms", "reconstruct", "update_codebooks", "train_lsq", "train_pq", "quantize_pq", "train_opq", "quantize_opq",
+    "quantize_norms", "reconstruct", "update_codebooks", "train_lsq", "train_lsq_dev", "train_pq", "quantize_pq", "train_opq", "quantize_opq",
     "train_chainq", "encoding_viterbi", "update_codebooks_chain", "get_cbdims_chain", "fvecs_read", "ivecs_read", "bvecs_read",
 ]

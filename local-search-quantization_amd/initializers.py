@@ -36,8 +36,55 @@ def _sqdist(C, X):
     return np.maximum(cc + xx - 2.0 * (C.T @ X), 0.0).astype(np.float32)
 
 
+def _assign_scalar(c, x):
+    """r = 1 (the norm codebook of train_lsq: n scalars, h centres): argmin_k (x - c_k)^2 evaluated in f32, lowest index on ties -- the result of the
+    brute-force h x n scan, in O(n log h): the f32 distance is monotone in |x - c_k|, so the minimisers form a contiguous run of the SORTED centres
+    around x; the run is found from the two neighbours of x and widened while the distance stays equal.  (The pairwise expansion of _sqdist
+    cancels catastrophically for scalars of the size of squared norms; this is also the better-conditioned formula.)"""
+    c = np.asarray(c, dtype=np.float32).reshape(-1)
+    x = np.asarray(x, dtype=np.float32).reshape(-1)
+    h, n = c.shape[0], x.shape[0]
+    order = np.argsort(c, kind="stable")
+    cs = c[order]
+    pos = np.searchsorted(cs, x)                                   # cs[pos - 1] < x <= cs[pos]
+    L = np.clip(pos - 1, 0, h - 1)
+    R = np.clip(pos, 0, h - 1)
+    dL = (x - cs[L]) ** 2
+    dR = (x - cs[R]) ** 2
+    best = np.minimum(dL, dR)
+    lo = np.where(dL <= dR, L, R)                                  # one member of the run of minimisers
+    hi = lo.copy()
+    idx = order[lo].copy()                                         # lowest ORIGINAL index seen in the run so far
+    other = np.where(dL <= dR, R, L)
+    tie = (dL == dR) & (L != R)
+    idx[tie] = np.minimum(idx[tie], order[other[tie]])
+    lo = np.where(tie, np.minimum(lo, other), lo)
+    hi = np.where(tie, np.maximum(hi, other), hi)
+    live = np.arange(n)
+    while live.size:                                               # widen the run while the next centre on either side is exactly as far (duplicates, rounding)
+        l2, h2 = lo[live] - 1, hi[live] + 1
+        okl = l2 >= 0
+        okh = h2 < h
+        el = np.zeros(live.size, dtype=bool)
+        eh = np.zeros(live.size, dtype=bool)
+        el[okl] = (x[live[okl]] - cs[l2[okl]]) ** 2 == best[live[okl]]
+        eh[okh] = (x[live[okh]] - cs[h2[okh]]) ** 2 == best[live[okh]]
+        if el.any():
+            t = live[el]
+            lo[t] -= 1
+            idx[t] = np.minimum(idx[t], order[lo[t]])
+        if eh.any():
+            t = live[eh]
+            hi[t] += 1
+            idx[t] = np.minimum(idx[t], order[hi[t]])
+        live = live[el | eh]
+    return idx.astype(np.int64), best.astype(np.float32)
+
+
 def _assign(C, X):
     """Nearest codeword per column of X, lowest index on ties (update_assignments!, src/opq/kmeans.jl:6-75)."""
+    if X.shape[0] == 1:
+        return _assign_scalar(C, X)
     dm = _sqdist(C, X)
     a = dm.argmin(axis=0)
     return a, dm[a, np.arange(X.shape[1])]
@@ -48,9 +95,12 @@ def _centers(X, a, h, rng, old=None):
     r, n = X.shape
     C = np.zeros((r, h), dtype=np.float32)
     cnt = np.bincount(a, minlength=h)
-    np.add.at(C.T, a, X.T)
     nz = cnt > 0
-    C[:, nz] /= cnt[nz]
+    if r == 1:                                           # n scalars (the norm codebook): one weighted bincount, sums in f64
+        C[0] = np.bincount(a, weights=X[0].astype(np.float64), minlength=h).astype(np.float64)[:h] / np.maximum(cnt, 1)
+    else:
+        np.add.at(C.T, a, X.T)
+        C[:, nz] /= cnt[nz]
     for k in np.nonzero(~nz)[0]:
         C[:, k] = X[:, rng.integers(n)] if old is None else old[:, k]
     return C

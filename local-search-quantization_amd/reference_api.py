@@ -212,6 +212,43 @@ def train_lsq(X, m, h, R, B, C, niter, ilsiter, icmiter, randord, npert, V=False
     return C, B, cb, B_norms, obj
 
 
+def train_lsq_dev(dX, m, h, dB, niter, ilsiter, icmiter, randord, npert, *, seed=0, engine, R=None, norm_codebook=True):
+    """src/lsq/LSQ.jl:10-88 with everything resident in HBM: the same alternation as train_lsq -- LSQR codebook update (lsq_update_codebooks_dev),
+    ILS/ICM encode (lsq_encode_icm_dev, seed + call index), objective -- on device tensors, no host copy of X, the codes or the codebooks between the
+    steps.  dX (n, d) f32, dB (n, m) uint8 0-BASED: CUDA/HIP torch tensors (the layouts of Engine.encode_icm_dev); R (d, d) rotation or None (identity).
+    -> (dK (m*h, d) tensor, dB (n, m) uint8 tensor, cbnorms (<= h,) f32, B_norms (n,) int16 1-based, obj (niter,) f32).  Same codebooks, codes and
+    objective as train_lsq(..., engine=engine, device_update=True) on the same inputs (tests/test_pipeline_gpu.py).  torch is used for the two
+    rotations only (RX = X R once; K R' once): glue, not the path."""
+    import torch
+    n, d = dX.shape
+    dXr = dX if R is None else (dX @ torch.as_tensor(np.asarray(R, dtype=np.float32), device=dX.device)).contiguous()      # rows of RX' = (R' x)'
+    dK, _ = engine.update_codebooks_dev(dXr, dB.contiguous(), m, h=h)
+    if R is not None:
+        dK = (dK @ torch.as_tensor(np.asarray(R, dtype=np.float32), device=dX.device).T).contiguous()                       # C = R C: rows of K are codewords
+    del dXr
+    it = 0
+
+    def encode(dBc, it):
+        dBs, sums, _ = engine.encode_icm_dev(dX, dBc, dK, m, [ilsiter], icmiter, npert, randord, seed=seed + it, h=h)
+        return dBs[-1], float(sums[-1])
+
+    dB, s = encode(dB.contiguous(), it)
+    obj = np.zeros(niter, dtype=np.float32)
+    for iter_ in range(niter):
+        obj[iter_] = s / n                                                   # qerror(X, B, C): the mean cost of the codes the encode just returned
+        dK, _ = engine.update_codebooks_dev(dX, dB, m, h=h)
+        it += 1
+        dB, s = encode(dB, it)
+    if not norm_codebook:
+        return dK, dB, None, None, obj
+    # the codebook for norms (LSQ.jl:67-84): squared norms of the reconstructions on the device, the reference's plain k-means on the host (n scalars)
+    from .initializers import kmeans
+    _, _, nrm = engine.quantize_norms_dev(dB, dK, torch.zeros(1, dtype=torch.float32, device=dX.device), m, h=h)
+    dbnorms = nrm.cpu().numpy()
+    centers, assign, _ = kmeans(dbnorms.reshape(1, n), min(h, n), niter=100, seed=seed)
+    return dK, dB, centers.reshape(-1).astype(np.float32), (assign + 1).astype(np.int16), obj
+
+
 def reconstruct(B, C):
     """src/utils.jl:203-223: CB = sum_i C[i][:, B[i, :]] accumulated in codebook order from zero (f32). -> (d, n)"""
     B = np.asarray(B)

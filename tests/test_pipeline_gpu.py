@@ -61,3 +61,31 @@ def test_demo_flow_on_synthetic_data(lsq):
     rec = lsq.eval_recall(gt.astype(np.uint32), idx.astype(np.uint32), knn)
     assert rec[knn - 1] >= 0.9 and rec[0] >= 100.0 / nbase     # 32-bit codes on tight clusters: recall@1 is low, chance is 1/6000
     assert np.all(np.diff(rec) >= 0)
+
+
+def test_train_lsq_dev_is_the_same_training_resident_in_hbm(lsq):
+    """train_lsq_dev (LSQ.jl:10-88 on device tensors: no host copy between the steps) against train_lsq with the device codebook update on the same
+    inputs: identical codebooks, codes, norm codebook; with a rotation (RX by torch instead of numpy: a different summation order) the trajectories
+    stay together."""
+    import torch
+    d, m, n = 32, 4, 3000
+    X = clustered(d, n, k=300, seed=21)
+    B0 = lsq.randinit(n, m, H, seed=2)                              # (m, n) int16, 1-based
+    niter, ilsiter, icmiter, randord, npert = 3, 2, 4, True, 2
+    with lsq.Engine(0) as eng:
+        C, B, cb, Bn, obj = lsq.train_lsq(X, m, H, np.eye(d, dtype=np.float32), B0, None, niter, ilsiter, icmiter, randord, npert, seed=5,
+                                           engine=eng, device_update=True)
+        dX = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()
+        dB0 = torch.from_numpy(np.ascontiguousarray((B0.T - 1).astype(np.uint8))).cuda()
+        dK, dB, cb2, Bn2, obj2 = lsq.train_lsq_dev(dX, m, H, dB0, niter, ilsiter, icmiter, randord, npert, seed=5, engine=eng)
+        K = np.concatenate([np.asarray(Cj, dtype=np.float32).T for Cj in C], axis=0)
+        assert np.array_equal(dK.cpu().numpy(), K)
+        assert np.array_equal(dB.cpu().numpy().astype(np.int16) + 1, np.asarray(B).T)
+        assert np.allclose(obj2, obj, rtol=1e-6) and obj2[-1] <= obj2[0]
+        assert np.array_equal(cb2, cb) and np.array_equal(Bn2, np.asarray(Bn).reshape(-1))
+        # with a rotation
+        Q, _ = np.linalg.qr(np.random.default_rng(3).standard_normal((d, d)))
+        R = Q.astype(np.float32)
+        _, _, _, _, objr = lsq.train_lsq(X, m, H, R, B0, None, niter, ilsiter, icmiter, randord, npert, seed=5, engine=eng, device_update=True)
+        _, _, _, _, objr2 = lsq.train_lsq_dev(dX, m, H, dB0, niter, ilsiter, icmiter, randord, npert, seed=5, engine=eng, R=R, norm_codebook=False)
+        assert np.allclose(objr2, objr, rtol=2e-2) and objr2[-1] <= objr2[0] * 1.001

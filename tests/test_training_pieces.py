@@ -88,3 +88,35 @@ def test_train_lsq_objective_decreases(lsq):
     q = lsq.quantize_norms(B, C, cbnorms)
     assert (q == B_norms.ravel()).mean() > 0.95
     assert abs(lsq.qerror(X, B, C) - obj[-1]) <= obj[-1]                      # same scale; final encode only improves it
+
+
+def test_scalar_kmeans_assignment_equals_the_brute_force_scan(lsq):
+    """initializers._assign_scalar (the norm codebook's k-means: n scalars) returns what the h x n scan of f32 (x - c)^2 with first-minimum returns --
+    duplicated centres, exact midpoints, rounding collisions at the size of squared norms, centres in descending order."""
+    import importlib
+    ini = importlib.import_module(lsq.__name__ + ".initializers")
+    rng = np.random.default_rng(0)
+
+    def brute(c, x):
+        dm = (x[None, :].astype(np.float32) - c[:, None].astype(np.float32)) ** 2
+        a = dm.argmin(axis=0)
+        return a, dm[a, np.arange(x.shape[0])]
+
+    for t in range(120):
+        h, n, kind = int(rng.integers(1, 40)), int(rng.integers(1, 400)), t % 4
+        if kind == 0:
+            c, x = rng.standard_normal(h).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+        elif kind == 1:
+            c, x = rng.integers(0, 6, h).astype(np.float32), (rng.integers(0, 12, n) / 2).astype(np.float32)
+        elif kind == 2:
+            c, x = (4e5 + rng.integers(0, 8, h) * 0.03125).astype(np.float32), (4e5 + rng.integers(0, 64, n) * 0.0078125).astype(np.float32)
+        else:
+            c = np.sort(rng.standard_normal(h)).astype(np.float32)[::-1].copy()
+            x = np.concatenate([c[:min(h, n)], rng.standard_normal(max(n - h, 0)).astype(np.float32)])[:n]
+        a0, d0 = brute(c, x)
+        a1, d1 = ini._assign_scalar(c, x)
+        assert np.array_equal(a0, a1) and np.array_equal(d0, d1), (t, kind)
+    x = (rng.standard_normal(20_000) * 1e5 + 4e5).astype(np.float32)
+    C, a, cost = ini.kmeans(x.reshape(1, -1), 64, niter=30, seed=1)
+    assert C.shape == (1, 64) and a.shape == (20_000,) and np.isfinite(cost)
+    assert cost / x.size < 0.002 * float(x.var())                         # 64 centres on a Gaussian: the distortion is far below the variance
