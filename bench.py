@@ -219,7 +219,7 @@ def pmc_traffic(lib_sha):
 
 
 def train_codebooks(lsq, eng, dX, dB0, n, d, m, args):
-    """Codebooks of the representative workload: this package's train_lsq (8 iterations x 4 ILS, random initial codes) on the first 100 000 vectors.
+    """Codebooks of the representative workload: this package's train_lsq_dev (8 iterations x 4 ILS, random initial codes) on the first 100 000 vectors.
     -> (K host (m*h, d), K device, objective per iteration, seconds)"""
     import tempfile
     import torch
@@ -231,12 +231,10 @@ def train_codebooks(lsq, eng, dX, dB0, n, d, m, args):
     if os.path.exists(cache):
         z = np.load(cache)
         return z["K"], torch.from_numpy(z["K"]).to(dX.device), z["obj"], 0.0
-    Xs = dX[:ns].cpu().numpy()
-    Bs0 = dB0[:ns].cpu().numpy().astype(np.int16) + 1
-    with lsq.Engine(eng.device) as e2:
-        C, _, _, _, obj = lsq.train_lsq(np.ascontiguousarray(Xs.T), m, h, np.eye(d, dtype=np.float32), np.ascontiguousarray(Bs0.T), None,
-                                        8, 4, args.icmiter, True, args.npert, False, seed=42, engine=e2)
-    Ktr = np.ascontiguousarray(np.concatenate([np.asarray(Cj, dtype=np.float32).T for Cj in C], axis=0))
+    with lsq.Engine(eng.device) as e2:          # the training loop resident in HBM: the same codebooks as train_lsq(..., device_update=True) (tests/test_pipeline_gpu.py)
+        dKt, _, _, _, obj = lsq.train_lsq_dev(dX[:ns].contiguous(), m, h, dB0[:ns].contiguous(), 8, 4, args.icmiter, True, args.npert, seed=42, engine=e2,
+                                              norm_codebook=False)
+    Ktr = np.ascontiguousarray(dKt.cpu().numpy())
     try:
         np.savez(cache, K=Ktr, obj=np.asarray(obj))
     except OSError:
