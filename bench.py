@@ -1,9 +1,10 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark: vectors encoded / second (ICM, m=8, h=256) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N=1 by default)
+    python bench.py --gpus N --steps K --warmup W            (N=1 by default; N > 1 without a launcher: the script starts its own N ranks
+                                                              under torch.distributed.run on a free loopback port and rank 0 prints the line)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W        (the driver's form: same ranks, same line)
 
 A "step" = one full `encode_icm_cuda`-equivalent call: pair tables + unary build +
 16 ILS iterations x (perturb + 4 sweeps x m node updates + cost + accept) over this rank's batch,
@@ -376,6 +377,22 @@ def search_leg(lsq, eng, dK, dcodes, n, d, m, nq=10000, knn=1000):
     return res
 
 
+def self_launch(ngpus):
+    """`python bench.py --gpus N` without a launcher: re-run this command line under torch.distributed.run with N local ranks on a free
+    loopback port.  -> the launcher's exit code (rank 0 prints the JSON line; the children inherit stdout / stderr)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
@@ -385,12 +402,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: launch the N ranks ourselves (one process per GPU, the same command the driver's
+        # torch.distributed.run form runs); rank 0's JSON line is this process' only stdout
+        raise SystemExit(self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU, or plain `python bench.py --gpus N`)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     ndev = torch.cuda.device_count()
+    if world > ndev and "LSQ_BENCH_BACKEND" not in os.environ:
+        os.environ["LSQ_BENCH_BACKEND"] = "gloo"      # more ranks than devices (a 1-GPU smoke run): RCCL cannot put two ranks on one device
     dev_index = local_rank % ndev                      # one rank per GPU in production; modulo only for 1-GPU smoke runs
     torch.cuda.set_device(dev_index)
     dist = None
@@ -486,7 +508,9 @@ def main():
     hbm_bytes = nu_per_launch * bytes_nu              # M2 data-flow, per RECOMPUTED node update
     achieved = hbm_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
     mine = {"rank": rank, "device": dev_index, "vectors": n, "global_offset": goff, "ms_per_step": dt_local / args.steps * 1e3,
-            "vectors_per_s": n * args.steps / dt_local, "hbm_frac": achieved / HBM_PEAK_GBS, "icm_ms_per_step": tm["icm_ms"] / args.steps}
+            "vectors_per_s": n * args.steps / dt_local, "hbm_frac": achieved / HBM_PEAK_GBS, "icm_ms_per_step": tm["icm_ms"] / args.steps,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "avg_launch_us": avg_launch_s * 1e6, "launches": int(tm["icm_launches"])}}
     ranks = [mine]
     if dist is not None:
         ranks = [None] * world

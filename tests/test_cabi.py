@@ -118,3 +118,19 @@ def test_bench_matches_pmc_profiles_by_workload():
     assert k("--codebooks 16 --steps 1".split()) == "--codebooks=16" != k([])
     assert k("--scaling strong --total 125000 --dim 960".split()) == k("--dim 960 --total=125000 --scaling strong --warmup 0".split())
     assert k("--vectors 12500000".split()) != k("--vectors 1000000".split())
+
+
+def test_bench_plain_multi_gpu_form_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE must start its own ranks (missing #2) -- here, without a GPU, every rank stops at
+    "needs a GPU": what is checked is that the plain form reaches the ranks instead of asking for a launcher."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-side check of the launcher (the GPU-side one is tests/test_gpu_depth.py)")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode != 0
+    assert "needs a GPU" in p.stderr and "launch with torch.distributed.run" not in p.stderr, p.stderr[-1500:]

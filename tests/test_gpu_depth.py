@@ -1,0 +1,101 @@
+"""The STATED depth under pytest: BASELINE configs[1] at its full size AND its full depth (16 ILS iterations x 4 sweeps),
+with 512 + 64 rows of the output re-encoded by the oracle -- on the synthetic codebooks of SURVEY 8(d) and on codebooks trained by this package
+(the representative workload: the reference encodes with trained codebooks, LSQ.jl:10-88 -> demo_lsq_gpu.jl:33-50); a fixed-seed slice of the
+two randomised campaigns (tools/fuzz_filter.py, tools/fuzz_scan.py); and `python bench.py --gpus 2` in its plain form (the script launches its own ranks).
+
+Valid as a parity check because results depend on (vector, global index) only: the oracle run on rows [a, b) with global_offset = a
+must reproduce rows [a, b) of the full-size call bit for bit.  Parity stays "unpinned": the oracle is this repo's restatement."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+H = 256
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _rows(n):
+    rng = np.random.default_rng(5)
+    blocks = [(0, 256), (n // 2 - 128, n // 2 + 128)]                                            # the two blocks bench.py's sample_parity uses
+    singles = [(int(i), int(i) + 1) for i in np.sort(rng.choice(n, size=64, replace=False))]    # + 64 scattered rows
+    return blocks + singles
+
+
+@pytest.mark.parametrize("codebooks", ["synthetic", "trained"])
+def test_cfg2_full_size_full_depth_rows_vs_oracle(lsq, oracle, codebooks):
+    import torch
+    n, d, m, ils, J, npert, seed = 1_000_000, 128, 8, [16], 4, 4, 42
+    with lsq.Engine(0) as eng:
+        dX = eng.synth_data_u8_dev(1234, n, d)
+        dB0 = eng.randinit_dev(7, n, m)
+        if codebooks == "synthetic":
+            dK = eng.synth_codebooks_dev(4321, m, d)
+        else:
+            ns = 100_000
+            with lsq.Engine(0) as e2:
+                dK, _, _, _, obj = lsq.train_lsq_dev(dX[:ns].contiguous(), m, H, dB0[:ns].contiguous(), 8, 4, J, True, npert, seed=42, engine=e2,
+                                                     norm_codebook=False)
+            assert obj[-1] < obj[0]
+        dBs, sums, stats = eng.encode_icm_dev(dX, dB0, dK, m, ils, J, npert, True, seed=seed)
+        torch.cuda.synchronize()
+        tm = eng.timings()
+        assert tm["filtered_blocks"] > 0, tm                                   # the default road at this size: the 16-bit filtered walk
+        rows = _rows(n)
+        idx = np.concatenate([np.arange(a, b) for a, b in rows])
+        t_idx = torch.from_numpy(idx).to(dX.device)
+        # only the checked rows travel to the host
+        Xr, Br, got_r = dX[t_idx].cpu().numpy(), dB0[t_idx].cpu().numpy().astype(np.int16) + 1, dBs[0][t_idx].cpu().numpy().astype(np.int16) + 1
+        K = dK.cpu().numpy()
+    # re-index the gathered rows as contiguous slices
+    bad, pos = 0, 0
+    for a, b in rows:
+        w = b - a
+        ref, _ = oracle.encode_icm(Xr[pos:pos + w], Br[pos:pos + w], K, m, H, ils, J, npert, True, seed, global_offset=a)
+        bad += int((ref[0] != got_r[pos:pos + w]).any(axis=1).sum())
+        pos += w
+    assert bad == 0, "%d of %d checked rows differ from the oracle (%s codebooks)" % (bad, len(idx), codebooks)
+    assert stats.shape == (16, 2) and stats[0, 1] > 0.9 * n and np.all(np.diff(stats[1:, 1]) <= 0.02 * n)      # "% better" falls off (encode_icm_cuda.jl:199-204)
+    assert np.isfinite(sums[0]) and sums[0] > 0
+
+
+def test_fuzz_filter_fixed_seed_slice():
+    """50 cases of the randomised campaign for the filtered walk (random shapes / scales / offsets / duplicated codewords / heavy tails, every block
+    staged, every vector compared with the oracle), fixed seed."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_filter
+    bad, summary = fuzz_filter.run(50, 20260929, verbose=False)
+    assert bad == 0, summary
+
+
+def test_fuzz_scan_fixed_seed_slice():
+    """50 cases of the randomised campaign for the device ADC scan against the host scan (itself pinned to the reference's build), fixed seed."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_scan
+    bad, summary = fuzz_scan.run(50, 20260929, verbose=False)
+    assert bad == 0, summary
+
+
+def test_bench_plain_multi_gpu_form_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher and NO WORLD_SIZE: the script starts two ranks itself (on a 1-GPU box they share the device and
+    the collective backend falls back to gloo), rank 0 prints ONE JSON line with both ranks' figures.  The command the driver would run on 8 GPUs
+    is the same with --gpus 8."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--vectors", "70000", "--ils", "2",
+           "--no-cpu-baseline", "--no-extra-legs", "--no-sample-parity"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and len(out["ranks"]) == 2 and out["config"]["vectors_total"] == 140000
+    assert {r["rank"] for r in out["ranks"]} == {0, 1} and all("roofline" in r for r in out["ranks"])
+    assert out["value"] > 0 and out["scaling"] == "weak"
+    import torch
+    if torch.cuda.device_count() >= 2:
+        assert out["config"]["rccl_ranks"] == 2 and out["config"]["collective_backend"] == "rccl"
+    else:
+        assert out["config"]["collective_backend"] == "gloo"
