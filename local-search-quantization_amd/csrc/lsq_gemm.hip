@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                          int64_t Mtot, int64_t rbase, uint16_t *__restrict__ Dq, int slice_q,
                                                          lsq_q16_params *__restrict__ qp, int64_t lda, unsigned short *__restrict__ qflag,
                                                          unsigned *__restrict__ qrange, int rts, const float *__restrict__ sigma,
-                                                         const float *__restrict__ colshift) {
+                                                         const float *__restrict__ colshift, int stagger) {
     constexpr int LD = BK + LSQ_GEMM_PAD;
     __shared__ float smem[2 * BM * LD + 2 * BN * LD];      // A and B panels, double-buffered; reused by the u16 epilogue as a 128 x 128 level tile
     float (*As)[BM * LD] = reinterpret_cast<float (*)[BM * LD]>(smem);
@@ -112,6 +112,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int64_t rt = (s / col_tiles) * 8 + xcd;
     const int ct = (int)(s % col_tiles);
     if (rt >= row_tiles) return;
+    // Phase stagger: all resident blocks start together and do identical work, so K loops (MFMA) and epilogues (12 KB of stores per thread-block row) of the
+    // four blocks of a CU would stay in step -- the matrix cores idle while every block stores, HBM idles while every block multiplies.  The first
+    // generation of blocks is delayed by a pseudo-random quarter of a tile time; the offsets persist because every tile takes the same time.
+    if (stagger > 0 && b < 1024) {
+        const unsigned slot = ((unsigned)b * 2654435761u) >> 30;
+        for (unsigned w = 0; w < slot * (unsigned)stagger; ++w) __builtin_amdgcn_s_sleep(127);
+    }
     const int64_t row0 = rt * BM * rts;                  // rts > 1 (range-only pass): every rts-th 128-row panel
     const int col0 = ct * BN;
 
@@ -300,14 +307,15 @@ int lsq_launch_chain_gemm(hipStream_t s, const float *A, const float *Bm, const 
     if (blocks > 0x7fffffffLL) { lsq_set_error("chain_gemm: grid too large"); return LSQ_EINVAL; }
     const bool vec4 = (Kd % 4 == 0) && (((uintptr_t)A | (uintptr_t)Bm) % 16 == 0);
     const int bk = LSQ_KNOB("LSQ_GEMM_BK", 16);
+    const int stagger = (M >= 65536) ? LSQ_KNOB("LSQ_GEMM_STAGGER", 0) : 0;      // units of s_sleep(127) = 8128 clocks per quarter
     // K chunks of 8 or 16 only: both fit four resident blocks per CU (the kernel is compiled for 4 waves per SIMD)
     if (qrange) {          // range-only pass
         if (vec4 && lda % 4 == 0)
             hipLaunchKernelGGL((chain_gemm_kernel<true, 16, 2>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                               plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, qrange, rts, sigma, colshift);
+                               plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, qrange, rts, sigma, colshift, 0);
         else
             hipLaunchKernelGGL((chain_gemm_kernel<false, 16, 2>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                               plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, qrange, rts, sigma, colshift);
+                               plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, qrange, rts, sigma, colshift, 0);
         LSQ_HIP(hipGetLastError());
         return LSQ_OK;
     }
@@ -315,22 +323,22 @@ int lsq_launch_chain_gemm(hipStream_t s, const float *A, const float *Bm, const 
         if (!qp || !qflag || slice_q < 1) { lsq_set_error("chain_gemm: quantised output needs parameters"); return LSQ_EINVAL; }
         if (vec4)
             hipLaunchKernelGGL((chain_gemm_kernel<true, 16, 1>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                               plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, Dq, slice_q, qp, lda, qflag, nullptr, 1, sigma, colshift);
+                               plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, Dq, slice_q, qp, lda, qflag, nullptr, 1, sigma, colshift, stagger);
         else
             hipLaunchKernelGGL((chain_gemm_kernel<false, 16, 1>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                               plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, Dq, slice_q, qp, lda, qflag, nullptr, 1, sigma, colshift);
+                               plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, Dq, slice_q, qp, lda, qflag, nullptr, 1, sigma, colshift, stagger);
         LSQ_HIP(hipGetLastError());
         return LSQ_OK;
     }
     if (vec4 && bk == 8)
         hipLaunchKernelGGL((chain_gemm_kernel<true, 8>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, nullptr, 1, nullptr, nullptr);
+                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, nullptr, 1, nullptr, nullptr, stagger);
     else if (vec4)
         hipLaunchKernelGGL((chain_gemm_kernel<true, 16>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, nullptr, 1, nullptr, nullptr);
+                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, nullptr, 1, nullptr, nullptr, stagger);
     else
         hipLaunchKernelGGL((chain_gemm_kernel<false, 16>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
-                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, nullptr, 1, nullptr, nullptr);
+                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, nullptr, 1, nullptr, nullptr, stagger);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }

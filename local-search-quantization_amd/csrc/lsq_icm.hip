@@ -422,19 +422,24 @@ __global__ __launch_bounds__(256) void icm_wave_kernel(const float *__restrict__
 // ---- perturbation (cudautils.cu:27-80 / encode_icm.jl:55-70) ------------------------------------
 // npert distinct positions (selection sampling, ascending) of the record w get uniform codes; Philox keyed by (seed, global index, ILS iteration)
 __device__ inline bool perturb_record(uint64_t (&w)[2], int m, int npert, uint64_t seed, uint32_t it, uint64_t gi) {
+    // Same stream as orc_perturb (word p decides position p, word 16 + p is its value), drawn BLOCKWISE: the selection words of positions 4 g .. 4 g + 3
+    // are Philox block g, their value words block 4 + g -- both computed unconditionally, once per group.  (Round 4 drew every value word with its own
+    // Philox call inside the data-dependent branch: up to 2 + m blocks per wave, ~80 quarter-rate multiplies each -- a fifth of the cost pass.)
     int need = npert < m ? npert : m;
-    lsq_u32x4 sel = {{0, 0, 0, 0}};
     bool changed = false;
-    for (int pp = 0; pp < m && need > 0; ++pp) {
-        if ((pp & 3) == 0) sel = lsq_rng_block(seed, gi, it, LSQ_DOM_PERTURB, (uint32_t)(pp >> 2));
-        const uint32_t r = sel.v[pp & 3];
-        if (lsq_mulhi32(r, (uint32_t)(m - pp)) < (uint32_t)need) {
-            const uint32_t rv = lsq_rng_word(seed, gi, it, LSQ_DOM_PERTURB, (uint32_t)(16 + pp));
-            const uint64_t val = lsq_mulhi32(rv, LSQ_H);
-            const int sh = 8 * (pp & 7);
-            changed |= (((w[pp >> 3] >> sh) & 0xffull) != val);
-            w[pp >> 3] = (w[pp >> 3] & ~(0xffull << sh)) | (val << sh);
-            --need;
+    for (int g = 0; 4 * g < m && need > 0; ++g) {
+        const lsq_u32x4 sel = lsq_rng_block(seed, gi, it, LSQ_DOM_PERTURB, (uint32_t)g);
+        const lsq_u32x4 vals = lsq_rng_block(seed, gi, it, LSQ_DOM_PERTURB, (uint32_t)(4 + g));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int pp = 4 * g + e;
+            if (pp < m && need > 0 && lsq_mulhi32(sel.v[e], (uint32_t)(m - pp)) < (uint32_t)need) {
+                const uint64_t val = lsq_mulhi32(vals.v[e], LSQ_H);
+                const int sh = 8 * (pp & 7);
+                changed |= (((w[pp >> 3] >> sh) & 0xffull) != val);
+                w[pp >> 3] = (w[pp >> 3] & ~(0xffull << sh)) | (val << sh);
+                --need;
+            }
         }
     }
     return changed;
@@ -447,7 +452,12 @@ __device__ inline void perturb_next_store(const lsq_perturb_next &pn, int64_t i,
     uint64_t w[2];
     w[0] = (uint64_t)fin[0] | ((uint64_t)fin[1] << 32);
     w[1] = (CS == 16) ? ((uint64_t)fin[CS / 4 - 2] | ((uint64_t)fin[CS / 4 - 1] << 32)) : 0ull;
+#ifdef LSQ_TUNING
+    if (pn.abl & 16) return;
+    const bool changed = (pn.abl & 1) ? false : perturb_record(w, pn.m, pn.npert, pn.seed, pn.it, pn.goff + (uint64_t)i);
+#else
     const bool changed = perturb_record(w, pn.m, pn.npert, pn.seed, pn.it, pn.goff + (uint64_t)i);
+#endif
     uint64_t *q = reinterpret_cast<uint64_t *>(pn.dst + i * CS);
     q[0] = w[0];
     if (CS == 16) q[1] = w[1];
@@ -714,13 +724,20 @@ __global__ __launch_bounds__(256) void cost2_kernel(const float *__restrict__ X,
 // d % 4 == 0: a QUARTER wave (one 16-lane DPP row) per vector, 16-byte loads.  Lane l' (0..15) of a row owns dimensions t = 64 q + 4 l' .. + 3
 // for q = 0, 1, ..: the four residues 4 l' .. 4 l' + 3 (mod 64) of the canonical 64 strided partial sums, each accumulated in ascending t, so the
 // reduction order is exactly oracle cost_one()'s: levels 1 and 2 in-lane ((p0 + p1) + (p2 + p3)), levels 4 .. 32 across the 16 lanes of the row
-// (DPP).  A global load costs the texture-address unit 16 cycles per wave whatever its width, and the kernel is bound by what a CU can pull out
-// of L2 (m codeword rows per vector): four-dword loads move twice the bytes per instruction of cost2_kernel, four times those of cost_kernel.
-template <int M>
-__global__ __launch_bounds__(256) void cost4_kernel(const float *__restrict__ X, const float *__restrict__ K,
-                                                    const uint8_t *rec, uint8_t *cur, float *__restrict__ prev,
-                                                    unsigned long long *__restrict__ counters, int64_t n, int d, int mode,
-                                                    const unsigned short *vnew, unsigned short *vcur, const lsq_perturb_next pn) {
+// (DPP).
+//
+// Round 5 rewrite (same arithmetic, same results).  Measured on the round-4 kernel: the pass took 212-340 us where its own memory traffic, replayed by
+// tools/ubench_cost.hip, needs 100-280 us -- the rest was structure: (i) the batch preamble (candidate record, current record, cost, two validity
+// words) compiled into FIVE dependent round trips (a load, a wait, a branch, the next load); (ii) every accepted vector stored its record / cost and
+// re-LOADED its validity word inside the round (a wait for a scattered load in front of the next round's gathers); (iii) one 64-float step of d per
+// wait.  Now: MODE / HASV are template parameters, so the preamble is one group of unconditional loads; a round only computes -- its four costs
+// travel to the lanes that own the vectors (v_readlane / select) and the batch ends with lane-parallel, coalesced stores of whatever was
+// accepted; NQ steps of d (two for d >= 128: 18 sixteen-byte loads per lane) are in flight per wait.
+template <int M, int MODE, int HASV, int NQ>
+__device__ inline void cost4_body(const float *__restrict__ X, const float *__restrict__ K,
+                                  const uint8_t *rec, uint8_t *cur, float *__restrict__ prev,
+                                  unsigned long long *__restrict__ counters, int64_t n, int d,
+                                  const unsigned short *vnew, unsigned short *vcur, const lsq_perturb_next &pn) {
     constexpr int CS = (M <= 8) ? 8 : 16;
     constexpr int RW = CS / 4;
     const int lane = threadIdx.x & 63;
@@ -728,29 +745,46 @@ __global__ __launch_bounds__(256) void cost4_kernel(const float *__restrict__ X,
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     const int64_t w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     unsigned n_eq = 0, n_lt = 0;
-    // 64 consecutive vectors per wave batch; vectors whose candidate record equals the current one keep their cost (see cost_kernel) and are
-    // skipped; the others are taken four at a time, one per row.
+    // 64 consecutive vectors per wave batch.  Accept mode: a vector whose candidate record equals its current record has, bit for bit, the cost it
+    // already has (same codes, same arithmetic) -- counted as "equal" (encode_icm_cuda.jl:199-204) without touching X or the codebooks (a NaN cost is
+    // never "equal" in the reference's comparison: those are evaluated).  The others are taken four at a time, one per row.
     for (int64_t base = w * 64; base < n; base += nwaves * 64) {
         const int64_t il = base + lane;
         const bool livel = il < n;
         const int64_t ic = livel ? il : n - 1;
         uint32_t rn[RW], cw[RW];
-        bool same = (mode == 1);
+        float pl = 0.0f;
+        unsigned short vc = 0, vn = 0;
+        {   // one group of independent loads (no control flow between them)
+            const uint32_t *rp = reinterpret_cast<const uint32_t *>(rec + ic * CS), *cp = reinterpret_cast<const uint32_t *>(cur + ic * CS);
+#pragma unroll
+            for (int q = 0; q < RW; ++q) rn[q] = rp[q];
+            if (MODE == 1) {
+#pragma unroll
+                for (int q = 0; q < RW; ++q) cw[q] = cp[q];
+                pl = prev[ic];
+            }
+            if (HASV) vc = vcur[ic];
+            if (HASV && MODE == 1) vn = vnew[ic];
+        }
+        bool same = (MODE == 1);
 #pragma unroll
         for (int q = 0; q < RW; ++q) {
-            rn[q] = reinterpret_cast<const uint32_t *>(rec + ic * CS)[q];
-            cw[q] = (mode == 1) ? reinterpret_cast<const uint32_t *>(cur + ic * CS)[q] : rn[q];
+            if (MODE == 0) cw[q] = rn[q];
             same = same && (rn[q] == cw[q]);
         }
-        const float pl = (mode == 1) ? prev[ic] : 0.0f;
         const bool skip = livel && same && (pl == pl);
         const unsigned nskip = (unsigned)__popcll(__ballot(skip));
         if (lane == 0) n_eq += nskip;
-        unsigned short vfin = (livel && vcur) ? vcur[il] : (unsigned short)0;      // the vector's validity word after this kernel (for the fused perturbation)
-        const unsigned short vn = (livel && vcur && mode == 1) ? vnew[il] : (unsigned short)0;
-        if (same && livel && vcur) { vfin = (unsigned short)(vfin | vn); vcur[il] = vfin; }     // same tuple: what the sweeps learnt about it is kept
+        unsigned short vfin = vc;                                                   // the vector's validity word after this kernel (for the fused perturbation)
+        const bool merge_v = HASV && MODE == 1 && same && livel;                    // same tuple: what the sweeps learnt about it is kept
+        if (merge_v) vfin = (unsigned short)(vfin | vn);
         uint64_t accepted = 0;                                                      // bit l: the candidate of vector base + l replaced the current record
+        float newp = 0.0f;                                                          // the evaluated cost of this lane's vector
         uint64_t todo = __ballot(livel && !skip);
+#ifdef LSQ_TUNING
+        if (pn.abl & 8) todo = 0;
+#endif
         while (todo) {
             int sidx[4];
             bool hv[4];
@@ -783,61 +817,90 @@ __global__ __launch_bounds__(256) void cost4_kernel(const float *__restrict__ X,
 #pragma unroll
             for (int k = 0; k < M; ++k) kb[k] = K + ((int64_t)(k * LSQ_H) + ((r[k >> 2] >> (8 * (k & 3))) & 0xffu)) * d;
             f32x4 p = (f32x4){0.f, 0.f, 0.f, 0.f};
-            for (int c0 = 0; c0 < d; c0 += 64) {
-                const int t = c0 + 4 * lp;
-                const bool ok = t < d;
-                const int u = ok ? t : 0;
-                const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + u);
-                f32x4 kv[M];
+            for (int c0 = 0; c0 < d; c0 += 64 * NQ) {
+                f32x4 xv[NQ], kv[NQ][M];
+                bool ok[NQ];
 #pragma unroll
-                for (int k = 0; k < M; ++k) kv[k] = *reinterpret_cast<const f32x4 *>(kb[k] + u);
-                f32x4 cb = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int g = 0; g < NQ; ++g) {                                       // every load of the NQ steps is issued before the first add
+                    const int t = c0 + 64 * g + 4 * lp;
+                    ok[g] = t < d;
+                    const int u = ok[g] ? t : 0;
+                    xv[g] = *reinterpret_cast<const f32x4 *>(x + u);
 #pragma unroll
-                for (int k = 0; k < M; ++k) cb = cb + kv[k];                            // k ascending from 0 (utils.jl:238-244)
-                const f32x4 rr = cb - xv;
-                const f32x4 sq = rr * rr;                                               // never fused (-ffp-contract=off)
-                p.x = p.x + (ok ? sq.x : 0.0f);                                         // residues 4 l' .. 4 l' + 3: t ascending
-                p.y = p.y + (ok ? sq.y : 0.0f);
-                p.z = p.z + (ok ? sq.z : 0.0f);
-                p.w = p.w + (ok ? sq.w : 0.0f);
+                    for (int k = 0; k < M; ++k) kv[g][k] = *reinterpret_cast<const f32x4 *>(kb[k] + u);
+                }
+#pragma unroll
+                for (int g = 0; g < NQ; ++g) {                                       // step by step: residues 4 l' .. 4 l' + 3 accumulate in ascending t
+                    f32x4 cb = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < M; ++k) cb = cb + kv[g][k];                  // k ascending from 0 (utils.jl:238-244)
+                    const f32x4 rr = cb - xv[g];
+                    const f32x4 sq = rr * rr;                                        // never fused (-ffp-contract=off)
+                    p.x = p.x + (ok[g] ? sq.x : 0.0f);
+                    p.y = p.y + (ok[g] ? sq.y : 0.0f);
+                    p.z = p.z + (ok[g] ? sq.z : 0.0f);
+                    p.w = p.w + (ok[g] ? sq.w : 0.0f);
+                }
             }
-            float v = (p.x + p.y) + (p.z + p.w);                                        // tree levels 1 and 2
-            v = v + dpp_self<DPP_XOR1, 0xf>(v);                                         // levels 4, 8, 16, 32: within the row
+            float v = (p.x + p.y) + (p.z + p.w);                                    // tree levels 1 and 2
+            v = v + dpp_self<DPP_XOR1, 0xf>(v);                                     // levels 4, 8, 16, 32: within the row
             v = v + dpp_self<DPP_XOR2, 0xf>(v);
             v = v + dpp_self<DPP_HALF_MIRROR, 0xf>(v);
             v = v + dpp_self<DPP_MIRROR, 0xf>(v);
-            const float cost = v;                                                       // every lane of the row holds its vector's cost
-            if (mode == 0) {
-                if (live && lp == 0) prev[i] = cost;
-            } else {
-                const bool eq = live && (cost == pc), lt = live && (cost < pc);          // strict improvement only (encode_icm.jl:183-186)
-                const uint64_t bl = __ballot(lt && lp == 0);                              // bits 0, 16, 32, 48: the four rows' vectors
+            const float cost = v;                                                   // every lane of the row holds its vector's cost
+            // the four costs go to the lanes that own the vectors: nothing is stored inside the round
+#pragma unroll
+            for (int v2 = 0; v2 < 4; ++v2) {
+                const float cv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cost), 16 * v2));
+                if (hv[v2] && lane == sidx[v2]) newp = cv;
+            }
+            if (MODE == 1) {
+                const bool eq = live && (cost == pc), lt = live && (cost < pc);     // strict improvement only (encode_icm.jl:183-186)
+                const uint64_t bl = __ballot(lt && lp == 0);                        // bits 0, 16, 32, 48: the four rows' vectors
                 const unsigned ne = (unsigned)__popcll(__ballot(eq && lp == 0)), nl = (unsigned)__popcll(bl);
 #pragma unroll
                 for (int v2 = 0; v2 < 4; ++v2)
                     if ((bl >> (16 * v2)) & 1ull) accepted |= 1ull << sidx[v2];
                 if (lane == 0) { n_eq += ne; n_lt += nl; }
-                if (lt && lp == 0) {
-                    prev[i] = cost;
-                    uint32_t *qd = reinterpret_cast<uint32_t *>(cur + i * CS);
-#pragma unroll
-                    for (int q = 0; q < RW; ++q) qd[q] = r[q];
-                    if (vcur) vcur[i] = vnew[i];
-                }
             }
         }
+        // lane-parallel epilogue of the batch: coalesced stores of what changed
+        const bool acc = (accepted >> lane) & 1ull;
+        if (MODE == 0) {
+            if (livel) prev[il] = newp;
+        } else if (acc) {
+            prev[il] = newp;
+            uint32_t *qd = reinterpret_cast<uint32_t *>(cur + il * CS);
+#pragma unroll
+            for (int q = 0; q < RW; ++q) qd[q] = rn[q];
+        }
+        if (HASV && MODE == 1 && (acc || merge_v)) vcur[il] = acc ? vn : vfin;
         if (pn.on && livel) {
-            const bool acc = (accepted >> lane) & 1ull;
             uint32_t fin[RW];
 #pragma unroll
             for (int q = 0; q < RW; ++q) fin[q] = acc ? rn[q] : cw[q];
             perturb_next_store<CS>(pn, il, fin, acc ? vn : vfin);
         }
     }
-    if (mode == 1 && lane == 0 && (n_eq | n_lt)) {
+    if (MODE == 1 && lane == 0 && (n_eq | n_lt)) {
         if (n_eq) atomicAdd(&counters[0], (unsigned long long)n_eq);
         if (n_lt) atomicAdd(&counters[1], (unsigned long long)n_lt);
     }
+}
+
+// NQ = 1 (d <= 64): the compiler's own register budget; NQ = 2: four waves per SIMD (128 VGPRs) so that the 18 loads of a round really are in flight together
+template <int M, int MODE, int HASV, int NQ>
+__global__ __launch_bounds__(256) void cost4_kernel(const float *__restrict__ X, const float *__restrict__ K, const uint8_t *rec, uint8_t *cur,
+                                                    float *__restrict__ prev, unsigned long long *__restrict__ counters, int64_t n, int d,
+                                                    const unsigned short *vnew, unsigned short *vcur, const lsq_perturb_next pn) {
+    cost4_body<M, MODE, HASV, NQ>(X, K, rec, cur, prev, counters, n, d, vnew, vcur, pn);
+}
+template <int M, int MODE, int HASV, int NQ>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void cost4w_kernel(const float *__restrict__ X, const float *__restrict__ K,
+                                                    const uint8_t *rec, uint8_t *cur, float *__restrict__ prev,
+                                                    unsigned long long *__restrict__ counters, int64_t n, int d,
+                                                    const unsigned short *vnew, unsigned short *vcur, const lsq_perturb_next pn) {
+    cost4_body<M, MODE, HASV, NQ>(X, K, rec, cur, prev, counters, n, d, vnew, vcur, pn);
 }
 
 __global__ __launch_bounds__(256) void sum_f64_kernel(const float *__restrict__ v, int64_t n, double *__restrict__ sum) {
@@ -1090,11 +1153,31 @@ int lsq_launch_cost(hipStream_t s, const float *X, const float *K, const uint8_t
     if (n <= 0) return LSQ_OK;
     lsq_perturb_next pn = {};
     if (next) pn = *next;
+    pn.abl = LSQ_KNOB("LSQ_COST_ABL", 0);
     const int use_v2 = LSQ_KNOB("LSQ_COST_V2", 1), use_v4 = LSQ_KNOB("LSQ_COST_V4", 1);
     // a quarter wave per vector with 16-byte loads (any d that is a multiple of 4); else half a wave per vector with 8-byte loads (measured 13 %
     // faster than the scalar kernel at d = 128, 7 % slower at d = 960); else one wave per vector, 4-byte loads
     if (use_v4 && d % 4 == 0 && ((uintptr_t)X | (uintptr_t)K) % 16 == 0) {
-        LSQ_DISPATCH_M(m, hipLaunchKernelGGL(cost4_kernel<M_>, dim3(wave_grid((n + 3) / 4)), dim3(256), 0, s, X, K, rec, cur, prev, counters, n, d, mode, vnew, vcur, pn));
+        // persistent grid: as many 256-thread blocks as are resident at once (a second, partial generation of blocks would idle the CUs it does not reach)
+        const int64_t want = (n + 255) / 256;
+#define LSQ_COST4(KERN_, MODE_, HASV_, NQ_)                                                                                                        \
+        LSQ_DISPATCH_M(m, {                                                                                                                 \
+            static int per_cu = 0;                                                                                                          \
+            if (per_cu == 0) {                                                                                                              \
+                int nb = 0;                                                                                                                 \
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, KERN_<M_, MODE_, HASV_, NQ_>, 256, 0) != hipSuccess || nb < 1) nb = 4;   \
+                per_cu = nb > 8 ? 8 : nb;                                                                                                   \
+            }                                                                                                                               \
+            const int64_t cap = 256 * (int64_t)per_cu;                                                                                      \
+            hipLaunchKernelGGL((KERN_<M_, MODE_, HASV_, NQ_>), dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, s, X, K, rec, cur, prev, counters, n, d, vnew, vcur, pn); \
+        })
+        if (mode == 1 && (!vnew || !vcur)) { lsq_set_error("lsq_launch_cost: accept mode needs both validity arrays"); return LSQ_EINVAL; }
+        if (d > 64) {
+            if (mode == 1) { LSQ_COST4(cost4w_kernel, 1, 1, 2); } else if (vcur) { LSQ_COST4(cost4w_kernel, 0, 1, 2); } else { LSQ_COST4(cost4w_kernel, 0, 0, 2); }
+        } else {
+            if (mode == 1) { LSQ_COST4(cost4_kernel, 1, 1, 1); } else if (vcur) { LSQ_COST4(cost4_kernel, 0, 1, 1); } else { LSQ_COST4(cost4_kernel, 0, 0, 1); }
+        }
+#undef LSQ_COST4
     } else if (use_v2 && d % 2 == 0 && d <= 256 && ((uintptr_t)X | (uintptr_t)K) % 8 == 0) {
         LSQ_DISPATCH_M(m, hipLaunchKernelGGL(cost2_kernel<M_>, dim3(wave_grid((n + 1) / 2)), dim3(256), 0, s, X, K, rec, cur, prev, counters, n, d, mode, vnew, vcur, pn));
     } else {

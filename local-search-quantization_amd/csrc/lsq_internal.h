@@ -192,7 +192,7 @@ int lsq_launch_icm_xs(hipStream_t s, const float *U, const uint16_t *Uq, const u
 // and counters[0] += (#cost == prev), counters[1] += (#cost < prev)   (counters: 2 x uint64 on device)
 // perturbation for the NEXT ILS iteration fused into the cost kernel's exit (on = 0: none): dst / vdst receive the perturbed copy of every vector's
 // final record / validity word (dst may be the candidate array the kernel has just judged)
-struct lsq_perturb_next { int on; int m, npert; uint32_t it; uint64_t seed, goff; uint8_t *dst; unsigned short *vdst; };
+struct lsq_perturb_next { int on; int m, npert; uint32_t it; uint64_t seed, goff; uint8_t *dst; unsigned short *vdst; int abl; };      // abl: timing-only ablations of the cost kernel (tuning build; 0 in the shipped library)
 int lsq_launch_cost(hipStream_t s, const float *X, const float *K, const uint8_t *rec, uint8_t *cur, float *prev,
                     unsigned long long *counters, int64_t n, int d, int m, int mode,
                     const unsigned short *vnew, unsigned short *vcur,
