@@ -785,18 +785,43 @@ __device__ inline void cost4_body(const float *__restrict__ X, const float *__re
 #ifdef LSQ_TUNING
         if (pn.abl & 8) todo = 0;
 #endif
-        while (todo) {
+        // Rounds of four vectors.  The x row comes from HBM, the codeword rows from L2: waiting for both in the same round leaves the L1 idle for the
+        // length of an HBM round trip, so the x loads run ONE STEP AHEAD -- those of the next 64 NQ dimensions (or of the next round's vectors) are
+        // issued behind the current step's codeword loads and are still in flight while it is summed.
+        int nsidx[4];
+        bool nhv[4];
+        auto pick = [&]() {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {                                           // fewer than four left: the spare rows repeat the first, unwritten
+                nhv[v] = todo != 0;
+                nsidx[v] = nhv[v] ? __builtin_ctzll(todo) : (v ? nsidx[0] : 0);
+                if (nhv[v]) todo &= todo - 1;
+            }
+        };
+        auto xrow = [&]() -> const float * {
+            const int mys = qtr == 0 ? nsidx[0] : qtr == 1 ? nsidx[1] : qtr == 2 ? nsidx[2] : nsidx[3];
+            return X + (base + mys) * (int64_t)d;                                   // an empty pick points at the batch's first vector: a harmless read
+        };
+        f32x4 xn[NQ];
+        auto xload = [&](const float *x, int c0) {
+#pragma unroll
+            for (int g = 0; g < NQ; ++g) {
+                const int t = c0 + 64 * g + 4 * lp;
+                xn[g] = *reinterpret_cast<const f32x4 *>(x + (t < d ? t : 0));
+            }
+        };
+        pick();
+        const float *xnext = xrow();
+        if (nhv[0]) xload(xnext, 0);
+        while (nhv[0]) {
             int sidx[4];
             bool hv[4];
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {                                           // fewer than four left: the spare rows repeat the first, unwritten
-                hv[v] = todo != 0;
-                sidx[v] = hv[v] ? __builtin_ctzll(todo) : sidx[0];
-                if (hv[v]) todo &= todo - 1;
-            }
+            for (int v = 0; v < 4; ++v) { sidx[v] = nsidx[v]; hv[v] = nhv[v]; }
+            const float *x = xnext;
+            pick();                                                                 // the NEXT round's vectors (none: nhv[0] = false)
+            xnext = xrow();
             const bool live = qtr == 0 ? hv[0] : qtr == 1 ? hv[1] : qtr == 2 ? hv[2] : hv[3];
-            const int mys = qtr == 0 ? sidx[0] : qtr == 1 ? sidx[1] : qtr == 2 ? sidx[2] : sidx[3];
-            const int64_t i = base + mys;
             uint32_t r[RW];
             float pc;
             {
@@ -812,23 +837,24 @@ __device__ inline void cost4_body(const float *__restrict__ X, const float *__re
                 for (int q = 0; q < RW; ++q) r[q] = qtr == 0 ? rv4[0][q] : qtr == 1 ? rv4[1][q] : qtr == 2 ? rv4[2][q] : rv4[3][q];
                 pc = qtr == 0 ? pc4[0] : qtr == 1 ? pc4[1] : qtr == 2 ? pc4[2] : pc4[3];
             }
-            const float *x = X + i * (int64_t)d;
-            const float *kb[M];
+            uint32_t kb[M];                                                          // element offsets into K (m h d < 2^32: checked by the launcher): one register per row
 #pragma unroll
-            for (int k = 0; k < M; ++k) kb[k] = K + ((int64_t)(k * LSQ_H) + ((r[k >> 2] >> (8 * (k & 3))) & 0xffu)) * d;
+            for (int k = 0; k < M; ++k) kb[k] = ((uint32_t)(k * LSQ_H) + ((r[k >> 2] >> (8 * (k & 3))) & 0xffu)) * (uint32_t)d;
             f32x4 p = (f32x4){0.f, 0.f, 0.f, 0.f};
             for (int c0 = 0; c0 < d; c0 += 64 * NQ) {
                 f32x4 xv[NQ], kv[NQ][M];
                 bool ok[NQ];
 #pragma unroll
-                for (int g = 0; g < NQ; ++g) {                                       // every load of the NQ steps is issued before the first add
+                for (int g = 0; g < NQ; ++g) {                                       // every codeword load of the NQ steps is issued before the first add
                     const int t = c0 + 64 * g + 4 * lp;
                     ok[g] = t < d;
-                    const int u = ok[g] ? t : 0;
-                    xv[g] = *reinterpret_cast<const f32x4 *>(x + u);
+                    const uint32_t u = ok[g] ? (uint32_t)t : 0u;
+                    xv[g] = xn[g];
 #pragma unroll
-                    for (int k = 0; k < M; ++k) kv[g][k] = *reinterpret_cast<const f32x4 *>(kb[k] + u);
+                    for (int k = 0; k < M; ++k) kv[g][k] = *reinterpret_cast<const f32x4 *>(K + (size_t)(kb[k] + u));
                 }
+                if (c0 + 64 * NQ < d) xload(x, c0 + 64 * NQ);                        // ... and behind them the x of the next step
+                else xload(xnext, 0);
 #pragma unroll
                 for (int g = 0; g < NQ; ++g) {                                       // step by step: residues 4 l' .. 4 l' + 3 accumulate in ascending t
                     f32x4 cb = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -882,9 +908,15 @@ __device__ inline void cost4_body(const float *__restrict__ X, const float *__re
             perturb_next_store<CS>(pn, il, fin, acc ? vn : vfin);
         }
     }
-    if (MODE == 1 && lane == 0 && (n_eq | n_lt)) {
-        if (n_eq) atomicAdd(&counters[0], (unsigned long long)n_eq);
-        if (n_lt) atomicAdd(&counters[1], (unsigned long long)n_lt);
+    if (MODE == 1) {                                                                 // one pair of device atomics per block
+        __shared__ unsigned cnt_s[2];
+        if (threadIdx.x == 0) { cnt_s[0] = 0u; cnt_s[1] = 0u; }
+        __syncthreads();
+        if (lane == 0 && n_eq) atomicAdd(&cnt_s[0], n_eq);
+        if (lane == 0 && n_lt) atomicAdd(&cnt_s[1], n_lt);
+        __syncthreads();
+        if (threadIdx.x == 0 && cnt_s[0]) atomicAdd(&counters[0], (unsigned long long)cnt_s[0]);
+        if (threadIdx.x == 0 && cnt_s[1]) atomicAdd(&counters[1], (unsigned long long)cnt_s[1]);
     }
 }
 
@@ -1172,7 +1204,8 @@ int lsq_launch_cost(hipStream_t s, const float *X, const float *K, const uint8_t
             hipLaunchKernelGGL((KERN_<M_, MODE_, HASV_, NQ_>), dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, s, X, K, rec, cur, prev, counters, n, d, vnew, vcur, pn); \
         })
         if (mode == 1 && (!vnew || !vcur)) { lsq_set_error("lsq_launch_cost: accept mode needs both validity arrays"); return LSQ_EINVAL; }
-        if (d > 64) {
+        if ((int64_t)m * LSQ_H * d >= (1ll << 31)) { lsq_set_error("lsq_launch_cost: codebook matrix too large"); return LSQ_EINVAL; }
+        if (d > 64 && m <= 8) {             // two 64-float steps of d in flight (18 loads per lane); above m = 8 the codeword rows of ONE step already fill the registers
             if (mode == 1) { LSQ_COST4(cost4w_kernel, 1, 1, 2); } else if (vcur) { LSQ_COST4(cost4w_kernel, 0, 1, 2); } else { LSQ_COST4(cost4w_kernel, 0, 0, 2); }
         } else {
             if (mode == 1) { LSQ_COST4(cost4_kernel, 1, 1, 1); } else if (vcur) { LSQ_COST4(cost4_kernel, 0, 1, 1); } else { LSQ_COST4(cost4_kernel, 0, 0, 1); }
