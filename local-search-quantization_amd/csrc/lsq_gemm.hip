@@ -92,7 +92,7 @@ __device__ inline void tile_store(const TileRegs<VEC4, BK> &t, float scale, floa
 // icm_walkq_kernel sends that vector's node j through the f32 path -- exactness never depends on the sample.
 // Q16 = 2: range-only pass over a sample of the rows (every rts-th 128-row panel, contiguous reads): nothing is stored, the minimum / maximum of every column plane are
 // accumulated in qrange[2 j], qrange[2 j + 1] as order-preserving uint keys.
-template <bool VEC4, int BK, int Q16 = 0>
+template <bool VEC4, int BK, int Q16 = 0, bool FULLK = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void chain_gemm_kernel(const float *__restrict__ A, const float *__restrict__ Bm,
                                                          const float *__restrict__ addv, float alpha, int64_t M, int N,
                                                          int Kd, int h, int64_t plane_stride, int64_t row_stride,
@@ -157,9 +157,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             tile_load<VEC4, BK>(A, M, row0, Kd, k0 + BK, ra, tid, lda);
             tile_load<VEC4, BK>(Bm, N, col0, Kd, k0 + BK, rb, tid, (int64_t)Kd);
         }
-        const int kend = (Kd - k0 < BK) ? ((Kd - k0 + 1) & ~1) : BK;   // odd tail: one zero product appended
+        // FULLK (Kd a multiple of BK: the launcher knows): fixed trip count, unrolled -- the operand reads of the later k-steps are issued under the MFMAs
+        // of the earlier ones (the variable-trip loop waits for its four ds_reads in every step: tools/ubench_gemm.hip, 5.25 -> 5.03 ms per 10^6 x 128)
+        const int kend = FULLK ? BK : ((Kd - k0 < BK) ? ((Kd - k0 + 1) & ~1) : BK);   // odd tail: one zero product appended
         const float *ap = As[cur] + (wy * 64 + l31) * LD + lhi;
         const float *bp = Bs[cur] + (wx * 64 + l31) * LD + lhi;
+#pragma unroll
         for (int kk = 0; kk < kend; kk += 2) {                  // ascending k through one accumulator: the oracle's fmaf chain
             const float a0 = ap[kk], a1 = ap[32 * LD + kk];
             const float b0 = bp[kk], b1 = bp[32 * LD + kk];
@@ -307,11 +310,14 @@ int lsq_launch_chain_gemm(hipStream_t s, const float *A, const float *Bm, const 
     if (blocks > 0x7fffffffLL) { lsq_set_error("chain_gemm: grid too large"); return LSQ_EINVAL; }
     const bool vec4 = (Kd % 4 == 0) && (((uintptr_t)A | (uintptr_t)Bm) % 16 == 0);
     const int bk = LSQ_KNOB("LSQ_GEMM_BK", 16);
+    const bool fullk = Kd % 16 == 0;
     const int stagger = (M >= 65536) ? LSQ_KNOB("LSQ_GEMM_STAGGER", 0) : 0;      // units of s_sleep(127) = 8128 clocks per quarter
     // K chunks of 8 or 16 only: both fit four resident blocks per CU (the kernel is compiled for 4 waves per SIMD)
     if (qrange) {          // range-only pass
         if (vec4 && lda % 4 == 0)
-            hipLaunchKernelGGL((chain_gemm_kernel<true, 16, 2>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
+            if (fullk) hipLaunchKernelGGL((chain_gemm_kernel<true, 16, 2, true>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
+                               plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, qrange, rts, sigma, colshift, 0);
+            else hipLaunchKernelGGL((chain_gemm_kernel<true, 16, 2>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
                                plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, qrange, rts, sigma, colshift, 0);
         else
             hipLaunchKernelGGL((chain_gemm_kernel<false, 16, 2>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
@@ -321,7 +327,10 @@ int lsq_launch_chain_gemm(hipStream_t s, const float *A, const float *Bm, const 
     }
     if (Dq) {
         if (!qp || !qflag || slice_q < 1) { lsq_set_error("chain_gemm: quantised output needs parameters"); return LSQ_EINVAL; }
-        if (vec4)
+        if (vec4 && fullk)
+            hipLaunchKernelGGL((chain_gemm_kernel<true, 16, 1, true>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
+                               plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, Dq, slice_q, qp, lda, qflag, nullptr, 1, sigma, colshift, stagger);
+        else if (vec4)
             hipLaunchKernelGGL((chain_gemm_kernel<true, 16, 1>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
                                plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, Dq, slice_q, qp, lda, qflag, nullptr, 1, sigma, colshift, stagger);
         else
@@ -332,6 +341,9 @@ int lsq_launch_chain_gemm(hipStream_t s, const float *A, const float *Bm, const 
     }
     if (vec4 && bk == 8)
         hipLaunchKernelGGL((chain_gemm_kernel<true, 8>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
+                           plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, nullptr, 1, nullptr, nullptr, stagger);
+    else if (vec4 && fullk)
+        hipLaunchKernelGGL((chain_gemm_kernel<true, 16, 0, true>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
                            plane_stride, row_stride, D, row_tiles, col_tiles, slice, Mtot, rbase, nullptr, 0, nullptr, lda, nullptr, nullptr, 1, nullptr, nullptr, stagger);
     else if (vec4)
         hipLaunchKernelGGL((chain_gemm_kernel<true, 16>), dim3((unsigned)blocks), dim3(256), 0, s, A, Bm, addv, alpha, M, N, Kd, h,
