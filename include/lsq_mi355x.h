@@ -34,13 +34,14 @@
 #ifndef LSQ_MI355X_H
 #define LSQ_MI355X_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define LSQ_VERSION 400
+#define LSQ_VERSION 500
 
 #if defined(__GNUC__)
 #define LSQ_API __attribute__((visibility("default")))
@@ -83,7 +84,8 @@ typedef struct lsq_timings {
     int64_t xs_launches;     /* schedule 7: launches of the XCD-cooperative kernel (since v400)                                  */
     int64_t xs_fallback_launches; /* ... of which the start barrier turned away (the device was shared: not all 256 blocks resident, or the blocks
                                 * were not spread 32 per XCD): the block-per-range filtered walk did that launch's work instead (since v400) */
-} lsq_timings;
+    int64_t table_reuses;    /* host-buffer calls that found their codebooks unchanged since the previous one: no upload of K, no table rebuild (since v500) */
+} lsq_timings;      /* fields are only ever APPENDED: a caller built against an older header passes its own sizeof to lsq_get_timings_sized */
 
 LSQ_API const char *lsq_last_error(void);
 LSQ_API int lsq_version(void);
@@ -135,7 +137,10 @@ LSQ_API int lsq_set_stream(lsq_ctx *ctx, void *hip_stream);
  *        (starts at 0, advances by one per such call).
  *   (liblsq_mi355x_tuning.so only) "ablation": timing-only kernel variants whose results are garbage. */
 LSQ_API int lsq_set_option(lsq_ctx *ctx, const char *key, int64_t value);
-LSQ_API int lsq_get_timings(lsq_ctx *ctx, lsq_timings *out);
+LSQ_API int lsq_get_timings(lsq_ctx *ctx, lsq_timings *out);      /* writes sizeof(lsq_timings) of THIS header: rebuild the caller with the library, or use: */
+/* ... the size-checked form: at most `bytes` bytes of the structure are written (the fields a caller compiled against an older header knows about);
+ * compare lsq_version() with LSQ_VERSION at load time to learn which fields the library fills. */
+LSQ_API int lsq_get_timings_sized(lsq_ctx *ctx, void *out, size_t bytes);
 /* Node updates actually recomputed (not memoised) per POSITION in an ILS iteration's node sequence, position = sweep * m + rank in
  * the visiting order (mod 64), summed over ILS iterations, chunks and calls since the last lsq_reset_timings: the device-side
  * counterpart of the reference's per-iteration "% equal / % better" prints, for the sweeps.  out[count], count <= 64. */

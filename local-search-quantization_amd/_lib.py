@@ -28,7 +28,8 @@ class Timings(C.Structure):
                 ("icm_launches", C.c_int64), ("icm_node_updates", C.c_int64),
                 ("staged_blocks", C.c_int64), ("light_blocks", C.c_int64), ("filtered_blocks", C.c_int64),
                 ("filter_refined", C.c_int64), ("filter_exact", C.c_int64), ("filter_f32", C.c_int64),
-                ("filter_fallback_chunks", C.c_int64), ("xs_launches", C.c_int64), ("xs_fallback_launches", C.c_int64)]
+                ("filter_fallback_chunks", C.c_int64), ("xs_launches", C.c_int64), ("xs_fallback_launches", C.c_int64),
+                ("table_reuses", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -55,6 +56,7 @@ SIGNATURES = {
     "lsq_set_stream": (_i, [_vp, _vp]),
     "lsq_set_option": (_i, [_vp, C.c_char_p, _i64]),
     "lsq_get_timings": (_i, [_vp, C.POINTER(Timings)]),
+    "lsq_get_timings_sized": (_i, [_vp, _vp, C.c_size_t]),
     "lsq_get_walk_trace": (_i, [_vp, _vp, _i]),
     "lsq_reset_timings": (_i, [_vp]),
     "lsq_synchronize": (_i, [_vp]),

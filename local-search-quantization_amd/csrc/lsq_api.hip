@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <string>
 #include <thread>
 #include <vector>
@@ -50,6 +51,14 @@ struct lsq_ctx {
                              // tuning build only: 0 per-node L2 gathers, 1 fused sweeps, 2 LDS slices + combine
     int64_t q16_min = 65536; // schedule 6: smaller chunks take schedule 4 (every block is light there: nothing to filter)
     int tables_changed = 1;  // schedule 6: the pair tables were rebuilt since the last lsq_launch_q16_prepare
+    int new_call = 1;        // schedule 6: no chunk of this call has reset the level parameters' counters yet
+    // Host-buffer entry points called again with the SAME codebooks (the trainer's chained encoding_icm, demos/demo_lsq.jl:48-51 / LSQ.jl:54-57 -- the
+    // reference rebuilds its binaries in every call, encode_icm.jl:145, with identical results): the uploaded K, ||c||^2, the pair tables and what the
+    // filtered walk derives from them are still in this context -- one memcmp of the caller's K against a host copy decides
+    std::vector<float> hostK;
+    int hostK_d = 0, hostK_m = 0;
+    bool tables_valid = false;
+    int64_t table_reuses = 0;
     int per_node = 0;        // schedule 6: one launch per node update instead of 64 per launch (profiling: per-sweep timings / counters)
     int ablation = 0;        // timing-only kernel ablations (results are garbage when != 0)
     int light = -1;          // schedules 3/4: light-block threshold (-1 = default)
@@ -86,6 +95,11 @@ struct lsq_ctx {
     lsq_linscan_stats adc_stats{};
     int adc_exhaustive = 0, adc_rank = 0;              // options "linscan_exhaustive", "linscan_rank": test hooks of the scan's selection
     DevBuf sX, sX2, sK, sB16, sOut16, sTight, sF32;    // staging for the host-buffer entry points (sX/sX2: double-buffered X chunks)
+    DevBuf sSample, sSigmaS;                           // host-buffer pipeline: the level sample (compacted rows of X) and its sigma
+    std::vector<float> sample_host;                    // ... packed on the host before its upload
+    std::vector<hipEvent_t> panel_ev;                  // ... one event per uploaded panel
+    int64_t panel_bytes = 48ll << 20;                  // option "upload_panel_bytes": size of one uploaded panel (rounded down to whole 128-row tiles)
+    int64_t pipeline_min_bytes = 64ll << 20;           // option "upload_pipeline_min_bytes": first chunks of at least this many bytes of X are uploaded panel by panel under their unary GEMM (0 = never)
     hipStream_t copy_stream = nullptr;               // H2D of X runs here, under the compute of the previous panel / chunk
     hipEvent_t copy_done = nullptr;
     // timings
@@ -175,8 +189,9 @@ extern "C" int lsq_destroy(lsq_ctx *c) {
     for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : c->pool) (void)hipEventDestroy(e);
     DevBuf *bufs[] = {&c->road, &c->xsPart, &c->xsSync, &c->xsErr, &c->probe, &c->Uq, &c->Tq, &c->qp, &c->qscratch, &c->qflag, &c->qsigma, &c->sci, &c->T, &c->Ts, &c->U, &c->vCur, &c->vNew, &c->active, &c->recCur, &c->recNew, &c->prev, &c->counters, &c->obj, &c->bad,
-                      &c->sX, &c->sX2, &c->sK, &c->sB16, &c->sOut16, &c->sTight, &c->sF32};
+                      &c->sX, &c->sX2, &c->sK, &c->sB16, &c->sOut16, &c->sTight, &c->sF32, &c->sSample, &c->sSigmaS};
     for (DevBuf *b : bufs) b->release();
+    for (auto e : c->panel_ev) (void)hipEventDestroy(e);
     lsq_adc_free(c->adc);
     lsq_lsqr_free(c->lsqr);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -210,6 +225,14 @@ extern "C" int lsq_set_option(lsq_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "xs_min")) c->xs_min = value;
     else if (!strcmp(key, "async")) c->async_mode = value != 0;
     else if (!strcmp(key, "per_node")) c->per_node = value != 0;
+    else if (!strcmp(key, "upload_panel_bytes")) {
+        if (value < 1) { lsq_set_error("upload_panel_bytes must be >= 1"); return LSQ_EINVAL; }
+        c->panel_bytes = value;
+    }
+    else if (!strcmp(key, "upload_pipeline_min_bytes")) {
+        if (value < 0) { lsq_set_error("upload_pipeline_min_bytes must be >= 0"); return LSQ_EINVAL; }
+        c->pipeline_min_bytes = value;
+    }
     else if (!strcmp(key, "filter_probe_div")) {
         if (value < 0) { lsq_set_error("filter_probe_div must be >= 0"); return LSQ_EINVAL; }
         c->probe_div = value;
@@ -238,9 +261,23 @@ extern "C" int lsq_set_option(lsq_ctx *c, const char *key, int64_t value) {
     return LSQ_OK;
 }
 
+static int fill_timings(lsq_ctx *c, lsq_timings *out);
+
 extern "C" int lsq_get_timings(lsq_ctx *c, lsq_timings *out) {
-    LSQ_TRY(use_device(c));
     if (!out) { lsq_set_error("lsq_get_timings: null out"); return LSQ_EINVAL; }
+    return fill_timings(c, out);
+}
+
+extern "C" int lsq_get_timings_sized(lsq_ctx *c, void *out, size_t bytes) {
+    if (!out) { lsq_set_error("lsq_get_timings_sized: null out"); return LSQ_EINVAL; }
+    lsq_timings t;
+    LSQ_TRY(fill_timings(c, &t));
+    memcpy(out, &t, bytes < sizeof(t) ? bytes : sizeof(t));      // fields are only ever appended: an older caller gets the prefix it knows
+    return LSQ_OK;
+}
+
+static int fill_timings(lsq_ctx *c, lsq_timings *out) {
+    LSQ_TRY(use_device(c));
     LSQ_TRY(fold_pending(c));
     LSQ_TRY(resolve_timings(c));
     out->tables_ms = c->cat_ms[CAT_TABLES];
@@ -260,6 +297,7 @@ extern "C" int lsq_get_timings(lsq_ctx *c, lsq_timings *out) {
     out->filter_fallback_chunks = c->filter_fallback_chunks;
     out->xs_launches = c->xs_launches;
     out->xs_fallback_launches = c->xs_fallback_launches;
+    out->table_reuses = c->table_reuses;
     return LSQ_OK;
 }
 
@@ -277,6 +315,7 @@ extern "C" int lsq_reset_timings(lsq_ctx *c) {
     c->icm_launches = c->icm_node_updates = c->staged_blocks = c->light_blocks = c->filtered_blocks = c->filter_refined = c->filter_exact = c->filter_f32 = 0;
     c->filter_fallback_chunks = 0;
     c->xs_launches = c->xs_fallback_launches = 0;
+    c->table_reuses = 0;
     for (int64_t &v : c->trace) v = 0;
     c->adc_stats = lsq_linscan_stats{};
     return LSQ_OK;
@@ -377,6 +416,7 @@ static int u_slice_width(const lsq_ctx *c, int m) {      // layout of the unary 
 static int prepare_tables(lsq_ctx *c, const float *dK, int d, int m) {
     Timer t(c, CAT_TABLES);
     c->tables_changed = 1;
+    c->tables_valid = false;        // whoever knows the host copy of dK marks it valid again (host_codebooks)
     const int mh = m * LSQ_H;
     LSQ_TRY(c->sci.ensure(sizeof(float) * (size_t)mh));
     LSQ_TRY(c->T.ensure(sizeof(float) * (size_t)mh * mh));
@@ -393,12 +433,11 @@ static int prepare_tables(lsq_ctx *c, const float *dK, int d, int m) {
 // unaries of rows [r0, r0 + rows) of a cn-vector chunk (dX points at the chunk's first vector)
 static bool use_q16(const lsq_ctx *c, int64_t cn) { return c->schedule >= 6 && cn >= c->q16_min; }
 
-static int build_unaries(lsq_ctx *c, const float *dX, const float *dK, int d, int64_t cn, int m, int slice, int64_t r0, int64_t rows) {
-    c->chunk_q16 = false;
-    const bool q16 = slice > 0 && r0 == 0 && rows == cn && use_q16(c, cn);
-    if (q16) c->call_q16_chunks += 1;
-    if (q16) {
-        // 16-bit filtered walk: sampled value ranges of this chunk -> parameters -> 16-bit slice tables; the GEMM below then also emits the u16 planes
+// q16 part of a chunk's unary build: buffers, sampled value ranges -> parameters -> 16-bit slice tables.  Xsample != nullptr: the host-buffer pipeline
+// (the sample was uploaded ahead of X: lsq_launch_q16_prepare's sample mode); -> *means_out = the codebook means the panel-wise sigma pass needs
+static int q16_prepare_chunk(lsq_ctx *c, const float *dX, const float *dK, int d, int64_t cn, int m, const float *Xsample = nullptr, int64_t nsample_rows = 0,
+                             float **means_out = nullptr) {
+    {
         Timer t(c, CAT_TABLES);
         LSQ_TRY(c->Uq.ensure(sizeof(uint16_t) * (size_t)m * (size_t)cn * LSQ_H));
         LSQ_TRY(c->Tq.ensure(sizeof(uint16_t) * (size_t)m * (size_t)(m > 1 ? m - 1 : 1) * LSQ_H * LSQ_H));
@@ -412,16 +451,30 @@ static int build_unaries(lsq_ctx *c, const float *dX, const float *dK, int d, in
         LSQ_TRY(c->qsigma.ensure(sizeof(float) * (size_t)cn * m));      // per-(vector, node) unary shift: levels only (lsq_icmq.hip)
         LSQ_TRY(c->qflag.ensure(sizeof(unsigned short) * (size_t)(cn + 2)));
         LSQ_TRY(c->qp.ensure(sizeof(lsq_q16_params)));
-        if (c->tables_changed) LSQ_HIP(hipMemsetAsync(c->qp.p, 0, sizeof(lsq_q16_params), c->stream));      // first chunk of a call: ok = 0, oor = 0
+        if (c->new_call) LSQ_HIP(hipMemsetAsync(c->qp.p, 0, sizeof(lsq_q16_params), c->stream));      // first chunk of a call: ok = 0, oor = 0
+        c->new_call = 0;
         char *sc = c->qscratch.as<char>();
+        if (Xsample) LSQ_TRY(c->sSigmaS.ensure(sizeof(float) * (size_t)nsample_rows * m));
         LSQ_TRY(lsq_launch_q16_prepare(c->stream, dX, cn, d, dK, c->sci.as<float>(), c->T.as<float>(), m, c->Tq.as<uint16_t>(),
                                        reinterpret_cast<int *>(sc + 16), reinterpret_cast<float *>(sc + 256), reinterpret_cast<unsigned *>(sc + 64),
                                        c->qflag.as<unsigned short>(), c->qp.as<lsq_q16_params>(), c->tables_changed,
                                        reinterpret_cast<float *>(sc + off_rowmin), reinterpret_cast<float *>(sc + off_means), c->qsigma.as<float>(),
-                                       reinterpret_cast<float *>(sc + off_colmean), reinterpret_cast<float *>(sc + off_colshift)));
+                                       reinterpret_cast<float *>(sc + off_colmean), reinterpret_cast<float *>(sc + off_colshift), Xsample, nsample_rows,
+                                       Xsample ? c->sSigmaS.as<float>() : nullptr));
         c->q_colshift = reinterpret_cast<float *>(sc + off_colshift);
         c->tables_changed = 0;
+        if (means_out) *means_out = reinterpret_cast<float *>(sc + off_means);
     }
+    return LSQ_OK;
+}
+
+static int q16_verdict(lsq_ctx *c, bool q16, int64_t cn, int m);
+
+static int build_unaries(lsq_ctx *c, const float *dX, const float *dK, int d, int64_t cn, int m, int slice, int64_t r0, int64_t rows) {
+    c->chunk_q16 = false;
+    const bool q16 = slice > 0 && r0 == 0 && rows == cn && use_q16(c, cn);
+    if (q16) c->call_q16_chunks += 1;
+    if (q16) LSQ_TRY(q16_prepare_chunk(c, dX, dK, d, cn, m));      // 16-bit filtered walk: the GEMM below then also emits the u16 planes
     {
         Timer t(c, CAT_UNARIES);
         LSQ_TRY(c->U.ensure(sizeof(float) * (size_t)m * (size_t)cn * LSQ_H));
@@ -433,6 +486,11 @@ static int build_unaries(lsq_ctx *c, const float *dX, const float *dK, int d, in
                                       dq ? c->qflag.as<unsigned short>() : nullptr, nullptr, 1, dq ? c->qsigma.as<float>() : nullptr,
                                       dq ? c->q_colshift : nullptr));
     }
+    return q16_verdict(c, q16, cn, m);
+}
+
+// which road the chunk takes after its unary GEMM (filtered walk / f32 walk): on the host, or -- option "async" -- by a one-thread kernel
+static int q16_verdict(lsq_ctx *c, bool q16, int64_t cn, int m) {
     c->chunk_road_dev = false;
     if (q16 && c->async_mode) {
         // option "async": the same verdict taken by a one-thread kernel; both walks are enqueued and the word picks (run_sweeps)
@@ -453,6 +511,78 @@ static int build_unaries(lsq_ctx *c, const float *dX, const float *dK, int d, in
         else c->filter_fallback_chunks += 1;
     }
     return LSQ_OK;
+}
+
+// The FIRST chunk of a host-buffer call: X goes up panel by panel on the copy stream (a helper thread issues the pageable copies: each one blocks its
+// caller for the length of the transfer) and every panel's sigma pass + unary GEMM runs on the compute stream as soon as the panel has landed -- the
+// GEMM hides under the upload instead of following it (measured: 512 MB take 9.5 ms at 56 GB/s whichever way they are issued).
+// The filtered walk's level parameters need value ranges BEFORE the first GEMM panel: the sample rows (the same every-rts-th 128-row panels the
+// strided pass reads) are packed on the host and uploaded first, a few MB.  Same codes as the one-piece path: the parameters only steer the filter.
+static int build_unaries_from_host(lsq_ctx *c, const float *Xh, float *dXc, const float *dK, int d, int64_t cn, int m, int slice) {
+    c->chunk_q16 = false;
+    const bool q16 = slice > 0 && use_q16(c, cn);
+    if (q16) c->call_q16_chunks += 1;
+    const size_t row_bytes = sizeof(float) * (size_t)d;
+    int64_t prow = (int64_t)((uint64_t)c->panel_bytes / row_bytes) / 128 * 128;      // ~48 MB panels, whole 128-row tiles
+    if (prow < 128) prow = 128;
+    const int npan = (int)((cn + prow - 1) / prow);
+    if (!c->copy_stream) LSQ_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    while ((int)c->panel_ev.size() < npan) {
+        hipEvent_t e = nullptr;
+        LSQ_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->panel_ev.push_back(e);
+    }
+    float *means = nullptr;
+    if (q16) {
+        int64_t rts = 1;
+        const int spanels = lsq_q16_sample_rows(cn, d, &rts);
+        int64_t ns = 0;
+        for (int sp = 0; sp < spanels; ++sp) ns += std::min<int64_t>(128, cn - (int64_t)sp * rts * 128);
+        c->sample_host.resize((size_t)ns * d);
+        int64_t at = 0;
+        for (int sp = 0; sp < spanels; ++sp) {
+            const int64_t r0 = (int64_t)sp * rts * 128, rows = std::min<int64_t>(128, cn - r0);
+            memcpy(c->sample_host.data() + (size_t)at * d, Xh + (size_t)r0 * d, (size_t)rows * row_bytes);
+            at += rows;
+        }
+        LSQ_TRY(c->sSample.ensure((size_t)ns * row_bytes));
+        LSQ_HIP(hipMemcpyAsync(c->sSample.p, c->sample_host.data(), (size_t)ns * row_bytes, hipMemcpyHostToDevice, c->stream));
+        LSQ_TRY(q16_prepare_chunk(c, dXc, dK, d, cn, m, c->sSample.as<float>(), ns, &means));
+    }
+    LSQ_TRY(c->U.ensure(sizeof(float) * (size_t)m * (size_t)cn * LSQ_H));
+    std::atomic<int> landed{0};
+    hipError_t herr = hipSuccess;
+    std::thread feeder([&]() {
+        hipError_t e = hipSetDevice(c->device);
+        for (int p = 0; p < npan && e == hipSuccess; ++p) {
+            const int64_t r0 = (int64_t)p * prow, rows = std::min<int64_t>(prow, cn - r0);
+            e = hipMemcpyAsync(dXc + (size_t)r0 * d, Xh + (size_t)r0 * d, (size_t)rows * row_bytes, hipMemcpyHostToDevice, c->copy_stream);
+            if (e == hipSuccess) e = hipEventRecord(c->panel_ev[(size_t)p], c->copy_stream);
+            if (e == hipSuccess) landed.store(p + 1, std::memory_order_release);
+        }
+        herr = e;
+        if (e != hipSuccess) landed.store(npan + 1, std::memory_order_release);      // release the consumer: it checks herr after the join
+    });
+    int rc = LSQ_OK;
+    uint16_t *dq = q16 ? c->Uq.as<uint16_t>() : nullptr;
+    char *sc = q16 ? c->qscratch.as<char>() : nullptr;
+    for (int p = 0; p < npan && rc == LSQ_OK; ++p) {
+        while (landed.load(std::memory_order_acquire) <= p) std::this_thread::yield();
+        if (landed.load(std::memory_order_acquire) > npan) break;                    // the feeder failed
+        const int64_t r0 = (int64_t)p * prow, rows = std::min<int64_t>(prow, cn - r0);
+        if (hipStreamWaitEvent(c->stream, c->panel_ev[(size_t)p], 0) != hipSuccess) { lsq_set_error("hipStreamWaitEvent failed"); rc = LSQ_EHIP; break; }
+        Timer t(c, CAT_UNARIES);
+        if (q16) rc = lsq_launch_unary_shift_panel(c->stream, dXc + (size_t)r0 * d, rows, d, m, means, c->qsigma.as<float>() + (size_t)r0 * m,
+                                                   reinterpret_cast<unsigned *>(sc + 64), c->qflag.as<unsigned short>(), r0, c->qp.as<lsq_q16_params>());
+        if (rc == LSQ_OK)
+            rc = lsq_launch_chain_gemm(c->stream, dXc + (size_t)r0 * d, dK, c->sci.as<float>(), -2.0f, rows, m * LSQ_H, d, LSQ_H, cn * (int64_t)LSQ_H, LSQ_H,
+                                       c->U.as<float>(), slice, cn, r0, dq, dq ? lsq_q16_slice_width(m) : 0, dq ? c->qp.as<lsq_q16_params>() : nullptr, 0,
+                                       dq ? c->qflag.as<unsigned short>() : nullptr, nullptr, 1, dq ? c->qsigma.as<float>() : nullptr, dq ? c->q_colshift : nullptr);
+    }
+    feeder.join();
+    if (herr != hipSuccess) { lsq_set_error("upload of X failed: %s", hipGetErrorString(herr)); return herr == hipErrorOutOfMemory ? LSQ_ENOMEM : LSQ_EHIP; }
+    LSQ_TRY(rc);
+    return q16_verdict(c, q16, cn, m);
 }
 
 // ref_rec / ref_valid: the vectors' current records and validity masks (read-only during the sweeps), or nullptr
@@ -656,6 +786,7 @@ static int begin_call(lsq_ctx *c, int64_t I, int nr) {
     }
     c->walk_counters = c->active.as<unsigned long long>();
     c->call_q16_chunks = 0;
+    c->new_call = 1;
     LSQ_HIP(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long) * 2 * (size_t)std::max<int64_t>(I, 1), c->stream));
     LSQ_HIP(hipMemsetAsync(c->obj.p, 0, sizeof(double) * (size_t)std::max(nr, 1), c->stream));
     LSQ_HIP(hipMemsetAsync(c->bad.p, 0, sizeof(int), c->stream));
@@ -738,6 +869,23 @@ extern "C" int lsq_encode_icm_dev(lsq_ctx *c, const float *dX, const uint8_t *dB
     return finish_call(c, I, nr, obj_sums, stats);
 }
 
+// The caller's host codebooks -> c->sK + tables.  Unchanged since the last host-buffer call of this context (same shape, same bytes): nothing is
+// uploaded or rebuilt.
+static int host_codebooks(lsq_ctx *c, const float *K, int d, int m) {
+    const size_t count = (size_t)m * LSQ_H * d, kbytes = sizeof(float) * count;
+    if (c->tables_valid && c->hostK_d == d && c->hostK_m == m && c->hostK.size() == count && memcmp(c->hostK.data(), K, kbytes) == 0) {
+        c->table_reuses += 1;
+        return LSQ_OK;
+    }
+    LSQ_TRY(c->sK.ensure(kbytes));
+    LSQ_HIP(hipMemcpyAsync(c->sK.p, K, kbytes, hipMemcpyHostToDevice, c->stream));
+    LSQ_TRY(prepare_tables(c, c->sK.as<float>(), d, m));
+    c->hostK.assign(K, K + count);        // (the pageable copy above has read K by the time it returns)
+    c->hostK_d = d; c->hostK_m = m;
+    c->tables_valid = true;
+    return LSQ_OK;
+}
+
 // host-buffer core shared by lsq_encode_icm / lsq_encoding_icm
 // `place` (multi-GPU shards): the shard's rows go to rows [row0, row0 + n) of snapshots that are ntot rows long, and the
 // objective sums / counters are handed back raw so that the caller can combine the shards.
@@ -753,11 +901,8 @@ static int encode_host(lsq_ctx *c, const char *fn, const float *X, const int16_t
     if (!K || (!objs && !place) || (n > 0 && (!X || !B || !Bs))) { lsq_set_error("%s: null pointer", fn); return LSQ_EINVAL; }
     const int64_t ntot = place ? place->ntot : n, row0 = place ? place->row0 : 0;
     LSQ_TRY(begin_call(c, I, nr));
-    const size_t kbytes = sizeof(float) * (size_t)m * LSQ_H * d;
-    LSQ_TRY(c->sK.ensure(kbytes));
-    LSQ_HIP(hipMemcpyAsync(c->sK.p, K, kbytes, hipMemcpyHostToDevice, c->stream));
+    LSQ_TRY(host_codebooks(c, K, d, m));
     const float *dK = c->sK.as<float>();
-    LSQ_TRY(prepare_tables(c, dK, d, m));
     // The ONE range check of the input codes (1..h): a host scan, hidden under the table kernels just enqueued and done before anything
     // reads B or writes Bs -- an invalid call never touches the caller's output and the codes are not checked twice (ADVICE r2:
     // the device flag of codes_from_i16_kernel is only consulted by the fine-grained entry points, which have no host scan).
@@ -786,14 +931,17 @@ static int encode_host(lsq_ctx *c, const char *fn, const float *X, const int16_t
         LSQ_TRY(c->sOut16.ensure(sizeof(int16_t) * (size_t)cn * m * nr));
         LSQ_TRY(c->recCur.ensure((size_t)cn * cs));
         float *dXc = xb[which]->as<float>();
-        if (off == 0) LSQ_HIP(hipMemcpyAsync(dXc, X, sizeof(float) * (size_t)cn * d, hipMemcpyHostToDevice, c->stream));
+        const bool piped = off == 0 && c->pipeline_min_bytes > 0 && (int64_t)sizeof(float) * cn * d >= c->pipeline_min_bytes;
+        if (piped) {}                                                       // X goes up panel by panel under its own unary GEMM (below)
+        else if (off == 0) LSQ_HIP(hipMemcpyAsync(dXc, X, sizeof(float) * (size_t)cn * d, hipMemcpyHostToDevice, c->stream));
         else LSQ_HIP(hipStreamWaitEvent(c->stream, c->copy_done, 0));      // uploaded under the previous chunk's compute
         LSQ_HIP(hipMemcpyAsync(c->sB16.p, B + off * m, sizeof(int16_t) * (size_t)cn * m, hipMemcpyHostToDevice, c->stream));
         LSQ_TRY(lsq_launch_codes_from_i16(c->stream, c->sB16.as<int16_t>(), cn, m, h, c->recCur.as<uint8_t>(), c->bad.as<int>()));
         auto snap = [&](int r, const uint8_t *cur) {
             return lsq_launch_codes_to_i16(c->stream, cur, cn, m, c->sOut16.as<int16_t>() + (int64_t)r * cn * m);
         };
-        LSQ_TRY(encode_chunk(c, dXc, dK, cn, global_offset + (uint64_t)off, P, I, snap));
+        if (piped) LSQ_TRY(build_unaries_from_host(c, X, dXc, dK, d, cn, m, u_slice_width(c, m)));
+        LSQ_TRY(encode_chunk(c, dXc, dK, cn, global_offset + (uint64_t)off, P, I, snap, piped));
         const int64_t noff = off + c->chunk;
         if (noff < n) {      // next chunk's X: its buffer was last read by chunk c-1, which completed at the previous synchronize
             const int64_t ncn = std::min<int64_t>(c->chunk, n - noff);
@@ -993,6 +1141,7 @@ extern "C" int lsq_encoding_icm(lsq_ctx *c, const float *X, const int16_t *oldB,
 // upload helpers for the fine-grained entry points
 static int upload_xk(lsq_ctx *c, const float *X, const float *K, int d, int64_t n, int m) {
     const size_t kbytes = sizeof(float) * (size_t)m * LSQ_H * d;
+    c->tables_valid = false;        // sK is about to hold other codebooks than the cached tables were built from
     LSQ_TRY(c->sK.ensure(kbytes));
     LSQ_HIP(hipMemcpyAsync(c->sK.p, K, kbytes, hipMemcpyHostToDevice, c->stream));
     if (X) {
@@ -1138,6 +1287,7 @@ extern "C" int lsq_update_codebooks_gpu(lsq_ctx *c, const float *X, const int16_
     if (n < 1 || !X || !B || !K_out) { lsq_set_error("lsq_update_codebooks_gpu: bad arguments"); return LSQ_EINVAL; }
     LSQ_TRY(c->sX.ensure(sizeof(float) * (size_t)n * d));
     LSQ_TRY(c->sK.ensure(sizeof(float) * (size_t)m * LSQ_H * d));
+    c->tables_valid = false;
     LSQ_HIP(hipMemcpyAsync(c->sX.p, X, sizeof(float) * (size_t)n * d, hipMemcpyHostToDevice, c->stream));
     LSQ_TRY(upload_codes(c, B, n, m, h, c->recCur));                          // records of stride 8 / 16 -> tight [n][m] below
     LSQ_TRY(c->sTight.ensure((size_t)n * m));

@@ -162,14 +162,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const int kend = FULLK ? BK : ((Kd - k0 < BK) ? ((Kd - k0 + 1) & ~1) : BK);   // odd tail: one zero product appended
         const float *ap = As[cur] + (wy * 64 + l31) * LD + lhi;
         const float *bp = Bs[cur] + (wx * 64 + l31) * LD + lhi;
-#pragma unroll
-        for (int kk = 0; kk < kend; kk += 2) {                  // ascending k through one accumulator: the oracle's fmaf chain
+        auto kstep = [&](int kk) {                              // ascending k through one accumulator: the oracle's fmaf chain
             const float a0 = ap[kk], a1 = ap[32 * LD + kk];
             const float b0 = bp[kk], b1 = bp[32 * LD + kk];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        };
+        if constexpr (FULLK) {
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) kstep(kk);
+        } else {
+            for (int kk = 0; kk < kend; kk += 2) kstep(kk);
         }
         if (more) {                                              // the other buffer was last read one iteration ago (barrier below)
             tile_store<VEC4, BK>(ra, 1.0f, As[cur ^ 1], tid);

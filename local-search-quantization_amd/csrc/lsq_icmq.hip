@@ -129,17 +129,33 @@ __global__ __launch_bounds__(256) void codebook_means_kernel(const float *__rest
 // sigma[i][j] = 2 <x_i, r_j>  (one 16-lane DPP row per vector, grid-stride);  sigmax[0] = bits of max |sigma| over the chunk (non-negative floats
 // order like uints).  One atomic per wave at most, and only when the wave's maximum beats the word as L2 holds it (an L1-cached read would stay at
 // the initial 0 and send every wave's atomic to the same word: 2.5 ms of serialisation per 10^6 vectors, measured).
+// bound (optional; with qflag, P): the level parameters were derived from a SAMPLE's max |sigma| (the host-buffer pipeline: the sample is uploaded ahead
+// of the panels); a vector whose |sigma| exceeds the bound the parameters assumed gets every node flagged -- it takes the f32 routine, like a unary
+// outside the sampled level range -- so the window stays rigorous for every vector the filter decides.  flag_row0: the row of sigma[0] in qflag.
 __global__ __launch_bounds__(256) void unary_shift_kernel(const float *__restrict__ X, const float *__restrict__ R, int64_t n, int d, int m,
-                                                          float *__restrict__ sigma, unsigned *__restrict__ sigmax) {
+                                                          float *__restrict__ sigma, unsigned *__restrict__ sigmax,
+                                                          const unsigned *__restrict__ bound = nullptr, unsigned short *__restrict__ qflag = nullptr,
+                                                          int64_t flag_row0 = 0, lsq_q16_params *__restrict__ P = nullptr) {
     const int lane = threadIdx.x & 63, lp = lane & 15;
     const int64_t nrows = (int64_t)gridDim.x * 16;
     const bool vec = (d & 3) == 0 && ((((uintptr_t)X | (uintptr_t)R) & 15) == 0);
     float amax = 0.0f;
     // whole waves stay together (the DPP row sums read neighbour lanes): the loop bound is wave-uniform, dead rows are masked
     const int64_t first = ((int64_t)blockIdx.x * 256 + (threadIdx.x & ~63)) >> 4;      // the wave's first row
+    const float bnd = bound ? __uint_as_float(*bound) : __builtin_inff();
+    auto flag_row = [&](int64_t i, bool live, float rmax, bool rnan) {
+        if (!qflag || !live || lp != 0 || (!(rmax > bnd) && !rnan)) return;
+        const int64_t gi = flag_row0 + i;
+        const unsigned bits = ((1u << m) - 1u) << (16 * (int)(gi & 1));
+        const unsigned old = atomicOr(reinterpret_cast<unsigned *>(qflag + (gi & ~(int64_t)1)), bits);
+        const int fresh = __popc(bits & ~old);
+        if (P && fresh) atomicAdd(&P->nflag, fresh);
+    };
     for (int64_t base = first; base < n; base += nrows) {
         const int64_t i = base + (lane >> 4);
         const bool live = i < n;
+        float rmax = 0.0f;
+        bool rnan = false;
         const float *x = X + (live ? i : 0) * (int64_t)d;
         if (vec && d <= 256) {                                      // the vector stays in registers (16 floats per lane) while the m means pass by (L1)
             f32x4 xr[4];
@@ -161,8 +177,9 @@ __global__ __launch_bounds__(256) void unary_shift_kernel(const float *__restric
                 acc = acc + dpp_self<DPP_MIRROR, 0xf>(acc);
                 const float sg = 2.0f * acc;
                 if (live && lp == 0) sigma[i * m + j] = sg;
-                if (live) amax = fmaxf(amax, fabsf(sg));
+                if (live) { amax = fmaxf(amax, fabsf(sg)); rmax = fmaxf(rmax, fabsf(sg)); if (!(sg == sg)) rnan = true; }
             }
+            flag_row(i, live, rmax, rnan);
             continue;
         }
         for (int j = 0; j < m; ++j) {
@@ -182,8 +199,9 @@ __global__ __launch_bounds__(256) void unary_shift_kernel(const float *__restric
             acc = acc + dpp_self<DPP_MIRROR, 0xf>(acc);
             const float sg = 2.0f * acc;
             if (live && lp == 0) sigma[i * m + j] = sg;
-            if (live) amax = fmaxf(amax, fabsf(sg));                // NaN-ignoring: a non-finite sigma shows up in the range pass
+            if (live) { amax = fmaxf(amax, fabsf(sg)); rmax = fmaxf(rmax, fabsf(sg)); if (!(sg == sg)) rnan = true; }      // amax is NaN-ignoring: a non-finite sigma shows up in the range pass
         }
+        flag_row(i, live, rmax, rnan);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
@@ -197,9 +215,13 @@ __global__ __launch_bounds__(256) void unary_shift_kernel(const float *__restric
 //   T_jk: exact range (table_range_kernel).
 // ok = 0 -- the whole chunk goes to the f32 walk -- when a pair table or the sample holds a non-finite value, or a range degenerates.
 __global__ __launch_bounds__(64) void q16_params_kernel(const float *__restrict__ trange, const int *__restrict__ bad, const unsigned *__restrict__ qrange,
-                                                        int m, lsq_q16_params *__restrict__ P, const unsigned *__restrict__ sigrange) {
+                                                        int m, lsq_q16_params *__restrict__ P, unsigned *__restrict__ sigrange, float sig_scale) {
     if (threadIdx.x != 0) return;
-    const double sigmax = sigrange ? (double)__uint_as_float(sigrange[0]) : 0.0;      // max |sigma| of the chunk (bit pattern of a non-negative float)
+    // max |sigma| of the chunk (bit pattern of a non-negative float) -- or, sig_scale > 1: of a SAMPLE of it, widened; sigrange[1] then tells the
+    // panel-wise unary_shift_kernel launches which bound the parameters assumed (vectors beyond it are flagged)
+    const float sigb = sigrange ? __uint_as_float(sigrange[0]) * sig_scale + (sig_scale > 1.0f ? 1e-30f : 0.0f) : 0.0f;
+    if (sigrange) sigrange[1] = __float_as_uint(sigb);
+    const double sigmax = (double)sigb;
     bool ok = (bad[0] == 0) && (qrange[2 * LSQ_MAX_M] == 0);
     for (int j = 0; j < m; ++j) {
         const unsigned kl = qrange[2 * j], kh = qrange[2 * j + 1];
@@ -917,9 +939,28 @@ int lsq_q16_slice_width(int m) {
     return 2 * lsq_walk_slice_width(m);
 }      // candidates per 16-bit slice: the same bytes per piece as the f32 walk
 
+int lsq_launch_unary_shift_panel(hipStream_t s, const float *Xp, int64_t rows, int d, int m, const float *means, float *sigma_p, unsigned *qrange,
+                                 unsigned short *qflag, int64_t row0, lsq_q16_params *P) {
+    if (rows <= 0) return LSQ_OK;
+    const int64_t shift_blocks = (rows * 16 + 255) / 256;
+    // the chunk maximum is not collected here (a scratch word takes it): the parameters were fixed from the sample
+    hipLaunchKernelGGL(unary_shift_kernel, dim3((unsigned)(shift_blocks < 2048 ? shift_blocks : 2048)), dim3(256), 0, s, Xp, means, rows, d, m, sigma_p,
+                       qrange + 2 * LSQ_MAX_M + 3, qrange + 2 * LSQ_MAX_M + 2, qflag, row0, P);
+    LSQ_HIP(hipGetLastError());
+    return LSQ_OK;
+}
+
+int lsq_q16_sample_rows(int64_t n, int d, int64_t *rts_out) {
+    const int64_t nsample = d <= 128 ? 16384 : (d <= 512 ? 8192 : 4096);      // the pass costs 2 d m h flops per sampled vector: fewer of them at large d
+    const int64_t rts = n > nsample ? n / nsample : 1;
+    if (rts_out) *rts_out = rts;
+    return (int)((n + 128 * rts - 1) / (128 * rts));      // number of 128-row panels in the sample (the last one may be short)
+}
+
 int lsq_launch_q16_prepare(hipStream_t s, const float *X, int64_t n, int d, const float *K, const float *sci, const float *T, int m, uint16_t *Tq,
                            int *bad, float *trange, unsigned *qrange, unsigned short *qflag, lsq_q16_params *P, int tables_changed,
-                           float *rowmin, float *means, float *sigma, float *colmean, float *colshift) {
+                           float *rowmin, float *means, float *sigma, float *colmean, float *colshift, const float *Xsample, int64_t nsample_rows,
+                           float *sigma_sample) {
     // bad[0]: a non-finite pair table (per call); rowmin / colmean [m*m*256], colshift [m*256], means [m*d]: per call; sigma [n*m]: per chunk;
     // qrange[2*16 + 1]: sample flag, [2*16 + 2]: max |sigma|
     if (tables_changed) {
@@ -930,19 +971,29 @@ int lsq_launch_q16_prepare(hipStream_t s, const float *X, int64_t n, int d, cons
         hipLaunchKernelGGL(codebook_means_kernel, dim3((unsigned)((d + 63) / 64), (unsigned)m), dim3(256), 0, s, K, m, d, means);
     }
     // sampled range of the SHIFTED unaries: about 16 384 vectors at d <= 128 (every rts-th panel of 128 consecutive ones) through the range-only GEMM pass
-    LSQ_HIP(hipMemsetAsync(qrange, 0, sizeof(unsigned) * (2 * LSQ_MAX_M + 2), s));
+    LSQ_HIP(hipMemsetAsync(qrange, 0, sizeof(unsigned) * (2 * LSQ_MAX_M + 4), s));
     for (int j = 0; j < m; ++j) LSQ_HIP(hipMemsetAsync(qrange + 2 * j, 0xff, sizeof(unsigned), s));      // min slots start at the largest key
-    if (n > 0) {
+    if (Xsample) {
+        // host-buffer pipeline: the sample (the same rows the strided pass would read) was uploaded ahead of the panels, compacted; sigma of the sample,
+        // its maximum (widened below) and the value ranges come from it alone; the panels' own sigma follow panel by panel (lsq_launch_unary_shift_panel)
+        const int64_t shift_blocks = (nsample_rows * 16 + 255) / 256;
+        hipLaunchKernelGGL(unary_shift_kernel, dim3((unsigned)(shift_blocks < 2048 ? shift_blocks : 2048)), dim3(256), 0, s, Xsample, means, nsample_rows, d, m,
+                           sigma_sample, qrange + 2 * LSQ_MAX_M + 1);
+        LSQ_TRY(lsq_launch_chain_gemm(s, Xsample, K, sci, -2.0f, nsample_rows, m * LSQ_H, d, LSQ_H, 0, 0, nullptr, 0, nsample_rows, 0, nullptr, 0, nullptr, 0, nullptr,
+                                      qrange, 1, sigma_sample, colshift));
+        LSQ_HIP(hipMemsetAsync(qflag, 0, sizeof(unsigned short) * (size_t)((n + 1) & ~(int64_t)1), s));
+    } else if (n > 0) {
         const int64_t shift_blocks = (n * 16 + 255) / 256;           // 16 vectors per block per pass, at most 8 blocks per CU in flight
         hipLaunchKernelGGL(unary_shift_kernel, dim3((unsigned)(shift_blocks < 2048 ? shift_blocks : 2048)), dim3(256), 0, s, X, means, n, d, m, sigma,
                            qrange + 2 * LSQ_MAX_M + 1);
-        const int64_t nsample = d <= 128 ? 16384 : (d <= 512 ? 8192 : 4096);      // the pass costs 2 d m h flops per sampled vector: fewer of them at large d
-        const int rts = n > nsample ? (int)(n / nsample) : 1;
+        int64_t rts64 = 1;
+        (void)lsq_q16_sample_rows(n, d, &rts64);
+        const int rts = (int)rts64;
         LSQ_TRY(lsq_launch_chain_gemm(s, X, K, sci, -2.0f, n, m * LSQ_H, d, LSQ_H, 0, 0, nullptr, 0, n, 0, nullptr, 0, nullptr, 0, nullptr, qrange, rts, sigma,
                                       colshift));
         LSQ_HIP(hipMemsetAsync(qflag, 0, sizeof(unsigned short) * (size_t)((n + 1) & ~(int64_t)1), s));
     }
-    hipLaunchKernelGGL(q16_params_kernel, dim3(1), dim3(64), 0, s, trange, bad, qrange, m, P, qrange + 2 * LSQ_MAX_M + 1);
+    hipLaunchKernelGGL(q16_params_kernel, dim3(1), dim3(64), 0, s, trange, bad, qrange, m, P, qrange + 2 * LSQ_MAX_M + 1, Xsample ? 2.0f : 1.0f);
     if (m > 1) {
         const int slq = lsq_q16_slice_width(m);
         const int64_t total = (int64_t)m * (LSQ_H / slq) * (m - 1) * LSQ_H * (slq / 8);

@@ -167,7 +167,14 @@ int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const fl
 int lsq_q16_slice_width(int m);
 int lsq_launch_q16_prepare(hipStream_t s, const float *X, int64_t n, int d, const float *K, const float *sci, const float *T, int m, uint16_t *Tq,
                            int *bad, float *trange, unsigned *qrange, unsigned short *qflag, lsq_q16_params *P, int tables_changed,
-                           float *rowmin, float *means, float *sigma, float *colmean, float *colshift);
+                           float *rowmin, float *means, float *sigma, float *colmean, float *colshift, const float *Xsample = nullptr,
+                           int64_t nsample_rows = 0, float *sigma_sample = nullptr);
+// Xsample (optional; the host-buffer pipeline): the rows the strided sample pass would read -- every rts-th 128-row panel, lsq_q16_sample_rows -- already
+// compacted on the device; the level parameters come from them alone (max |sigma| widened x2) and X itself is not touched: its sigma are computed panel by
+// panel as the panels land (lsq_launch_unary_shift_panel: vectors beyond the assumed |sigma| bound are flagged for the f32 routine).
+int lsq_q16_sample_rows(int64_t n, int d, int64_t *rts_out);      // -> number of 128-row sample panels; *rts_out = the panel stride
+int lsq_launch_unary_shift_panel(hipStream_t s, const float *Xp, int64_t rows, int d, int m, const float *means, float *sigma_p, unsigned *qrange,
+                                 unsigned short *qflag, int64_t row0, lsq_q16_params *P);
 // rowmin [m*m*256], means [m*d], colmean [m*m*256], colshift [m*256] (per call), sigma [n*m] (per chunk); trange: 3 floats per pair table
 int lsq_launch_icm_walkq(hipStream_t s, const float *U, const uint16_t *Uq, const uint16_t *Tq, const float *T, uint8_t *rec, unsigned short *valid,
                          int64_t n, int m, const int32_t *order, int nnodes, int pos0, int use_skip, unsigned long long *active_total, int light,

@@ -84,7 +84,7 @@ class Engine:
 
     def timings(self):
         t = _lib.Timings()
-        self._check(self._L.lsq_get_timings(self._h, C.byref(t)))
+        self._check(self._L.lsq_get_timings_sized(self._h, C.addressof(t), C.sizeof(t)))      # size-checked: this binding and the library may be of different versions
         return t.as_dict()
 
     def walk_trace(self, count=64):

@@ -99,3 +99,55 @@ def test_bench_plain_multi_gpu_form_launches_its_own_ranks():
         assert out["config"]["rccl_ranks"] == 2 and out["config"]["collective_backend"] == "rccl"
     else:
         assert out["config"]["collective_backend"] == "gloo"
+
+
+def test_chained_host_calls_reuse_the_tables_of_unchanged_codebooks(lsq, oracle):
+    """The trainer's chain (demos/demo_lsq.jl:48-51: encoding_icm called ilsiter times with the SAME codebooks): from the second call on the context
+    finds the caller's K unchanged (one memcmp) and neither uploads it nor rebuilds the tables; a K that differs in ONE float rebuilds them.  Codes
+    equal the oracle's chain either way (cfg1's shape)."""
+    from conftest import make_problem
+    d, n, m, J, npert, seed = 128, 10_000, 8, 4, 4, 42
+    X, K, B0 = make_problem(d, n, m, seed=3)
+    with lsq.Engine(0) as eng:
+        B, Bref = B0, B0
+        for it in range(3):
+            B = eng.encoding_icm(X, B, K, m, J, True, npert, seed=seed, it=it)
+            Bref = oracle.encoding_icm_faithful(X, Bref, K, m, H, J, True, npert, seed, it)
+            assert np.array_equal(B, Bref), "call %d" % it
+        assert eng.timings()["table_reuses"] == 2
+        K2 = K.copy()
+        K2[5 * H + 17, 3] += np.float32(0.5)
+        B = eng.encoding_icm(X, B, K2, m, J, True, npert, seed=seed, it=3)
+        Bref = oracle.encoding_icm_faithful(X, Bref, K2, m, H, J, True, npert, seed, 3)
+        assert np.array_equal(B, Bref)
+        assert eng.timings()["table_reuses"] == 2                       # rebuilt, not reused
+        # another entry point in between (it overwrites the staged codebooks): the next chained call must rebuild as well
+        eng.veccost(X[:100], B[:100], K, m)
+        B = eng.encoding_icm(X, B, K2, m, J, True, npert, seed=seed, it=4)
+        Bref = oracle.encoding_icm_faithful(X, Bref, K2, m, H, J, True, npert, seed, 4)
+        assert np.array_equal(B, Bref)
+        assert eng.timings()["table_reuses"] == 2
+
+
+@pytest.mark.parametrize("n,d,m,forced", [(70_001, 32, 8, True), (70_001, 32, 8, False), (9_000, 24, 5, False), (66_000, 16, 12, True)])
+def test_host_upload_pipeline_gives_the_same_codes(lsq, oracle, n, d, m, forced):
+    """The host-buffer entry point's first chunk uploaded panel by panel under its own unary GEMM (level sample first; a helper thread feeds the copy
+    stream): every vector against the oracle, with the filtered walk forced onto the chunk (`forced`) and on the default roads, several ragged panels,
+    heavy-tailed rows in the LAST panel (their |sigma| lies beyond what the early sample predicted: they must be flagged, not mis-filtered)."""
+    from conftest import make_problem
+    ils, J, npert, seed = [2], 3, 3, 5
+    X, K, B0 = make_problem(d, n, m, seed=9, kind="gauss")
+    X[-300:] *= np.float32(50.0)                                                   # not in the sample's first panels
+    ref, objs_ref = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, True, seed)
+    with lsq.Engine(0) as eng:
+        eng.set_option("upload_pipeline_min_bytes", 1)
+        eng.set_option("upload_panel_bytes", 4 * d * 128 * 37)                    # 37 tiles per panel: several panels, the last one ragged
+        if forced:
+            for k, v in (("q16_min", 0), ("light", 0), ("filter_probe_div", 0), ("filter_fallback_div", 0)):
+                eng.set_option(k, v)
+        Bs, objs = eng.encode_icm(X, B0, K, m, ils, J, npert, True, seed=seed)
+        tm = eng.timings()
+    assert np.array_equal(Bs, ref), "%d codes differ" % (Bs != ref).sum()
+    assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0)
+    if forced:
+        assert tm["filtered_blocks"] > 0 and tm["filter_f32"] > 0, tm             # the scaled rows went through the f32 routine
