@@ -51,7 +51,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (~6.3 TB/s achievable)
 HBM_ACHIEVABLE_GBS = 6300.0
-LDS_PEAK_GBS = 150000.0        # same guide, section LDS: ds_read_b64/b128 aggregate with every CU streaming
+LDS_PEAK_GBS = 150000.0        # same guide, section LDS: ds_read_b64/b128 aggregate with every CU streaming (reproduced: profiles/r05_ubench_lds.txt)
+LDS_PATTERN_GBS = LDS_PEAK_GBS / 2.125      # 16 random 64-byte rows per ds_read_b128 (four per 16-lane group): E[max rows per bank quarter] = 2.125 cycles per group
 PMC_GLOB = "r[0-9][0-9]*_pmc_per_kernel.json"      # committed PMC passes; `traffic` is read from the newest one whose build hash matches
 
 
@@ -228,18 +229,25 @@ def train_codebooks(lsq, eng, dX, dB0, n, d, m, args):
     ns = min(n, 100_000)
     t0 = time.perf_counter()
     # profiling runs are several processes on one box: the codebooks are trained once and cached, so that the profiled processes contain no training launches
-    cache = os.path.join(tempfile.gettempdir(), "lsq_bench_trained_K_%d_%d_%d_%d_%d.npz" % (ns, d, m, args.icmiter, args.npert))
-    if os.path.exists(cache):
+    # (opt-in: LSQ_BENCH_TRAIN_CACHE=1, set by tools/profile_round.sh; the key carries everything the codebooks depend on -- build, data seed / offset,
+    #  shape, training parameters -- so a stale file of another build or data set can never be picked up silently: ADVICE r4)
+    lib_path = lsq._lib.TUNING_LIB_PATH if args.tuning else lsq._lib.LIB_PATH
+    key = "%s_%d_%d_%d_%d_%d_seed1234_goff%d_train8x4_seed42" % (lib_hash(lib_path), ns, d, m, args.icmiter, args.npert, int(getattr(args, "_goff", 0)))
+    cache = os.path.join(tempfile.gettempdir(), "lsq_bench_trained_K_%s.npz" % key)
+    use_cache = os.environ.get("LSQ_BENCH_TRAIN_CACHE") == "1"
+    if use_cache and os.path.exists(cache):
         z = np.load(cache)
-        return z["K"], torch.from_numpy(z["K"]).to(dX.device), z["obj"], 0.0
+        if str(z["key"]) == key:
+            return z["K"], torch.from_numpy(z["K"]).to(dX.device), z["obj"], -1.0      # -1: cache hit (reported as such)
     with lsq.Engine(eng.device) as e2:          # the training loop resident in HBM: the same codebooks as train_lsq(..., device_update=True) (tests/test_pipeline_gpu.py)
         dKt, _, _, _, obj = lsq.train_lsq_dev(dX[:ns].contiguous(), m, h, dB0[:ns].contiguous(), 8, 4, args.icmiter, True, args.npert, seed=42, engine=e2,
                                               norm_codebook=False)
     Ktr = np.ascontiguousarray(dKt.cpu().numpy())
-    try:
-        np.savez(cache, K=Ktr, obj=np.asarray(obj))
-    except OSError:
-        pass
+    if use_cache:
+        try:
+            np.savez(cache, K=Ktr, obj=np.asarray(obj), key=key)
+        except OSError:
+            pass
     return Ktr, torch.from_numpy(Ktr).to(dX.device), obj, time.perf_counter() - t0
 
 
@@ -287,7 +295,7 @@ def workloads_leg(lsq, eng, dX, dB0, dK, n, d, m, args, goff):
     ns = min(n, 100_000)
     Ktr, dKtr, obj, train_s = train_codebooks(lsq, eng, dX, dB0, n, d, m, args)
     out["trained"], btr = timed(dX, dKtr, {}, "codebooks = train_lsq(first %d vectors of the same data, random initial codes, 8 iterations x 4 ILS): "
-                                "trained in %.1f s (not timed); default options" % (ns, train_s))
+                                "%s (not timed); default options" % (ns, "taken from this build's cache (LSQ_BENCH_TRAIN_CACHE=1)" if train_s < 0 else "trained in %.1f s" % train_s))
     out["trained"]["train_objective_first_last"] = [float(obj[0]), float(obj[-1])]
     # parity on the trained workload too: 256 vectors of its output vs the oracle
     import oracle as O
@@ -530,6 +538,7 @@ def main():
             "avg_launch_us": avg_launch_s * 1e6, "launches": int(tm["icm_launches"]),
             "algorithmic_bytes_per_launch": hbm_bytes,
             "bytes_per_node_update": bytes_nu,
+            "hbm_achieved": achieved, "hbm_frac": achieved / HBM_PEAK_GBS,
             "node_updates_recomputed_per_launch": nu_per_launch,
             "recomputed_fraction": tm["icm_node_updates"] / max(total_nu * args.steps, 1),
             "blocks": {"staged_f32": int(tm["staged_blocks"]), "light_f32": int(tm["light_blocks"]), "filtered_u16": int(tm["filtered_blocks"])},
@@ -543,12 +552,22 @@ def main():
                          "m1_compulsory.  The filtered walk's slice loop was bound by VALU issue (removing every LDS read changed nothing, removing VALU work shortened it); after the instruction-count work of round 2 its measured traffic moves at ~5.1 TB/s of the ~6.3 TB/s a streaming kernel reaches on this part (traffic_rate below): the launch is HBM-bound on the bytes it creates, 1.5x the algorithmic ones (DESIGN 4.2).",
             "gather": {"achieved": table_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0, "peak": LDS_PEAK_GBS, "unit": "GB/s",
                        "frac": (table_bytes / avg_launch_s / 1e9 / LDS_PEAK_GBS) if avg_launch_s > 0 else 0.0,
+                       "pattern_ceiling": LDS_PATTERN_GBS,
+                       "frac_of_pattern_ceiling": (table_bytes / avg_launch_s / 1e9 / LDS_PATTERN_GBS) if avg_launch_s > 0 else 0.0,
                        "note": "(m-1) pair-table rows per recomputed node update (512 B each as u16 levels, 1 KiB as f32), read from LDS-staged slices with "
                                "ds_read_b128 (16 random 64-byte rows per wave read: ~2.1-way bank conflicts are intrinsic to the lookup); peak = guide's aggregate"},
             "m1_compulsory": {"bytes_per_step": m1_bytes, "achieved": m1_bytes / step_s / 1e9, "unit": "GB/s",
                               "frac": m1_bytes / step_s / 1e9 / HBM_PEAK_GBS,
                               "note": "SURVEY 8(d) model M1 (X once, codes in/out, unaries written once and read once, X re-read for the cost) / whole step time"},
         }
+        # which ceiling does this shape use more of?  HBM (the level stream) or the LDS gathers (against the ceiling of THEIR access pattern)
+        util = {"hbm": roof["frac"], "lds": roof["gather"]["frac_of_pattern_ceiling"]}
+        roof["utilisation"] = util
+        if util["lds"] > util["hbm"]:
+            roof.update({"bound": "lds", "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "frac": achieved / HBM_PEAK_GBS},
+                         "achieved": roof["gather"]["achieved"], "peak": LDS_PATTERN_GBS, "frac": util["lds"],
+                         "bound_note": "m = %d: %d table rows per node update -- the LDS gathers run closer to their ceiling (150 TB/s / 2.125 for 16 random 64-byte rows per "
+                                       "ds_read_b128) than the level stream to HBM's; achieved / peak / frac are the gather's, the HBM figures are under `hbm`" % (m, m - 1)})
         tr = pmc_traffic(lib_sha)
         if tr is not None:
             roof["traffic"] = tr["bytes_per_icm_launch"]
@@ -632,6 +651,35 @@ def main():
         nb_dt = (time.perf_counter() - t0) / args.steps
         out["nonblocking_call"] = {"value": n / nb_dt, "unit": "vectors/s", "ms_per_step": nb_dt * 1e3, "same_objective": bool(abs(float(nb_sums[0].item()) - float(sums[0])) <= 1e-9 * abs(float(sums[0]))),
                                    "note": "lsq_encode_icm_dev with option async = 1: verdict and probe decided on the device, sums / counters written in stream order"}
+        # BASELINE configs[0] on the GPU: the trainer's call -- n = 10 000, d = 128, m = 8, ONE ILS iteration per call (demo_lsq.jl:34),
+        # chained through the host-buffer entry point lsq_encoding_icm (tables cached after the first call: same codebooks) and through lsq_encode_icm_dev
+        if (d, m) == (128, 8):
+            n1 = 10_000
+            X1, B1 = dX[:n1].cpu().numpy(), dB0[:n1].cpu().numpy().astype(np.int16) + 1
+            K1 = dK.cpu().numpy()
+            with lsq.Engine(dev_index) as e1:
+                Bc = B1
+                for it in range(3):
+                    Bc = e1.encoding_icm(X1, Bc, K1, m, args.icmiter, True, args.npert, seed=42, it=it)
+                t0 = time.perf_counter()
+                for it in range(3, 23):
+                    Bc = e1.encoding_icm(X1, Bc, K1, m, args.icmiter, True, args.npert, seed=42, it=it)
+                t_host = (time.perf_counter() - t0) / 20
+                reuses = e1.timings()["table_reuses"]
+                dX1, dB1 = dX[:n1].contiguous(), dB0[:n1].contiguous()
+                o1 = torch.empty((1, n1, m), dtype=torch.uint8, device=dX.device)
+                for _ in range(3):
+                    e1.encode_icm_dev(dX1, dB1, dK, m, [1], args.icmiter, args.npert, True, seed=42, out=o1)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    e1.encode_icm_dev(dX1, dB1, dK, m, [1], args.icmiter, args.npert, True, seed=42, out=o1)
+                torch.cuda.synchronize()
+                t_dev = (time.perf_counter() - t0) / 20
+            out["cfg1_gpu"] = {"host_buffers": {"value": n1 / t_host, "ms_per_call": t_host * 1e3, "table_reuses_of_23_calls": int(reuses)},
+                               "device_buffers": {"value": n1 / t_dev, "ms_per_call": t_dev * 1e3},
+                               "unit": "vectors/s per encoding_icm call (1 ILS iteration, %d sweeps), blocking" % args.icmiter,
+                               "note": "BASELINE configs[0] exactly (n = 10 000, d = 128, m = 8): the GPU counterpart of cpu_baseline.cfg1"}
         # north_star's own operating point: 4 ILS iterations
         ns_ils = 4
         step(ns_ils)

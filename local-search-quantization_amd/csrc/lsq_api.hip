@@ -604,7 +604,8 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t c
             // schedule 7: the slices of a node spread over the CUs of an XCD (lsq_icmx.hip).  Its start barrier may turn a launch away (another
             // process' kernels on the device: not all 256 blocks resident): the filtered walk behind it is predicated on that verdict.
 #ifdef LSQ_TUNING
-            const bool xs = c->schedule == 7 && c->xs_dev_ok && cn >= c->xs_min && lsq_icm_xs_applies(cn, m) && !c->per_node;
+            // (not with option "async": there the stand-in launch is predicated on the road word, not on the xs launch's verdict -- ADVICE r4)
+            const bool xs = c->schedule == 7 && c->xs_dev_ok && cn >= c->xs_min && lsq_icm_xs_applies(cn, m) && !c->per_node && !c->chunk_road_dev;
 #else
             const bool xs = false;
 #endif
@@ -702,7 +703,9 @@ static int encode_chunk(lsq_ctx *c, const float *dXc, const float *dK, int64_t c
         // iteration's first sweep, the launch being split there -- are read back; a filter that decides too little hands the REST to the f32 walk.
         // Nothing is remembered across calls (round 3 kept a per-shape verdict: it could not tell two data sets of one shape apart).
         const bool probing = it == 0 && c->chunk_q16 && c->probe_div > 0 && (I > 1 || P.icmiter > 1);
-        const int probe_sweeps = I > 1 ? P.icmiter : 1;
+        // a call of ONE iteration probes its first sweeps: two of them when there are at least three (after the first sweep of an iteration EVERY node of every
+        // vector has just been recomputed, which dilutes the hard / recomputed ratio the threshold was calibrated on -- ADVICE r4), else one
+        const int probe_sweeps = I > 1 ? P.icmiter : (P.icmiter >= 3 ? 2 : 1);
         if (probing) {
             LSQ_TRY(c->probe.ensure(sizeof(unsigned long long) * LSQ_WALK_COUNTERS));
             LSQ_HIP(hipMemsetAsync(c->probe.p, 0, sizeof(unsigned long long) * LSQ_WALK_COUNTERS, c->stream));
@@ -725,7 +728,7 @@ static int encode_chunk(lsq_ctx *c, const float *dXc, const float *dK, int64_t c
             LSQ_HIP(hipStreamSynchronize(c->stream));
             fold_walk_counters(c, act);
             const unsigned long long hard = act[4 + LSQ_WALK_TRACE] + act[4 + LSQ_WALK_TRACE + 2];
-            if ((long double)hard * (long double)c->probe_div > (long double)act[0]) {
+            if ((double)hard * (double)c->probe_div > (double)act[0]) {      // the same arithmetic as q16_probe_kernel (option "async")
                 c->chunk_q16 = false;
                 c->filter_fallback_chunks += 1;
             }

@@ -40,7 +40,9 @@ def _assign_scalar(c, x):
     """r = 1 (the norm codebook of train_lsq: n scalars, h centres): argmin_k (x - c_k)^2 evaluated in f32, lowest index on ties -- the result of the
     brute-force h x n scan, in O(n log h): the f32 distance is monotone in |x - c_k|, so the minimisers form a contiguous run of the SORTED centres
     around x; the run is found from the two neighbours of x and widened while the distance stays equal.  (The pairwise expansion of _sqdist
-    cancels catastrophically for scalars of the size of squared norms; this is also the better-conditioned formula.)"""
+    cancels catastrophically for scalars of the size of squared norms; this is also the better-conditioned formula.)
+    Behaviour note: EVERY width-1 k-means goes through here, i.e. also a PQ / OPQ sub-space of width 1 (d == m) -- its assignments are those of
+    (x - c)^2, which can differ from the expanded-distance scan of wider sub-spaces on near-ties; the reference (Clustering.jl) is unpinned either way."""
     c = np.asarray(c, dtype=np.float32).reshape(-1)
     x = np.asarray(x, dtype=np.float32).reshape(-1)
     h, n = c.shape[0], x.shape[0]

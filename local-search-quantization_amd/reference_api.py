@@ -216,7 +216,7 @@ def train_lsq_dev(dX, m, h, dB, niter, ilsiter, icmiter, randord, npert, *, seed
     """src/lsq/LSQ.jl:10-88 with everything resident in HBM: the same alternation as train_lsq -- LSQR codebook update (lsq_update_codebooks_dev),
     ILS/ICM encode (lsq_encode_icm_dev, seed + call index), objective -- on device tensors, no host copy of X, the codes or the codebooks between the
     steps.  dX (n, d) f32, dB (n, m) uint8 0-BASED: CUDA/HIP torch tensors (the layouts of Engine.encode_icm_dev); R (d, d) rotation or None (identity).
-    -> (dK (m*h, d) tensor, dB (n, m) uint8 tensor, cbnorms (<= h,) f32, B_norms (n,) int16 1-based, obj (niter,) f32).  Same codebooks, codes and
+    -> (dK (m*h, d) tensor, dB (n, m) uint8 tensor, cbnorms (<= h,) f32, B_norms (1, n) int16 1-based, obj (niter,) f32).  Same codebooks, codes and
     objective as train_lsq(..., engine=engine, device_update=True) on the same inputs (tests/test_pipeline_gpu.py).  torch is used for the two
     rotations only (RX = X R once; K R' once): glue, not the path."""
     import torch
@@ -246,7 +246,7 @@ def train_lsq_dev(dX, m, h, dB, niter, ilsiter, icmiter, randord, npert, *, seed
     _, _, nrm = engine.quantize_norms_dev(dB, dK, torch.zeros(1, dtype=torch.float32, device=dX.device), m, h=h)
     dbnorms = nrm.cpu().numpy()
     centers, assign, _ = kmeans(dbnorms.reshape(1, n), min(h, n), niter=100, seed=seed)
-    return dK, dB, centers.reshape(-1).astype(np.float32), (assign + 1).astype(np.int16), obj
+    return dK, dB, centers.reshape(-1).astype(np.float32), (assign + 1).reshape(1, n).astype(np.int16), obj      # B_norms 1 x n like train_lsq (LSQ.jl:84)
 
 
 def reconstruct(B, C):

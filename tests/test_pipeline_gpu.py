@@ -82,10 +82,38 @@ def test_train_lsq_dev_is_the_same_training_resident_in_hbm(lsq):
         assert np.array_equal(dK.cpu().numpy(), K)
         assert np.array_equal(dB.cpu().numpy().astype(np.int16) + 1, np.asarray(B).T)
         assert np.allclose(obj2, obj, rtol=1e-6) and obj2[-1] <= obj2[0]
-        assert np.array_equal(cb2, cb) and np.array_equal(Bn2, np.asarray(Bn).reshape(-1))
+        assert np.array_equal(cb2, cb) and np.array_equal(Bn2, np.asarray(Bn)) and Bn2.shape == (1, n)
         # with a rotation
         Q, _ = np.linalg.qr(np.random.default_rng(3).standard_normal((d, d)))
         R = Q.astype(np.float32)
         _, _, _, _, objr = lsq.train_lsq(X, m, H, R, B0, None, niter, ilsiter, icmiter, randord, npert, seed=5, engine=eng, device_update=True)
         _, _, _, _, objr2 = lsq.train_lsq_dev(dX, m, H, dB0, niter, ilsiter, icmiter, randord, npert, seed=5, engine=eng, R=R, norm_codebook=False)
         assert np.allclose(objr2, objr, rtol=2e-2) and objr2[-1] <= objr2[0] * 1.001
+
+
+def test_train_lsq_dev_against_the_independent_oracle_trainer(lsq, oracle):
+    """SURVEY 8(f)-4 under an INDEPENDENT check: oracle/train_oracle.py restates LSQ.jl:36-66's step order with the oracle's C encoder
+    and scipy's LSQR (f64); train_lsq_dev (device LSQR in f32 + the HIP encoder, everything resident in HBM) must follow the same objective trajectory.
+    The two differ only through the LSQR arithmetic (f32 vs f64, and WHERE each solver meets the reference's own stopping tolerance atol = btol =
+    sqrt(eps(Float32)) = 3.5e-4: IterativeSolvers' default, codebook_update.jl:13-24): codebooks that are only determined to a few 1e-4 send a few
+    near-tied node updates the other way, and the free-running trajectories drift apart at that scale -- measured 0 / 8e-4 / 5e-4 / 2e-3 relative over
+    four iterations.  The first objective (before any data-dependent divergence) must agree to 1e-6, the others to 5e-3, both must decrease
+    monotonically; the pieces themselves are pinned elsewhere (encoder: bit-exact vs the oracle; LSQR: 1e-3 vs scipy on identical inputs)."""
+    import torch
+    from oracle import train_oracle
+    d, m, n = 32, 4, 6000
+    X = clustered(d, n, k=300, seed=22)                               # (d, n)
+    Xr = np.ascontiguousarray(X.T)
+    B0 = lsq.randinit(n, m, H, seed=4)                                # (m, n) int16 1-based
+    niter, ilsiter, icmiter, randord, npert = 4, 2, 4, True, 2
+    Kref, Bref, objref = train_oracle.train_lsq(Xr, m, H, np.ascontiguousarray(B0.T), niter, ilsiter, icmiter, randord, npert, seed=7)
+    with lsq.Engine(0) as eng:
+        dX = torch.from_numpy(Xr).cuda()
+        dB0 = torch.from_numpy(np.ascontiguousarray((B0.T - 1).astype(np.uint8))).cuda()
+        dK, dB, _, _, obj = lsq.train_lsq_dev(dX, m, H, dB0, niter, ilsiter, icmiter, randord, npert, seed=7, engine=eng, norm_codebook=False)
+        K, B = dK.cpu().numpy(), dB.cpu().numpy().astype(np.int16) + 1
+    assert abs(obj[0] - objref[0]) <= 1e-6 * objref[0], (obj, objref)
+    assert np.allclose(obj, objref, rtol=5e-3, atol=0), (obj, objref)
+    assert np.all(np.diff(obj) < 0) and np.all(np.diff(objref) < 0)
+    # (after four free-running iterations the two codebook sets are different local solutions of the same quality: their codes are not interchangeable --
+    #  re-scoring one trainer's codes under the other's codebooks gives 11.5 against 3.3 -- so nothing is asserted about K or B beyond the objective)

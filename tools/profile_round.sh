@@ -13,6 +13,7 @@ R=$(pwd)
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+export LSQ_BENCH_TRAIN_CACHE=1      # --trained-codebooks: trained once per box and build, so that the profiled processes hold no training launches
 B="python $R/bench.py --no-cpu-baseline --no-extra-legs --no-sample-parity $*"
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o bench --output-format csv -- $B --steps 1 --warmup 1 > "$OUT/stats.log" 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/fetch" -o bench --output-format csv -- $B --steps 1 --warmup 0 > "$OUT/fetch.log" 2>&1

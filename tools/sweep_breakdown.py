@@ -70,12 +70,10 @@ def main():
         dX = eng.synth_data_u8_dev(1234, n, 128)
         dB0 = eng.randinit_dev(7, n, m)
         dK = eng.synth_codebooks_dev(4321, m, 128)
-        if "--trained-codebooks" in extra:      # the codebooks bench.py trained and cached on this box (bench.py: train_codebooks)
-            import tempfile
-            import numpy as np
-            import torch
-            z = np.load(os.path.join(tempfile.gettempdir(), "lsq_bench_trained_K_%d_%d_%d_%d_%d.npz" % (min(n, 100_000), 128, m, J, 4)))
-            dK = torch.from_numpy(z["K"]).to(dX.device)
+        if "--trained-codebooks" in extra:      # the codebooks bench.py trains (bench.py: train_codebooks)
+            ns = min(n, 100_000)      # the same training bench.py runs (train_codebooks): 0.1 s on the device, no file in between
+            with lsq.Engine(0) as e2:
+                dK, _, _, _, _ = lsq.train_lsq_dev(dX[:ns].contiguous(), m, 256, dB0[:ns].contiguous(), 8, 4, J, True, 4, seed=42, engine=e2, norm_codebook=False)
         eng.reset_timings()
         eng.encode_icm_dev(dX, dB0, dK, m, [ils], J, 4, True, seed=42)
         res["node_updates_total"] = eng.timings()["icm_node_updates"]
