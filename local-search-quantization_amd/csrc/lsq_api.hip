@@ -52,6 +52,9 @@ struct lsq_ctx {
     int64_t q16_min = 65536; // schedule 6: smaller chunks take schedule 4 (every block is light there: nothing to filter)
     int tables_changed = 1;  // schedule 6: the pair tables were rebuilt since the last lsq_launch_q16_prepare
     int new_call = 1;        // schedule 6: no chunk of this call has reset the level parameters' counters yet
+    int fuse_cost = 0;       // option "fuse_cost" (tuning build only; measured, not adopted): the filtered walk's launch that ends an ILS iteration also judges its
+                             // vectors (cost + accept + next perturbation as the closing phase of every block: lsq_cost_phase) -- one launch per iteration instead of two
+    int64_t fused_cost_launches = 0;
     // Host-buffer entry points called again with the SAME codebooks (the trainer's chained encoding_icm, demos/demo_lsq.jl:48-51 / LSQ.jl:54-57 -- the
     // reference rebuilds its binaries in every call, encode_icm.jl:145, with identical results): the uploaded K, ||c||^2, the pair tables and what the
     // filtered walk derives from them are still in this context -- one memcmp of the caller's K against a host copy decides
@@ -225,6 +228,9 @@ extern "C" int lsq_set_option(lsq_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "xs_min")) c->xs_min = value;
     else if (!strcmp(key, "async")) c->async_mode = value != 0;
     else if (!strcmp(key, "per_node")) c->per_node = value != 0;
+#ifdef LSQ_TUNING
+    else if (!strcmp(key, "fuse_cost")) c->fuse_cost = value != 0;
+#endif
     else if (!strcmp(key, "upload_panel_bytes")) {
         if (value < 1) { lsq_set_error("upload_panel_bytes must be >= 1"); return LSQ_EINVAL; }
         c->panel_bytes = value;
@@ -587,8 +593,11 @@ static int build_unaries_from_host(lsq_ctx *c, const float *Xh, float *dXc, cons
 
 // ref_rec / ref_valid: the vectors' current records and validity masks (read-only during the sweeps), or nullptr
 // first_sweep: position of the first of the nsweeps sweeps inside its ILS iteration (the per-position trace counters only)
+// cost (optional): the closing phase of the LAST launch -- honoured on the filtered walk's host-decided road only (*cost_done tells the caller)
 static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t cn, int m, const int32_t *order, int nsweeps,
-                      const uint8_t *ref_rec = nullptr, const unsigned short *ref_valid = nullptr, int first_sweep = 0) {
+                      const uint8_t *ref_rec = nullptr, const unsigned short *ref_valid = nullptr, int first_sweep = 0,
+                      const lsq_cost_phase *cost = nullptr, bool *cost_done = nullptr) {
+    if (cost_done) *cost_done = false;
     if (nsweeps <= 0) return LSQ_OK;
     const int pos_base = first_sweep * m;
     Timer t(c, CAT_ICM);
@@ -621,9 +630,13 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t c
 #endif
                 if (xs) c->xs_launches += 1;
                 if (c->chunk_road_dev) gate = c->road.as<unsigned>();      // option "async": runs iff road[0] == 2
+                const bool last = done + per_launch >= seq.size();
+                const bool fuse = cost && last && !xs && !c->chunk_road_dev && !c->per_node;
                 LSQ_TRY(lsq_launch_icm_walkq(c->stream, c->U.as<float>(), c->Uq.as<uint16_t>(), c->Tq.as<uint16_t>(), c->T.as<float>(), rec, valid, cn, m,
                                              seq.data() + done, cntn, pos_base + (int)done, c->skip, c->walk_counters, c->light,
-                                             c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr, P, c->qflag.as<unsigned short>(), gate));
+                                             c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr, P, c->qflag.as<unsigned short>(), gate,
+                                             fuse ? cost : nullptr));
+                if (fuse) { if (cost_done) *cost_done = true; c->fused_cost_launches += 1; }
             }
             c->icm_launches += ((int64_t)seq.size() + (int64_t)per_launch - 1) / (int64_t)per_launch;
             if (c->chunk_road_dev) {      // ... and the f32 walk behind it idles on the same word (road[0] != 0) or does the work (road[0] == 0)
@@ -711,7 +724,16 @@ static int encode_chunk(lsq_ctx *c, const float *dXc, const float *dK, int64_t c
             LSQ_HIP(hipMemsetAsync(c->probe.p, 0, sizeof(unsigned long long) * LSQ_WALK_COUNTERS, c->stream));
             c->walk_counters = c->probe.as<unsigned long long>();
         }
-        LSQ_TRY(run_sweeps(c, nw, vnew, cn, P.m, order, probing ? probe_sweeps : P.icmiter, cur, vcur));
+        // the cost + accept + perturbation of this iteration as the closing phase of its last walk launch (filtered road, d a multiple of 4, aligned)
+        lsq_cost_phase cph = {};
+        cph.on = 1; cph.d = P.d; cph.X = dXc; cph.K = dK; cph.cur = cur; cph.prev = prev; cph.counters = counters + 2 * it; cph.vcur = vcur;
+        cph.pn = pn;
+        cph.pn.it = P.it0 + (uint32_t)it + 1u;
+        cph.pn.on = it + 1 < I ? 1 : 0;
+        const bool may_fuse = c->fuse_cost && c->schedule == 6 && P.d % 4 == 0 && (((uintptr_t)dXc | (uintptr_t)dK) % 16) == 0 && (int64_t)P.m * LSQ_H * P.d < (1ll << 31);
+        bool cost_done = false;
+        const bool whole = !probing || probe_sweeps == P.icmiter;       // this run_sweeps call holds the iteration's last node update
+        LSQ_TRY(run_sweeps(c, nw, vnew, cn, P.m, order, probing ? probe_sweeps : P.icmiter, cur, vcur, 0, (may_fuse && whole && !probing) ? &cph : nullptr, &cost_done));
         if (probing && c->chunk_road_dev) {
             // option "async": the same probe by a one-thread kernel (it also adds the probed launches' statistics to the call's)
             c->walk_counters = c->active.as<unsigned long long>();
@@ -732,9 +754,9 @@ static int encode_chunk(lsq_ctx *c, const float *dXc, const float *dK, int64_t c
                 c->chunk_q16 = false;
                 c->filter_fallback_chunks += 1;
             }
-            LSQ_TRY(run_sweeps(c, nw, vnew, cn, P.m, order, P.icmiter - probe_sweeps, cur, vcur, probe_sweeps));      // the rest of a single-iteration call
+            LSQ_TRY(run_sweeps(c, nw, vnew, cn, P.m, order, P.icmiter - probe_sweeps, cur, vcur, probe_sweeps, may_fuse ? &cph : nullptr, &cost_done));      // the rest of a single-iteration call
         }
-        {
+        if (!cost_done) {
             Timer t(c, CAT_COST);
             pn.it = P.it0 + (uint32_t)it + 1u;
             LSQ_TRY(lsq_launch_cost(c->stream, dXc, dK, nw, cur, prev, counters + 2 * it, cn, P.d, P.m, 1, vnew, vcur, it + 1 < I ? &pn : nullptr));

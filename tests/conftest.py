@@ -40,6 +40,8 @@ ENCODE_VARIANTS = [
     _variant("s4", schedule=4),
     _variant("s3", schedule=3),
     _variant("xs7", marks=[pytest.mark.tuning], schedule=7, tuning=1, q16_min=0, xs_min=0, filter_probe_div=0, filter_fallback_div=0),
+    # round 5's fused launch (cost + accept + perturbation as the closing phase of the walk kernel's blocks): bit-exact, measured slower, tuning build only
+    _variant("fused", marks=[pytest.mark.tuning], schedule=6, tuning=1, q16_min=0, light=0, filter_probe_div=0, filter_fallback_div=0, fuse_cost=1),
 ]
 
 
