@@ -48,8 +48,25 @@ __global__ void ref_kernel(Args g, int64_t rows) {
 }
 
 // ---- epilogue shared by the variants: acc[2][2] of a wave's 64 x 64 sub-tile -> f32 stores + u16 levels through an LDS tile ----------------
-template <int QLD, int EPF = 3>      // EPF bit 0: f32 stores, bit 1: u16 levels
-__device__ inline void epilogue(const Args &g, const f32x16 (&acc)[2][2], int64_t row0, int col0, int wy, int wx, int l31, int lhi, uint16_t *qtile, int tid) {
+template <int CTRL>
+__device__ inline float dppf(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); }
+// 4 x 4 transpose of r[0..3] across the four lanes of a quad: afterwards lane i of the quad holds, in r[0..3], what lanes 0..3 held in r[i]
+__device__ inline void quad_transpose(float (&r)[4], int lane) {
+    const bool o1 = lane & 1, o2 = lane & 2;
+    {   // exchange across lane ^ 1 (quad_perm [1,0,3,2] = 0xB1).  The DPP reads happen with ALL lanes active (a select inside a branch would read inactive lanes)
+        const float x0 = dppf<0xB1>(r[0]), x1 = dppf<0xB1>(r[1]), x2 = dppf<0xB1>(r[2]), x3 = dppf<0xB1>(r[3]);
+        const float a = o1 ? x1 : r[0], b = o1 ? r[1] : x0, c = o1 ? x3 : r[2], d = o1 ? r[3] : x2;
+        r[0] = a; r[1] = b; r[2] = c; r[3] = d;
+    }
+    {   // exchange across lane ^ 2 (quad_perm [2,3,0,1] = 0x4E)
+        const float x0 = dppf<0x4E>(r[0]), x1 = dppf<0x4E>(r[1]), x2 = dppf<0x4E>(r[2]), x3 = dppf<0x4E>(r[3]);
+        const float a = o2 ? x2 : r[0], c = o2 ? r[2] : x0, b = o2 ? x3 : r[1], d = o2 ? r[3] : x1;
+        r[0] = a; r[1] = b; r[2] = c; r[3] = d;
+    }
+}
+
+template <int QLD, int EPF = 3>      // EPF bit 0: f32 stores, bit 1: u16 levels, bit 2: f32 stores as 16-byte stores after a quad transpose, bit 3: the library's level arithmetic (row shift from LDS, column shift, range flag)
+__device__ inline void epilogue(const Args &g, const f32x16 (&acc)[2][2], int64_t row0, int col0, int wy, int wx, int l31, int lhi, uint16_t *qtile, int tid, const float *sgs = nullptr, unsigned *flagw = nullptr) {
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj) {
         const int c = col0 + wx * 64 + tj * 32 + l31;
@@ -57,6 +74,21 @@ __device__ inline void epilogue(const Args &g, const f32x16 (&acc)[2][2], int64_
         const int64_t lrow = row0 + wy * 64 + 4 * lhi;
         float *__restrict__ Dl = g.D + d_off(g.M, lrow, c);
         uint16_t *__restrict__ ql = qtile + (wy * 64 + 4 * lhi) * QLD + wx * 64 + tj * 32 + l31;
+        if (EPF & 4) {
+            // lane (column c, rows ro .. ro + 3)  ->  lane (row ro + (lane & 3), columns 4 (l31 >> 2) .. + 3): one 16-byte store per group of four rows
+            const int cq = col0 + wx * 64 + tj * 32 + (l31 & ~3);
+            float *__restrict__ Dq4 = g.D + d_off(g.M, lrow + (l31 & 3), cq);
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    float r4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r4[e] = acc[ti][tj][4 * gq + e] + add;
+                    quad_transpose(r4, l31);
+                    *reinterpret_cast<f32x4 *>(Dq4 + (int64_t)(ti * 32 + 8 * gq) * SL) = (f32x4){r4[0], r4[1], r4[2], r4[3]};
+                }
+        }
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
@@ -64,7 +96,13 @@ __device__ inline void epilogue(const Args &g, const f32x16 (&acc)[2][2], int64_
                 const int ro = ti * 32 + (r & 3) + 8 * (r >> 2);
                 const float v = acc[ti][tj][r] + add;
                 if (EPF & 1) Dl[(int64_t)ro * SL] = v;
-                if (EPF & 2) {
+                if ((EPF & 2) && (EPF & 8)) {
+                    const float sg = sgs[wy * 64 + 4 * lhi + ro];
+                    const float qf = rintf(((v + add * 1e-3f) - sg) * g.inv);
+                    const float qc = __builtin_amdgcn_fmed3f(qf, 0.f, 65535.f);
+                    if (!(qf == qc)) atomicOr(flagw + ((row0 + ro) >> 1), 1u);
+                    ql[ro * QLD] = (uint16_t)(unsigned)qc;
+                } else if (EPF & 2) {
                     const float qf = rintf((v - g.lo) * g.inv);
                     ql[ro * QLD] = (uint16_t)(unsigned)__builtin_amdgcn_fmed3f(qf, 0.f, 65535.f);
                 } else if (!(EPF & 1) && v == 12345.678f) ql[0] = 1;
@@ -166,7 +204,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if (sacc == 12345.678f) g.D[tid] = sacc;
         return;
     }
-    if (NOEPI == 3) epilogue<BN + 8, 1>(g, acc, row0, col0, wy, wx, l31, lhi, reinterpret_cast<uint16_t *>(smem), tid);
+    if (NOEPI == 7 || NOEPI == 8) {
+        __shared__ float sgs[BM];
+        if (tid < BM) sgs[tid] = g.lo + 1e-3f * (float)((row0 + tid) & 15);
+        __syncthreads();
+        if (NOEPI == 7) epilogue<BN + 8, 11>(g, acc, row0, col0, wy, wx, l31, lhi, reinterpret_cast<uint16_t *>(smem), tid, sgs, reinterpret_cast<unsigned *>(g.Dq));
+        else epilogue<BN + 8, 14>(g, acc, row0, col0, wy, wx, l31, lhi, reinterpret_cast<uint16_t *>(smem), tid, sgs, reinterpret_cast<unsigned *>(g.Dq));
+        return;
+    }
+    if (NOEPI == 5) epilogue<BN + 8, 6>(g, acc, row0, col0, wy, wx, l31, lhi, reinterpret_cast<uint16_t *>(smem), tid);
+    else if (NOEPI == 6) epilogue<BN + 8, 4>(g, acc, row0, col0, wy, wx, l31, lhi, reinterpret_cast<uint16_t *>(smem), tid);
+    else if (NOEPI == 3) epilogue<BN + 8, 1>(g, acc, row0, col0, wy, wx, l31, lhi, reinterpret_cast<uint16_t *>(smem), tid);
     else if (NOEPI == 4) epilogue<BN + 8, 2>(g, acc, row0, col0, wy, wx, l31, lhi, reinterpret_cast<uint16_t *>(smem), tid);
     else epilogue<BN + 8>(g, acc, NOEPI == 2 ? (row0 & 1023) & ~127ll : row0, col0, wy, wx, l31, lhi, reinterpret_cast<uint16_t *>(smem), tid);
 }
@@ -438,7 +486,7 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(A, hA.data(), sizeof(float) * Mr * Kd, hipMemcpyHostToDevice));
     CK(hipMemcpy(B, hB.data(), sizeof(float) * N * Kd, hipMemcpyHostToDevice));
     CK(hipMemcpy(sci, hs.data(), sizeof(float) * N, hipMemcpyHostToDevice));
-    g.A = A; g.B = B; g.sci = sci; g.D = D; g.Dq = Dq; g.M = Mr; g.N = N; g.Kd = Kd; g.lo = -6.0e5f; g.inv = 65535.f / 1.2e6f;
+    g.A = A; g.B = B; g.sci = sci; g.D = D; g.Dq = Dq; g.M = Mr; g.N = N; g.Kd = Kd; g.lo = -1.3e6f; g.inv = 65535.f / 2.8e6f;      // every value inside the level range: the flag branch of the library-like leg is never taken
     g.row_tiles = Mr / BM; g.col_tiles = N / BN;
     // reference for the first rows_ref rows of a SEPARATE output with the same M (offsets depend on M)
     CK(hipMalloc(&Dref, sizeof(float) * Mr * N)); CK(hipMalloc(&Dqref, sizeof(uint16_t) * Mr * N));
@@ -470,6 +518,10 @@ int main(int argc, char **argv) {
     RUN("v0 BK16 unrolled, stores into 1024 rows (L2)", (v0_kernel<16, 1, 2><<<grid0, 256>>>(g)));
     RUN("v0 BK16 unrolled, f32 stores only", (v0_kernel<16, 1, 3><<<grid0, 256>>>(g)));
     RUN("v0 BK16 unrolled, u16 levels only", (v0_kernel<16, 1, 4><<<grid0, 256>>>(g)));
+    RUN("v0 BK16 unrolled, f32 as 16-B stores after quad transpose + u16", (v0_kernel<16, 1, 5><<<grid0, 256>>>(g))); check("v0 transposed stores");
+    RUN("v0 BK16 unrolled, f32 as 16-B stores only", (v0_kernel<16, 1, 6><<<grid0, 256>>>(g)));
+    RUN("v0 BK16 unrolled, library-like level arithmetic, dword stores", (v0_kernel<16, 1, 7><<<grid0, 256>>>(g)));
+    RUN("v0 BK16 unrolled, library-like level arithmetic, wide stores", (v0_kernel<16, 1, 8><<<grid0, 256>>>(g)));
     RUN("v0 BK16 unrolled, K loop only", (v0_kernel<16, 1, 1><<<grid0, 256>>>(g)));
     RUN("v0 BK32 unrolled", (v0_kernel<32, 1, 0><<<grid0, 256>>>(g))); check("v0 bk32");
 #define V1(BPC, BKK) { char nm[80]; snprintf(nm, sizeof nm, "v1 persistent kperm BK%d, %d blocks/CU", BKK, BPC); \
