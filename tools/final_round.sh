@@ -34,5 +34,17 @@ cp "$(find "$O/linscan_stats" -name '*kernel_stats.csv' | head -1)" "$O/${TAG}_l
 # the codebook update on the device: host LSQR vs device LSQR on three shapes
 { python tools/lsqr_bench.py 100000 128 8; python tools/lsqr_bench.py 1000000 128 8; python tools/lsqr_bench.py 100000 960 8; } > "$O/${TAG}_lsqr.jsonl" 2> "$O/lsqr.err"
 [ -x tools/bin/ubench_lds ] && tools/bin/ubench_lds > "$O/ubench_lds_${TAG}.txt" 2>&1
+# round 5's micro-benchmarks: bare LDS read rates (the guide's figures reproduced), the cost pass's memory traffic replayed + the energy-identity filter's
+# scattered reads, the unary GEMM's structure variants, HBM write patterns, H2D rates; the host-buffer entry point with / without the upload pipeline
+[ -x tools/bin/ubench_lds2 ] && tools/bin/ubench_lds2 > "$O/${TAG}_ubench_lds2.txt" 2>&1
+[ -x tools/bin/ubench_cost ] && { tools/bin/ubench_cost 1000000 128; tools/bin/ubench_cost 125000 960; } > "$O/${TAG}_ubench_cost.txt" 2>&1
+[ -x tools/bin/ubench_gemm ] && tools/bin/ubench_gemm 1000064 128 > "$O/${TAG}_ubench_gemm.txt" 2>&1
+[ -x tools/bin/ubench_write ] && tools/bin/ubench_write > "$O/${TAG}_ubench_write.txt" 2>&1
+[ -x tools/bin/ubench_h2d ] && tools/bin/ubench_h2d > "$O/${TAG}_ubench_h2d.txt" 2>&1
+{ python tools/e2e_probe.py 1000000 128; python tools/e2e_probe.py 125000 960; } 2>&1 | grep -v amdgpu.ids > "$O/${TAG}_end_to_end_probe.txt"
+python tools/small_call.py 2>&1 | grep -v amdgpu.ids > "$O/${TAG}_small_call.txt"
+R2=$(pwd); ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace -d "$O/timeline" -o bench --output-format csv -- python "$R2/bench.py" --no-cpu-baseline --no-extra-legs --no-sample-parity --steps 1 --warmup 1 > "$O/timeline.log" 2>&1 )
+F=$(find "$O/timeline" -name '*kernel_trace.csv' | head -1)
+[ -n "$F" ] && { N=$(python -c "import csv;print(len(list(csv.DictReader(open('$F')))))"); python tools/trace_timeline.py "$F" $((N-75)) 75 > "$O/${TAG}_timeline_one_step.txt"; python tools/trace_gaps.py "$F" > "$O/${TAG}_trace_gaps.txt"; }
 find "$O" -name "*.csv" -size +4M -delete
 ls -la "$O"
