@@ -209,3 +209,22 @@ def test_bad_arguments(oracle):
         oracle.encode_icm(X, B0, K, 2, H, [0], 1, 1, True, 1)
     Bs, objs = oracle.encode_icm(X[:0], B0[:0], K, 2, H, [1], 1, 1, True, 1)   # empty input
     assert Bs.shape == (1, 0, 2)
+
+
+def test_oracle_side_trainer_follows_the_reference_step_order(oracle):
+    """oracle/train_oracle.py (the independent checker of SURVEY 8(f)-4, LSQ.jl:36-66): update -> ilsiter x encode -> qerror; the objective it records is
+    the qerror of the codes the previous encode returned, and alternating minimisation must not increase it; unused codewords stay at LSQR's minimum-norm 0."""
+    from oracle import train_oracle
+    rng = np.random.default_rng(4)
+    n, d, m, h = 1500, 12, 3, 256
+    cen = rng.standard_normal((40, d)).astype(np.float32) * 3
+    X = (cen[rng.integers(40, size=n)] + 0.3 * rng.standard_normal((n, d))).astype(np.float32)
+    B0 = oracle.randinit(5, n, m, h)
+    K, B, obj = train_oracle.train_lsq(X, m, h, B0, 3, 2, 3, True, 2, seed=9)
+    assert obj.shape == (3,) and np.all(np.diff(obj) <= 1e-6 * obj[:-1])
+    assert abs(oracle.qerror(X, B, K, m, h) - obj[-1]) <= obj[-1]          # same scale (one more update + encode after obj[-1])
+    S = train_oracle.sparsify_codes(B0, h)
+    assert S.shape == (n, m * h) and np.all(np.asarray(S.sum(1)).ravel() == m)
+    K0 = train_oracle.update_codebooks(X, B0, h)
+    used = np.asarray(S.sum(0)).ravel() > 0
+    assert np.all(K0[~used] == 0)
