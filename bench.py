@@ -17,7 +17,7 @@ of the 1 MiB codebook matrix from rank 0, inside the timed step).
 Other BASELINE configs through flags (same JSON line, `config.workload` names what ran):
     cfg3  --codebooks 16
     cfg4  --scaling strong --total 1000000 --dim 960     (GIST-shaped; `splitarray` shards: 125 000 vectors per GPU at N = 8)
-    cfg5  --vectors 12500000                              (weak scaling, 12.5 M vectors per GPU generated on the device, 12 resident chunks)
+    cfg5  --vectors 12500000                              (weak scaling, 12.5 M vectors per GPU generated on the device, 13 resident chunks)
 
 Prints ONE JSON line on rank 0 with the driver's contract fields plus
   `roofline`         dominant kernel (the ICM node update): algorithmic HBM bytes / HIP-event launch time vs 8 TB/s, the LDS-side

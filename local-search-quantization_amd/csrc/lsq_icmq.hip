@@ -315,7 +315,7 @@ template <int M, int SLQ, int NT>
 __device__ inline int q16_refine(const float *__restrict__ U, const uint16_t *__restrict__ Uq, const uint16_t *__restrict__ Tq,
                                  const float *__restrict__ T, uint8_t *__restrict__ rec, unsigned short *__restrict__ valid,
                                  const uint8_t *__restrict__ ref_rec, const unsigned short *__restrict__ ref_valid, int64_t n, int j,
-                                 int64_t lo, const unsigned short *list, const uint32_t *arec, int namb, int SLF, int abl) {
+                                 int64_t lo, const unsigned short *list, const uint32_t *arec, int namb, int SLF, int abl, unsigned short *vmir) {
     constexpr int CS = (M <= 8) ? 8 : 16;
     constexpr int RW = CS / 4;
     constexpr int AREC = 2 + RW;
@@ -428,6 +428,7 @@ __device__ inline int q16_refine(const float *__restrict__ U, const uint16_t *__
                     if (same) vm = (unsigned short)(vm | rv);
                 }
                 valid[i] = vm;
+                if (vmir) vmir[i - lo] = vm;
             }
         }
     }
@@ -496,6 +497,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
     uint32_t *bestA = reinterpret_cast<uint32_t *>(lds_walkq + LTAB);                           // [PP] smallest key (Q << 16 | candidate)
     uint32_t *bestB = bestA + PP;                                                              // [PP] second smallest key
     unsigned short *list = reinterpret_cast<unsigned short *>(bestB + PP);                     // [PP] active local indices
+    constexpr bool MIRROR = TL::mirror(M, BPC);
+    unsigned short *vmir = (MIRROR && valid) ? list + PP : nullptr;                              // [PP] mirror of valid[lo ..): read by the compaction, written with every store to valid[]
     __shared__ int wave_tot[16];
     __shared__ int nact_s;
     __shared__ int redo_s;
@@ -711,7 +714,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
                 on[e] = r < count;
                 vi[e] = lo_cur + __builtin_amdgcn_readfirstlane((int)pick(on[e] ? r : r0));
             }
-            light_update<M, CS, LB>(rec, valid, ref_rec, ref_valid, Usj, Tj, n, SLF, j, vi, on, lane);
+            light_update<M, CS, LB>(rec, valid, ref_rec, ref_valid, Usj, Tj, n, SLF, j, vi, on, lane, vmir, lo_cur);
         }
     };
 
@@ -721,6 +724,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
         const int64_t hi = (lo + per_pass < n) ? lo + per_pass : n;
         const int cnt = (int)(hi - lo);
         lo_cur = lo;
+        if (vmir) {
+            __syncthreads();                                   // (a previous pass' readers are done)
+            for (int idx = (int)threadIdx.x; idx < cnt; idx += NT) vmir[idx] = valid[lo + idx];
+            __syncthreads();
+        }
         for (int nu = 0; nu < nodes.count; ++nu) {
             const int j = nodes.j[nu];
 #ifdef LSQ_TUNING
@@ -733,7 +741,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
                 for (int e = 0; e < EPT; ++e) {
                     const int idx = base + e;
                     f[e] = 0;
-                    if (idx < cnt) f[e] = (!use_skip) || !((valid[lo + idx] >> j) & 1);
+                    if (idx < cnt) f[e] = (!use_skip) || !(((vmir ? vmir[idx] : valid[lo + idx]) >> j) & 1);
                     c += f[e];
                 }
                 int inc = c;
@@ -864,6 +872,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
                                 if (same) vm = (unsigned short)(vm | rv[e]);
                             }
                             valid[vi[e]] = vm;
+                            if (vmir) vmir[vi[e] - lo] = vm;
                         }
                     }
                     bool tof32 = vf32[e];
@@ -883,7 +892,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
             DBG_STAMP(12);
             // ---- exact refinement of the ambiguous vectors
             const int namb = redo_s < ACAP ? redo_s : ACAP;
-            int nexact = q16_refine<M, SLQ, NT>(U, Uq, Tq, T, rec, valid, ref_rec, ref_valid, n, j, lo, list, bestB, namb, SLF, abl);
+            int nexact = q16_refine<M, SLQ, NT>(U, Uq, Tq, T, rec, valid, ref_rec, ref_valid, n, j, lo, list, bestB, namb, SLF, abl, vmir);
             {   // vectors outside the sampled level range: one wave each, in full f32
                 const unsigned short *f32l = reinterpret_cast<const unsigned short *>(bestA);
                 const int nf32 = f32_s;
@@ -1047,7 +1056,7 @@ static int launch_walkq_t(hipStream_t s, const float *U, const uint16_t *Uq, con
                           const uint8_t *ref_rec, const unsigned short *ref_valid, const lsq_q16_params *P, const unsigned short *qflag, const unsigned *gate,
                           const lsq_cost_phase &cp) {
     constexpr int PP = WalkqTab<SLQ, CPL>::pp(M, BPC);
-    constexpr int LDS_BYTES = WalkqTab<SLQ, CPL>::lds_entries(M) * 16 + PP * 8 + PP * 2;      // slice table (planes, skew) + two smallest keys + active list
+    constexpr int LDS_BYTES = WalkqTab<SLQ, CPL>::lds_entries(M) * 16 + PP * 8 + PP * 2 + (WalkqTab<SLQ, CPL>::mirror(M, BPC) ? PP * 2 : 0);      // slice table (planes, skew) + two smallest keys + active list (+ validity mirror)
     static_assert((LDS_BYTES + 768) * BPC <= 160 * 1024, "slice table + keys must fit the block's share of the 160 KiB LDS");
     constexpr int NBLK = 256 * BPC;
     const int64_t rounds = (n + NBLK * (int64_t)PP - 1) / (NBLK * (int64_t)PP);      // passes per block

@@ -58,11 +58,16 @@ struct WalkqTab {
     __device__ static constexpr int entry(int kk, int code, int c) { return kk * TS_E + (c / LPV) * PLANE_E + code * LPV + (c % LPV); }
     static constexpr int lds_entries(int m) { return (m - 1) * TS_E; }
     // vectors per block pass with BPC blocks per CU: the slice table + 10 B per vector within the block's share of the 160 KiB
-    static constexpr int pp(int m, int bpc) {
+    static constexpr int pp_for(int m, int bpc, int bytes_per_vector) {
         const int avail = 160 * 1024 / bpc - 768 - lds_entries(m) * 16;
-        const int v = avail / 10 / 64 * 64;
+        const int v = avail / bytes_per_vector / 64 * 64;
         return v > 4096 / bpc ? 4096 / bpc : v;
     }
+    // Round 5: the block keeps a MIRROR of its vectors' validity words in LDS (2 more bytes per vector) so that the compaction at the head of every node
+    // update reads LDS instead of waiting for L2 -- where that costs at most 1/64 of the vectors per pass (m = 8: 4032 instead of 4096; m = 16 would drop
+    // from 3968 to 3328 and need a second pass per 10^6-vector chunk: no mirror there)
+    static constexpr bool mirror(int m, int bpc) { return pp_for(m, bpc, 12) * 64 >= pp_for(m, bpc, 10) * 63; }
+    static constexpr int pp(int m, int bpc) { return mirror(m, bpc) ? pp_for(m, bpc, 12) : pp_for(m, bpc, 10); }
 };
 
 

@@ -205,7 +205,8 @@ __device__ inline void apply_node_results(uint8_t *__restrict__ rec, unsigned sh
 template <int M, int CS, int LB>
 __device__ inline void light_update(uint8_t *__restrict__ rec, unsigned short *__restrict__ valid, const uint8_t *__restrict__ ref_rec,
                                     const unsigned short *__restrict__ ref_valid, const float *__restrict__ Usj, const float *__restrict__ Tj,
-                                    int64_t n, int SL, int j, const int64_t (&vi)[LB], const bool (&on)[LB], int lane) {
+                                    int64_t n, int SL, int j, const int64_t (&vi)[LB], const bool (&on)[LB], int lane,
+                                    unsigned short *vmir = nullptr, int64_t vmir_lo = 0) {      // vmir: the block's LDS mirror of valid[vmir_lo ..) (filtered walk), kept in step
     constexpr int RW = CS / 4;
     const int LPV = SL / 4;
     const bool have_ref = ref_rec && ref_valid;
@@ -258,6 +259,7 @@ __device__ inline void light_update(uint8_t *__restrict__ rec, unsigned short *_
                         if (mine.lo == rr[e].lo && (RW == 2 || mine.hi == rr[e].hi)) vm = (unsigned short)(vm | rv[e]);      // known_valid()
                     }
                     valid[vi[e]] = vm;
+                    if (vmir) vmir[vi[e] - vmir_lo] = vm;
                 }
             }
         }
