@@ -295,6 +295,9 @@ LSQ_API int lsq_quantize_norms_dev(lsq_ctx *ctx, const uint8_t *d_codes, const f
  * reference neither vendors nor pins IterativeSolvers).  X d x n, B m x n Int16 1-based; K_out d x (m*h)
  * = hcat(C...) caller-allocated.  nthreads 0 = all cores (dimensions are independent). */
 LSQ_API int lsq_update_codebooks(const float *X, const int16_t *B, int d, int64_t n, int m, int h, int nthreads, float *K_out);
+/* The reference's other solver, codebook_upd_method = "lsmr" (src/codebook_update.jl:18-21 -> IterativeSolvers.lsmr): LSMR of Fong & Saunders with the same
+ * operator, tolerances and threading as lsq_update_codebooks (host code; since v500). */
+LSQ_API int lsq_update_codebooks_lsmr(const float *X, const int16_t *B, int d, int64_t n, int m, int h, int nthreads, float *K_out);
 
 /* The same update ON THE DEVICE (csrc/lsq_lsqr.hip): all d systems advanced together, the same LSQR restatement (Float32 recurrences, the long sums
  * in double, IterativeSolvers' default stopping rules), the rows sorted by code once per call so that S'u is added in the host's order without atomics.

@@ -84,6 +84,7 @@ SIGNATURES = {
     "lsq_quantize_norms": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _i, _i, _vp, _vp, _vp]),
     "lsq_quantize_norms_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _i, _i, _vp, _vp, _vp]),
     "lsq_update_codebooks": (_i, [_vp, _vp, _i, _i64, _i, _i, _i, _vp]),
+    "lsq_update_codebooks_lsmr": (_i, [_vp, _vp, _i, _i64, _i, _i, _i, _vp]),
     "lsq_update_codebooks_gpu": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _vp, C.POINTER(_i)]),
     "lsq_update_codebooks_dev": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _vp, C.POINTER(_i)]),
     "lsq_synth_data_u8_dev": (_i, [_vp, _u64, _u64, _i64, _i, _vp]),

@@ -155,12 +155,14 @@ def eval_recall(ids_gnd, ids_predicted, k, V=False):
 
 
 def update_codebooks(X, B, h, V=False, codebook_upd_method="lsqr", *, nthreads=0, engine=None):
-    """src/codebook_update.jl:52-86 -> list of m (d, h) codebooks minimising ||X - sum_j C_j[:, B_j]||^2 (LSQR).
+    """src/codebook_update.jl:52-86 -> list of m (d, h) codebooks minimising ||X - sum_j C_j[:, B_j]||^2 (LSQR, or LSMR with codebook_upd_method="lsmr": host only).
     engine=None: the host solver (std::thread workers over the dimensions, the reference's own division of labour);
     engine=<Engine>: the device solver (lsq_update_codebooks_gpu: all dimensions at once) -- the same result on every tested problem (required: 1e-5)."""
     from . import _lib
-    if codebook_upd_method != "lsqr":
-        raise ValueError("only the reference's default method 'lsqr' is provided")
+    if codebook_upd_method not in ("lsqr", "lsmr"):
+        raise ValueError("Codebook update method unknown: %r" % (codebook_upd_method,))      # codebook_update.jl:22-23,60
+    if codebook_upd_method == "lsmr" and engine is not None:
+        raise ValueError("the device solver is LSQR (the reference's default); 'lsmr' runs on the host: pass engine=None")
     Xr, Br = _X_of(X), _B_of(B)
     n, d = Xr.shape
     m = Br.shape[1]
@@ -168,7 +170,8 @@ def update_codebooks(X, B, h, V=False, codebook_upd_method="lsqr", *, nthreads=0
         K, _ = engine.update_codebooks(Xr, Br, m, h=h)
         return [np.ascontiguousarray(K[j * h:(j + 1) * h].T) for j in range(m)]
     K = np.zeros((m * h, d), dtype=np.float32)
-    _lib.check(_lib.load().lsq_update_codebooks(Xr.ctypes.data, Br.ctypes.data, d, n, m, h, int(nthreads), K.ctypes.data))
+    fn = _lib.load().lsq_update_codebooks_lsmr if codebook_upd_method == "lsmr" else _lib.load().lsq_update_codebooks
+    _lib.check(fn(Xr.ctypes.data, Br.ctypes.data, d, n, m, h, int(nthreads), K.ctypes.data))
     return [np.ascontiguousarray(K[j * h:(j + 1) * h].T) for j in range(m)]
 
 

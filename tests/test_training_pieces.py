@@ -67,7 +67,7 @@ def test_update_codebooks_errors(lsq):
     with pytest.raises(lsq._lib.LsqError):
         lsq.update_codebooks(X, B * 300, H)
     with pytest.raises(ValueError):
-        lsq.update_codebooks(X, B, H, False, "lsmr")
+        lsq.update_codebooks(X, B, H, False, "cholesky")
 
 
 @pytest.mark.gpu
@@ -120,3 +120,28 @@ def test_scalar_kmeans_assignment_equals_the_brute_force_scan(lsq):
     C, a, cost = ini.kmeans(x.reshape(1, -1), 64, niter=30, seed=1)
     assert C.shape == (1, 64) and a.shape == (20_000,) and np.isfinite(cost)
     assert cost / x.size < 0.002 * float(x.var())                         # 64 centres on a Gaussian: the distortion is far below the variance
+
+
+def test_update_codebooks_lsmr_matches_scipy_lsmr(lsq):
+    """codebook_upd_method = "lsmr" (src/codebook_update.jl:18-21): the host LSMR against scipy's double-precision LSMR of the same system with the
+    same tolerances; the unknown-method error of codebook_update.jl:22-23; and LSMR and LSQR agree on what the system determines (the reconstruction)."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    rng = np.random.default_rng(11)
+    d, n, m = 10, 6000, 4
+    X, B = _problem(rng, d, n, m, noise=0.05)
+    C = lsq.update_codebooks(X, B, H, nthreads=3, codebook_upd_method="lsmr")
+    assert len(C) == m and C[0].shape == (d, H) and C[0].dtype == np.float32
+    K = np.concatenate(C, axis=1)
+    rows = np.tile(np.arange(n), m)
+    cols = np.concatenate([(B[j] - 1) + j * H for j in range(m)])
+    S = sp.csr_matrix((np.ones(n * m), (rows, cols)), shape=(n, m * H))
+    tol = float(np.sqrt(np.finfo(np.float32).eps))
+    Kref = np.stack([spl.lsmr(S, X[t].astype(np.float64), atol=tol, btol=tol, conlim=1e8, maxiter=max(n, m * H))[0] for t in range(d)])
+    rec, rec_ref = (S @ K.T).T, (S @ Kref.T).T
+    assert np.linalg.norm(rec - rec_ref) <= 1e-3 * np.linalg.norm(rec_ref)
+    assert np.linalg.norm(K - Kref) <= 2e-3 * np.linalg.norm(Kref)
+    Kq = np.concatenate(lsq.update_codebooks(X, B, H, nthreads=3), axis=1)
+    assert np.linalg.norm((S @ Kq.T).T - rec) <= 2e-3 * np.linalg.norm(rec)
+    with pytest.raises(ValueError, match="unknown"):
+        lsq.update_codebooks(X, B, H, codebook_upd_method="cholesky")
