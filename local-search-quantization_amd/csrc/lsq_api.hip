@@ -44,7 +44,7 @@ struct lsq_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    int64_t chunk = 256 * 4032;      // vectors per resident chunk: one pass of the filtered walk per block (256 blocks x 4032 vectors at m <= 8: lsq_q16.h)
+    int64_t chunk = 256 * 3968;      // vectors per resident chunk: one pass of the filtered walk per block (256 blocks x 3968 vectors: lsq_q16.h, WalkqRot::pp())
     int profile = 0;
     int schedule = 6;        // 3: LDS-walk (f32), one launch per node; 4: the same, one launch per ILS iteration; 6 (default): 16-bit filtered walk
                              // with exact refinement, one launch per ILS iteration (chunks below q16_min vectors / non-finite data: schedule 4);

@@ -64,11 +64,11 @@ __device__ inline void perturb_next_store(const lsq_perturb_next &pn, int64_t i,
 // wait.  Now: MODE / HASV are template parameters, so the preamble is one group of unconditional loads; a round only computes -- its four costs
 // travel to the lanes that own the vectors (v_readlane / select) and the batch ends with lane-parallel, coalesced stores of whatever was
 // accepted; NQ steps of d (two for d >= 128: 18 sixteen-byte loads per lane) are in flight per wait.
-template <int M, int MODE, int HASV, int NQ>
+template <int M, int MODE, int HASV, int NQ, bool EXTCNT = false>
 __device__ inline void cost4_body(const float *__restrict__ X, const float *__restrict__ K,
                                   const uint8_t *rec, uint8_t *cur, float *__restrict__ prev,
                                   unsigned long long *__restrict__ counters, int64_t lo, int64_t n, int64_t w, int64_t nwaves, int d,
-                                  const unsigned short *vnew, unsigned short *vcur, const lsq_perturb_next &pn) {
+                                  const unsigned short *vnew, unsigned short *vcur, const lsq_perturb_next &pn, unsigned *cnt_ext = nullptr) {      // EXTCNT: the caller's two LDS words instead of a static pair
     // vectors [lo, n): wave w of nwaves takes the 64-vector batches lo + 64 (w + q nwaves).  The cost kernels pass lo = 0 and their grid-wide wave
     // index; the filtered walk passes a block's own range and the wave's index inside the block.
     constexpr int CS = (M <= 8) ? 8 : 16;
@@ -240,7 +240,9 @@ __device__ inline void cost4_body(const float *__restrict__ X, const float *__re
         }
     }
     if (MODE == 1) {                                                                 // one pair of device atomics per block
-        __shared__ unsigned cnt_s[2];
+        unsigned *cnt_s;
+        if constexpr (EXTCNT) cnt_s = cnt_ext;
+        else { __shared__ unsigned cnt_own[2]; cnt_s = cnt_own; }
         if (threadIdx.x == 0) { cnt_s[0] = 0u; cnt_s[1] = 0u; }
         __syncthreads();
         if (lane == 0 && n_eq) atomicAdd(&cnt_s[0], n_eq);

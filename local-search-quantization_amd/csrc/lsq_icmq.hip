@@ -273,7 +273,7 @@ __global__ __launch_bounds__(64) void q16_params_kernel(const float *__restrict_
     P->nflag = 0;                // per chunk: raised by the GEMM epilogue that follows
 }
 
-// Tq[j][slice][kk][b][SLQ] (u16)  <-  rint(((T[j][k(kk)][b][slice*SLQ ..] - g_jk[a]) - rowmin[j][k][b]) * invD_j)      (one thread per 8 levels = 16 B)
+// Tq[j][slice][row q16_row_index(kk, b)][SLQ] (u16)  <-  rint(((T[j][k(kk)][b][slice*SLQ ..] - g_jk[a]) - rowmin[j][k][b]) * invD_j)      (one thread per 8 levels = 16 B)
 template <int SLQ>
 __global__ __launch_bounds__(256) void tables_to_q16_slices_kernel(const float *__restrict__ T, uint16_t *__restrict__ Tq, int m,
                                                                    const lsq_q16_params *__restrict__ P, const float *__restrict__ rowmin,
@@ -299,7 +299,8 @@ __global__ __launch_bounds__(256) void tables_to_q16_slices_kernel(const float *
         const float q1 = fminf(fmaxf(rintf(((src[2 * t + 1] - gs[2 * t + 1]) - lo) * inv), 0.0f), 65535.0f);
         w[t] = (uint32_t)q0 | ((uint32_t)q1 << 16);
     }
-    reinterpret_cast<u32x4 *>(Tq)[e] = (u32x4){w[0], w[1], w[2], w[3]};
+    const int64_t dst = (((int64_t)j * NS + slice) * (m - 1) * LSQ_H + q16_row_index<SLQ>(m, kk, b)) * LPV + qq;      // (plain geometry: dst == e)
+    reinterpret_cast<u32x4 *>(Tq)[dst] = (u32x4){w[0], w[1], w[2], w[3]};
 }
 
 // Exact refinement of the block's ambiguous vectors (records arec[0 .. namb): {ci | a1 << 16 | a2 << 24, limit, record words}, written by
@@ -373,7 +374,7 @@ __device__ inline int q16_refine(const float *__restrict__ U, const uint16_t *__
             if (abl & 8) break;
             const int k = kk + (kk >= j ? 1 : 0);
             const uint32_t bk = (rw[k >> 2] >> (8 * (k & 3))) & 0xffu;
-            const u32x4 *tp = reinterpret_cast<const u32x4 *>(Tqj + ((int64_t)kk * LSQ_H + bk) * SLQ);
+            const u32x4 *tp = reinterpret_cast<const u32x4 *>(Tqj + (int64_t)q16_row_index<SLQ>(M, kk, (int)bk) * SLQ);
             const u32x4 b0 = tp[0], b1 = tp[1];
             s0.x = pk_add_u16(s0.x, b0.x); s0.y = pk_add_u16(s0.y, b0.y); s0.z = pk_add_u16(s0.z, b0.z); s0.w = pk_add_u16(s0.w, b0.w);
             s1.x = pk_add_u16(s1.x, b1.x); s1.y = pk_add_u16(s1.y, b1.y); s1.z = pk_add_u16(s1.z, b1.z); s1.w = pk_add_u16(s1.w, b1.w);
@@ -439,15 +440,24 @@ __device__ inline int q16_refine(const float *__restrict__ U, const uint16_t *__
 // (tuning build only: measured, not adopted -- DESIGN 4.4.)  The closing phase as a REAL function call: inlined, its 128-register body joined the walk's register allocation and cost the slice loop 4.7 %
 // (17 -> 53 spilled VGPRs); as a call the walk is compiled as before and pays a handful of saves once per pass.
 template <int M>
-__device__ __attribute__((noinline)) void walkq_cost_phase(const uint32_t *cp_words, uint8_t *rec, unsigned short *valid, int64_t lo, int64_t hi, int wave, int nw) {
+__device__ __attribute__((noinline)) void walkq_cost_phase(const uint32_t *cp_words, uint8_t *rec, unsigned short *valid, int64_t lo, int64_t hi, int wave, int nw, unsigned *cnt) {
     constexpr int CPW = (int)((sizeof(lsq_cost_phase) + 3) / 4);
     lsq_cost_phase c2;
 #pragma unroll
     for (int e = 0; e < CPW; ++e) reinterpret_cast<uint32_t *>(&c2)[e] = (uint32_t)__builtin_amdgcn_readfirstlane((int)cp_words[e]);      // uniform: back into SGPRs
-    if (M <= 8 && c2.d > 64) cost4_body<M, 1, 1, 2>(c2.X, c2.K, rec, c2.cur, c2.prev, c2.counters, lo, hi, wave, nw, c2.d, valid, c2.vcur, c2.pn);
-    else cost4_body<M, 1, 1, 1>(c2.X, c2.K, rec, c2.cur, c2.prev, c2.counters, lo, hi, wave, nw, c2.d, valid, c2.vcur, c2.pn);
+    if (M <= 8 && c2.d > 64) cost4_body<M, 1, 1, 2, true>(c2.X, c2.K, rec, c2.cur, c2.prev, c2.counters, lo, hi, wave, nw, c2.d, valid, c2.vcur, c2.pn, cnt);
+    else cost4_body<M, 1, 1, 1, true>(c2.X, c2.K, rec, c2.cur, c2.prev, c2.counters, lo, hi, wave, nw, c2.d, valid, c2.vcur, c2.pn, cnt);
 }
 #endif
+
+// dynamic LDS of icm_walkq_kernel: the arrays (table, keys, active list, validity mirror), then the block's scalars
+template <int M, int SLQ, int CPL, int NT, int BPC>
+constexpr int walkq_main_bytes() {
+    if (walkq_rot(M, SLQ, CPL, NT, BPC)) return WalkqRot<M>::lds_bytes();
+    const int pp = WalkqTab<SLQ, CPL>::pp(M, BPC);
+    return WalkqTab<SLQ, CPL>::lds_entries(M) * 16 + pp * 8 + pp * 2 + (WalkqTab<SLQ, CPL>::mirror(M, BPC) ? pp * 2 : 0);
+}
+constexpr int WALKQ_MISC_BYTES = (20 + LSQ_WALK_COUNTERS + 2 + (int)((sizeof(lsq_cost_phase) + 3) / 4)) * 4;
 
 // ---- the filtered walk ----------------------------------------------------------------------------------------------------------
 // Block / pass / node structure, compaction of the active vectors, light blocks and the validity bookkeeping are those of
@@ -476,13 +486,20 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
     constexpr int RW = CS / 4;
     constexpr int TAB = (M - 1) * LSQ_H * EPR;           // 16-byte entries of one slice table (global)
     constexpr int LTAB = TL::lds_entries(M);             // ... in LDS (planes, skew)
-    constexpr int PP = TL::pp(M, BPC);                   // BPC = 1: the f32 walk's geometry (4096 up to m = 14); BPC = 2: two 512-thread blocks share a CU
+    using RT = WalkqRot<M>;
+    constexpr bool ROT = walkq_rot(M, SLQ, CPL, NT, BPC);   // rotated-rows placement of the slice table (lsq_q16.h): the default geometry up to m = 8
+    constexpr int PP = ROT ? RT::pp() : TL::pp(M, BPC);  // BPC = 1: the f32 walk's geometry (4096 up to m = 14); BPC = 2: two 512-thread blocks share a CU
     if (P->ok == 0) return;                              // never launched in that case (the host read the verdict after the GEMM); kept as a guard
     if (gate && *gate != 2u) return;                     // stand-in of an icm_xs_kernel launch (lsq_icmx.hip): runs only when that launch's start barrier said no
 #ifdef LSQ_TUNING
     unsigned long long *dbgp = nullptr;
+    extern __shared__ u32x4 lds_walkq[];
+    // No static __shared__ in this kernel: the dynamic segment must start at LDS address 0 -- the rotated placement builds table addresses byte-wise
+    // (v_perm_b32) and has no instruction to spare for a segment base.  The block's few scalars live behind the arrays (walkq_misc_words()).
+    constexpr int MAIN_BYTES = walkq_main_bytes<M, SLQ, CPL, NT, BPC>();
+    int *misc = reinterpret_cast<int *>(reinterpret_cast<char *>(lds_walkq) + MAIN_BYTES);
     if (g_walkq_dbg) {
-        __shared__ unsigned dbg_slot_s;
+        unsigned &dbg_slot_s = reinterpret_cast<unsigned *>(misc)[19];
         if (threadIdx.x == 0) dbg_slot_s = (blockIdx.x == 0) ? atomicAdd(&g_walkq_dbg_slot, 1u) : 0u;
         __syncthreads();
         // only block 0 knows the slot; other blocks use the launch's slot through a second counter-free trick: they record nothing
@@ -492,25 +509,38 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
     if (blockIdx.x == 0 && threadIdx.x == 0) g_walkq_dbg_cur = dbgp;
     if (g_walkq_blk && threadIdx.x == 0) g_walkq_blk[2 * blockIdx.x] = wall_clock64();
 #endif
+#ifndef LSQ_TUNING
     extern __shared__ u32x4 lds_walkq[];
+    constexpr int MAIN_BYTES = walkq_main_bytes<M, SLQ, CPL, NT, BPC>();
+    int *misc = reinterpret_cast<int *>(reinterpret_cast<char *>(lds_walkq) + MAIN_BYTES);      // (see the note in the tuning branch above: no static __shared__ here)
+#endif
+    if constexpr (walkq_rot(M, SLQ, CPL, NT, BPC)) {
+        if ((uint32_t)(uintptr_t)(lds_char *)lds_walkq != 0u) __builtin_trap();      // the rotated placement addresses LDS by number: the segment must start at 0
+    }
     u32x4 *tab = lds_walkq;
-    uint32_t *bestA = reinterpret_cast<uint32_t *>(lds_walkq + LTAB);                           // [PP] smallest key (Q << 16 | candidate)
-    uint32_t *bestB = bestA + PP;                                                              // [PP] second smallest key
+    constexpr bool HOLE = ROT && RT::HOLE;                                                       // bestA in the free slot of the table's second group
+    constexpr int TABE = ROT ? RT::TAB_BYTES / 16 : LTAB;
+    uint32_t *bestA = HOLE ? reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(lds_walkq) + RT::HOLE_BYTE0)
+                           : reinterpret_cast<uint32_t *>(lds_walkq + TABE);                     // [PP] smallest key (Q << 16 | candidate); HOLE: 16 words in every 64 (keyA())
+    uint32_t *bestB = HOLE ? reinterpret_cast<uint32_t *>(lds_walkq + TABE) : bestA + PP;        // [PP] second smallest key
     unsigned short *list = reinterpret_cast<unsigned short *>(bestB + PP);                     // [PP] active local indices
-    constexpr bool MIRROR = TL::mirror(M, BPC);
+    constexpr bool MIRROR = ROT ? RT::mirror() : TL::mirror(M, BPC);
+    auto keyA = [&](int ci) -> uint32_t * { return HOLE ? bestA + ((ci >> 4) << 6) + (ci & 15) : bestA + ci; };
+    // the f32-path list (16-bit entries) reuses bestA's storage after the decide phase has read the keys
+    auto f32slot = [&](int i) -> unsigned short * { return reinterpret_cast<unsigned short *>(keyA(i >> 1)) + (i & 1); };
     unsigned short *vmir = (MIRROR && valid) ? list + PP : nullptr;                              // [PP] mirror of valid[lo ..): read by the compaction, written with every store to valid[]
-    __shared__ int wave_tot[16];
-    __shared__ int nact_s;
-    __shared__ int redo_s;
-    __shared__ int f32_s;
+    int *wave_tot = misc;                                // [16]
+    int &nact_s = misc[16];
+    int &redo_s = misc[17];
+    int &f32_s = misc[18];
     // statistics are accumulated per block in LDS and flushed ONCE per launch: per-node device atomics from 256 blocks on the same few
     // words sat in front of every node update's first barrier (5-9 us per node, profiles/r02j_walkq_phases.txt "pre")
-    __shared__ unsigned stat_s[LSQ_WALK_COUNTERS];
+    unsigned *stat_s = reinterpret_cast<unsigned *>(misc) + 20;      // [LSQ_WALK_COUNTERS]
     for (int e = threadIdx.x; e < LSQ_WALK_COUNTERS; e += NT) stat_s[e] = 0u;
 #ifdef LSQ_TUNING
     // the closing phase's arguments wait in LDS: as kernel arguments they would sit in ~30 SGPRs through every node update (the kernel spills SGPRs as it is)
     constexpr int CPW = (int)((sizeof(lsq_cost_phase) + 3) / 4);
-    __shared__ uint32_t cp_s[CPW];
+    uint32_t *cp_s = reinterpret_cast<uint32_t *>(misc) + 20 + LSQ_WALK_COUNTERS + 2;      // [CPW]; the two words before it: the closing phase's block counters
     if (threadIdx.x < CPW) cp_s[threadIdx.x] = reinterpret_cast<const uint32_t *>(&cp)[threadIdx.x];
     const int cost_on = cp.on;
 #endif
@@ -545,12 +575,45 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
         }
         constexpr int NST = (TAB + NT - 1) / NT;
         u32x4 nxt[NST > 0 ? NST : 1];
+        // rotated rows (lsq_q16.h, WalkqRot): lane constants of this node.  selC0 / selC1 gather the record's code bytes of the lane's t-th read of group 0 / 1
+        // (slot (t + v) mod tables-of-the-group, table kk = 4 group + slot, code k = kk + (kk >= j)); base0 / base1 hold the matching slot | lane_q address bytes
+        // (byte 3 of base1 = 1: the second group starts at 65536).
+        uint32_t selC0 = 0x0c0c0c0cu, selC1 = 0x0c0c0c0cu, base0 = 0u, base1 = 0x01000000u;
+        if constexpr (ROT) {
+#pragma unroll
+            for (int t = 0; t < RT::NT0; ++t) {
+                const uint32_t slot = (uint32_t)(t + v) % (uint32_t)(RT::NT0 ? RT::NT0 : 1);
+                const uint32_t k = slot + (slot >= (uint32_t)j ? 1u : 0u);
+                selC0 = (selC0 & ~(0xffu << (8 * t))) | (k << (8 * t));
+                base0 |= ((slot << 6) | ((uint32_t)q << 4)) << (8 * t);
+            }
+#pragma unroll
+            for (int t = 0; t < RT::NT1; ++t) {
+                const uint32_t slot = (uint32_t)(t + v) % (uint32_t)(RT::NT1 ? RT::NT1 : 1);
+                const uint32_t k = 4u + slot + (4u + slot >= (uint32_t)j ? 1u : 0u);
+                selC1 = (selC1 & ~(0xffu << (8 * t))) | (k << (8 * t));
+                base1 |= ((slot << 6) | ((uint32_t)q << 4)) << (8 * t);
+            }
+        }
+        const uint32_t v4 = (uint32_t)v * 4u;
+        // staging of a slice: global rows are [group][code][slot] (q16_row_index) -- a straight copy for a group of four tables; a group of nt < 4 tables
+        // leaves 4 - nt slots of every 256-byte LDS line free
+        constexpr bool GROT = (SLQ == 32 && M <= 8);          // the global layout of this geometry
+        auto rot_entry = [&](auto R_) -> int {
+            constexpr int r = decltype(R_)::value;
+            constexpr int g = r >= RT::NT0 ? 1 : 0, nt = g ? RT::NT1 : RT::NT0, e0 = (r - g * RT::NT0) * NT;
+            const int eg = e0 + (int)threadIdx.x;             // entry inside the group
+            if constexpr (nt == 4) return g * 4096 + eg;
+            else { const int code = eg / (4 * (nt ? nt : 1)); return g * 4096 + code * 16 + (eg - code * 4 * nt); }
+        };
         auto prefetch_tab = [&](int sl) {
             const u32x4 *src = reinterpret_cast<const u32x4 *>(Tqj) + (int64_t)sl * TAB;
 #pragma unroll
             for (int r = 0; r < NST; ++r) {
                 const int e = (int)threadIdx.x + r * NT;
-                nxt[r] = (e < TAB) ? src[e] : (u32x4){0u, 0u, 0u, 0u};
+                if constexpr (GROT && !ROT)                   // (tuning geometries on slices of 32: plain LDS placement from the rotated global rows)
+                    nxt[r] = (e < TAB) ? src[q16_row_index<SLQ>(M, e / (LSQ_H * EPR), (e / EPR) % LSQ_H) * EPR + e % EPR] : (u32x4){0u, 0u, 0u, 0u};
+                else nxt[r] = (e < TAB) ? src[e] : (u32x4){0u, 0u, 0u, 0u};
             }
         };
         prefetch_tab(0);
@@ -604,6 +667,39 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
                     }
                 }
             }
+            if constexpr (ROT) {
+                u32x4 rd[M > 1 ? M - 1 : 1];
+                const uint32_t c0r = __builtin_amdgcn_perm(cur.r[1], cur.r[0], selC0);
+                // LDS addresses as plain numbers (the segment starts at 0, checked at kernel entry): through the segment's symbol every read pays an add of its base
+#pragma unroll
+                for (int t = 0; t < RT::NT0; ++t)            // address bytes: [slot | lane_q] [code] [0] [0]
+                    rd[t] = *reinterpret_cast<lds_cu32x4 *>(__builtin_amdgcn_perm(c0r, base0, 0x0c0c0400u + 0x0101u * (uint32_t)t));
+                auto add_rows = [&](int k0, int k1) {
+#ifdef LSQ_TUNING
+                    if (abl & 64) return;                    // ablation: no table rows
+#endif
+#pragma unroll
+                    for (int kk = k0; kk < k1; kk += 2) {
+                        if (kk + 1 < k1) {
+                            s[0].x = s[0].x + rd[kk].x + rd[kk + 1 < M - 1 ? kk + 1 : kk].x; s[0].y = s[0].y + rd[kk].y + rd[kk + 1 < M - 1 ? kk + 1 : kk].y;
+                            s[0].z = s[0].z + rd[kk].z + rd[kk + 1 < M - 1 ? kk + 1 : kk].z; s[0].w = s[0].w + rd[kk].w + rd[kk + 1 < M - 1 ? kk + 1 : kk].w;
+                        } else {
+                            s[0].x += rd[kk].x; s[0].y += rd[kk].y; s[0].z += rd[kk].z; s[0].w += rd[kk].w;
+                        }
+                    }
+                };
+                if constexpr (RT::NT1 > 0) {
+                    // the second group's rows are read only when the first group's are summed: seven reads in flight hold 28 registers, and what the
+                    // loop cannot keep is spilled AROUND it -- the compaction and the decide phase then wait for scratch (measured: +20 us per node update)
+                    const uint32_t c1r = __builtin_amdgcn_perm(cur.r[1], cur.r[0], selC1);
+                    add_rows(0, RT::NT0);
+                    asm volatile("" : "+v"(s[0].x), "+v"(s[0].y), "+v"(s[0].z), "+v"(s[0].w) : : "memory");
+#pragma unroll
+                    for (int t = 0; t < RT::NT1; ++t)        // ... [1] [0]: the second group
+                        rd[RT::NT0 + t] = *reinterpret_cast<lds_cu32x4 *>(__builtin_amdgcn_perm(c1r, base1, 0x0c030400u + 0x0101u * (uint32_t)t));
+                    add_rows(RT::NT0, M - 1);
+                } else add_rows(0, M - 1);
+            } else {
 #ifdef LSQ_TUNING
             if (!(abl & 64))                                 // ablation: no table rows
 #endif
@@ -621,9 +717,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
                     }
                 }
             }
+            }
 #ifdef LSQ_TUNING
             if (abl & 128) {                                 // ablation: no keys / top-2 / LDS atomics
-                if ((q == 0) & (c0 + v < nact) & (s[0].x == 0x12345678u)) bestA[c0 + v] = s[0].y ^ s[NR - 1].z;
+                if ((q == 0) & (c0 + v < nact) & (s[0].x == 0x12345678u)) *keyA(c0 + v) = s[0].y ^ s[NR - 1].z;
                 return;
             }
 #endif
@@ -650,8 +747,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
             if (LPV >= 2) top2_merge(l0, h0, dpp_u32<DPP_XOR1>(l0), dpp_u32<DPP_XOR1>(h0));
             if (LPV >= 4) top2_merge(l0, h0, dpp_u32<DPP_XOR2>(l0), dpp_u32<DPP_XOR2>(h0));
             if ((q == 0) & (c0 + v < nact)) {
-                const uint32_t old = atomicMin(&bestA[c0 + v], l0);      // returns the previous minimum: the larger of the two is a runner-up
-                atomicMin(&bestB[c0 + v], umin(umax(old, l0), h0));
+                if constexpr (HOLE) {      // c0 is a multiple of 16 and v < 16: the smallest key of vector c0 + v sits at byte 16 c0 + 4 v of the free slot
+                    const uint32_t sA = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)RT::HOLE_BYTE0 + (uint32_t)c0 * 16u));      // scalar parts: one add per address
+                    const uint32_t sB = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)RT::TAB_BYTES + (uint32_t)c0 * 4u));
+                    const uint32_t old = __hip_atomic_fetch_min(reinterpret_cast<lds_u32 *>(sA + v4), l0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_min(reinterpret_cast<lds_u32 *>(sB + v4), umin(umax(old, l0), h0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                    const uint32_t old = atomicMin(&bestA[c0 + v], l0);      // returns the previous minimum: the larger of the two is a runner-up
+                    atomicMin(&bestB[c0 + v], umin(umax(old, l0), h0));
+                }
             }
         };
         Item buf[DEPTH];
@@ -663,10 +767,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
 #ifdef LSQ_TUNING
             if (slice < 8) DBG_STAMP(3 + slice);
 #endif
+            if constexpr (ROT) {
+                static_for<NST>([&](auto R_) { tab[rot_entry(R_)] = nxt[decltype(R_)::value]; });
+            } else {
 #pragma unroll
-            for (int r = 0; r < NST; ++r) {
-                const int e = (int)threadIdx.x + r * NT;
-                if (e < TAB) tab[TL::entry(e / (LSQ_H * EPR), (e / EPR) % LSQ_H, e % EPR)] = nxt[r];      // NT = 1024, EPR = 4: table r, the thread's fixed (code, chunk)
+                for (int r = 0; r < NST; ++r) {
+                    const int e = (int)threadIdx.x + r * NT;
+                    if (e < TAB) tab[TL::entry(e / (LSQ_H * EPR), (e / EPR) % LSQ_H, e % EPR)] = nxt[r];      // NT = 1024, EPR = 4: table r, the thread's fixed (code, chunk)
+                }
             }
             __syncthreads();
             if (slice + 1 < NS) prefetch_tab(slice + 1);
@@ -777,7 +885,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
                 __syncthreads();
                 continue;
             }
-            for (int ci = threadIdx.x; ci < nact; ci += NT) { bestA[ci] = 0xffffffffu; bestB[ci] = 0xffffffffu; }
+            for (int ci = threadIdx.x; ci < nact; ci += NT) { *keyA(ci) = 0xffffffffu; bestB[ci] = 0xffffffffu; }
             DBG_STAMP(2);
             walk_slices(j, lo, nact, nact == cnt);
             DBG_STAMP(11);
@@ -808,7 +916,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
 #pragma unroll
                     for (int w2 = 0; w2 < RW; ++w2) { rw[e][w2] = 0; rr[e][w2] = 0; }
                     if (ci < nact) {
-                        kA[e] = bestA[ci]; kB[e] = bestB[ci];
+                        kA[e] = *keyA(ci); kB[e] = bestB[ci];
                         vi[e] = lo + list[ci];
                         fl[e] = qflag[vi[e]];
                         if constexpr (ONE_TRIP) {
@@ -852,7 +960,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
                 }
                 __syncthreads();                                       // every bestA[] / bestB[] has been read: their storage is reused below
                 uint32_t *arec = bestB;                                // ambiguous-vector records
-                unsigned short *f32l = reinterpret_cast<unsigned short *>(bestA);      // vectors for the f32 path
 #pragma unroll
                 for (int e = 0; e < EPD; ++e) {
                     if (von[e]) {
@@ -885,7 +992,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
                             for (int w2 = 0; w2 < RW; ++w2) arec[slot * AREC + 2 + w2] = rw[e][w2];
                         } else tof32 = true;                           // more ambiguous vectors than records (degenerate data): full f32 for the rest
                     }
-                    if (tof32) f32l[atomicAdd(&f32_s, 1)] = (unsigned short)(vkey[e] & 0xffffu);
+                    if (tof32) *f32slot(atomicAdd(&f32_s, 1)) = (unsigned short)(vkey[e] & 0xffffu);      // vectors for the f32 path
                 }
             }
             __syncthreads();
@@ -894,9 +1001,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
             const int namb = redo_s < ACAP ? redo_s : ACAP;
             int nexact = q16_refine<M, SLQ, NT>(U, Uq, Tq, T, rec, valid, ref_rec, ref_valid, n, j, lo, list, bestB, namb, SLF, abl, vmir);
             {   // vectors outside the sampled level range: one wave each, in full f32
-                const unsigned short *f32l = reinterpret_cast<const unsigned short *>(bestA);
                 const int nf32 = f32_s;
-                light_list(j, nf32, [&](int r) { return list[f32l[r]]; });
+                light_list(j, nf32, [&](int r) { return list[*f32slot(r)]; });
                 if (threadIdx.x == 0 && nf32) atomicAdd(&stat_s[4 + LSQ_WALK_TRACE + 2], (unsigned)nf32);
             }
             {
@@ -916,7 +1022,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
 #ifdef LSQ_TUNING
         if (cost_on) {
             __syncthreads();
-            walkq_cost_phase<M>(cp_s, rec, valid, lo, hi, wave, NW);
+            walkq_cost_phase<M>(cp_s, rec, valid, lo, hi, wave, NW, reinterpret_cast<unsigned *>(misc) + 20 + LSQ_WALK_COUNTERS);
         }
 #endif
     }
@@ -1055,9 +1161,10 @@ static int launch_walkq_t(hipStream_t s, const float *U, const uint16_t *Uq, con
                           int64_t n, const WalkNodes &nodes, int use_skip, unsigned long long *active_total, int light,
                           const uint8_t *ref_rec, const unsigned short *ref_valid, const lsq_q16_params *P, const unsigned short *qflag, const unsigned *gate,
                           const lsq_cost_phase &cp) {
-    constexpr int PP = WalkqTab<SLQ, CPL>::pp(M, BPC);
-    constexpr int LDS_BYTES = WalkqTab<SLQ, CPL>::lds_entries(M) * 16 + PP * 8 + PP * 2 + (WalkqTab<SLQ, CPL>::mirror(M, BPC) ? PP * 2 : 0);      // slice table (planes, skew) + two smallest keys + active list (+ validity mirror)
-    static_assert((LDS_BYTES + 768) * BPC <= 160 * 1024, "slice table + keys must fit the block's share of the 160 KiB LDS");
+    constexpr bool ROT = walkq_rot(M, SLQ, CPL, NT, BPC);
+    constexpr int PP = ROT ? WalkqRot<M>::pp() : WalkqTab<SLQ, CPL>::pp(M, BPC);
+    constexpr int LDS_BYTES = walkq_main_bytes<M, SLQ, CPL, NT, BPC>() + WALKQ_MISC_BYTES;      // slice table + two smallest keys + active list (+ validity mirror) + the block's scalars
+    static_assert(LDS_BYTES * BPC <= 160 * 1024 && WALKQ_MISC_BYTES <= 768, "slice table + keys must fit the block's share of the 160 KiB LDS");
     constexpr int NBLK = 256 * BPC;
     const int64_t rounds = (n + NBLK * (int64_t)PP - 1) / (NBLK * (int64_t)PP);      // passes per block
     int64_t per = rounds > 0 ? (n + NBLK * rounds - 1) / (NBLK * rounds) : 1;

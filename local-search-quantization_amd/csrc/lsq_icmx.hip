@@ -173,7 +173,7 @@ __device__ inline int xs_refine(const XsArgs &A, int j, int64_t gb, const uint32
         for (int kk = 0; kk < M - 1; ++kk) {
             const int k = kk + (kk >= j ? 1 : 0);
             const uint32_t bk = (rw[k >> 2] >> (8 * (k & 3))) & 0xffu;
-            const u32x4 *tp = reinterpret_cast<const u32x4 *>(Tqj + ((int64_t)kk * LSQ_H + bk) * SLQ);
+            const u32x4 *tp = reinterpret_cast<const u32x4 *>(Tqj + (int64_t)q16_row_index<SLQ>(M, kk, (int)bk) * SLQ);
             const u32x4 b0 = tp[0], b1 = tp[1];
             s0.x = pk_add_u16(s0.x, b0.x); s0.y = pk_add_u16(s0.y, b0.y); s0.z = pk_add_u16(s0.z, b0.z); s0.w = pk_add_u16(s0.w, b0.w);
             s1.x = pk_add_u16(s1.x, b1.x); s1.y = pk_add_u16(s1.y, b1.y); s1.z = pk_add_u16(s1.z, b1.z); s1.w = pk_add_u16(s1.w, b1.w);
@@ -390,7 +390,8 @@ __global__ __launch_bounds__(1024) void icm_xs_kernel(const XsArgs A, const Walk
                 if (t > 0 && !X.wait_lds(XC_WALK0 + ((t - 1) & 1), (unsigned)(W * ((t - 1) / 2 + 1)), 10u)) return;
                 if (wave == 0) XS_STAMP(t, 3);
                 const u32x4 *src = reinterpret_cast<const u32x4 *>(A.Tq) + ((int64_t)j * NS + slice) * TAB;
-                for (int e = wave * 64 + lane; e < TAB; e += W * 64) tab[TL::entry(e / (LSQ_H * EPR), (e / EPR) % LSQ_H, e % EPR)] = src[e];
+                for (int e = wave * 64 + lane; e < TAB; e += W * 64)
+                    tab[TL::entry(e / (LSQ_H * EPR), (e / EPR) % LSQ_H, e % EPR)] = src[q16_row_index<SLQ>(M, e / (LSQ_H * EPR), (e / EPR) % LSQ_H) * EPR + e % EPR];
                 if (lane == 0) lds_add(ctl + XC_TABBAR, 1u);
                 ++nstaged;
                 if (!X.wait_lds(XC_TABBAR, (unsigned)W * nstaged, 11u)) return;

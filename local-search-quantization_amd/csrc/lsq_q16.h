@@ -9,6 +9,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+// LDS addressed by number (address space 3 pointers made from integers)
+typedef const u32x4 __attribute__((address_space(3))) lds_cu32x4;
+typedef uint32_t __attribute__((address_space(3))) lds_u32;
+typedef char __attribute__((address_space(3))) lds_char;
+
 
 __device__ inline uint32_t pk_add_u16(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b));      // v_pk_add_u16
@@ -69,6 +74,54 @@ struct WalkqTab {
     static constexpr bool mirror(int m, int bpc) { return pp_for(m, bpc, 12) * 64 >= pp_for(m, bpc, 10) * 63; }
     static constexpr int pp(int m, int bpc) { return mirror(m, bpc) ? pp_for(m, bpc, 12) : pp_for(m, bpc, 10); }
 };
+
+// Round 5 (late): "rotated rows" placement for the default geometry up to m = 8 (slices of 32 candidates, four lanes of 16 bytes per vector).
+// The slice table is stored code-major in 256-byte lines: byte address = group * 65536 + code * 256 + slot * 64 + lane_q * 16, table kk = 4 group + slot
+// (group 0: tables 0..3, group 1: tables 4..m-2).  Two things follow.  (i) Code and bank are decoupled: the bank quarter of a read is its SLOT, so when the
+// four vectors of a 16-lane group read four different slots the read is conflict-free whatever their codes are -- vector v reads, as the t-th read of a
+// group, slot (t + v) mod (tables of the group); integer level sums do not care about the order (the old placement, 64-byte rows indexed by code, cost
+// E[max rows per bank quarter] = 2.125 LDS cycles per 16-lane group instead of 1: profiles/r05_ubench_lds.txt).  (ii) The code sits in byte 1 of the address:
+// one v_perm_b32 builds an address from the (rotated) code bytes and a lane constant holding the four slot | lane_q bytes -- 9 VALU instructions per item for
+// the seven addresses instead of 16 (extract, shift-add).  With 5..7 tables the free slot 3 of group 1 (64 bytes in every 256) holds the smallest keys
+// (bestA: word ci at line ci / 16, 16 words per line), so the table costs no more LDS than the plain placement: 128 KiB + 8 bytes per vector.
+template <int M>
+struct WalkqRot {
+    static constexpr int NTAB = M - 1;
+    static constexpr int NT0 = NTAB < 4 ? NTAB : 4, NT1 = NTAB - NT0;                      // tables of group 0 / group 1
+    static constexpr int NG = NT1 > 0 ? 2 : (NT0 > 0 ? 1 : 0);
+    static constexpr int TAB_BYTES = NG * 65536;
+    static constexpr bool HOLE = NT1 > 0;                                                    // bestA lives in slot 3 of group 1
+    static constexpr int HOLE_BYTE0 = 65536 + 192;
+    static constexpr int pp_for(int bytes_per_vector) {
+        const int avail = 160 * 1024 - 768 - TAB_BYTES;
+        const int v = avail / bytes_per_vector / 64 * 64;
+        return v > 4096 ? 4096 : v;
+    }
+    static constexpr int KEY_BYTES = HOLE ? 4 : 8;                                           // per vector outside the table: bestB (+ bestA)
+    // validity mirror (2 bytes per vector, see WalkqTab::mirror): kept where a block pass still holds 10^6 / 256 vectors (BASELINE configs[1] in one pass)
+    static constexpr bool mirror() { return pp_for(KEY_BYTES + 4) * 256 >= 1000000; }
+    static constexpr int pp() { return mirror() ? pp_for(KEY_BYTES + 4) : pp_for(KEY_BYTES + 2); }
+    static constexpr int lds_bytes() { return TAB_BYTES + pp() * (KEY_BYTES + 2 + (mirror() ? 2 : 0)); }
+};
+
+template <int N, class F, int I = 0>
+__device__ inline void static_for(F &&f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<N, F, I + 1>(static_cast<F &&>(f)); }
+}
+
+// Row (kk, code) of a slice table in GLOBAL memory, in rows of SLQ levels.  Slices of 32 candidates up to m = 8 are stored as the LDS image of the rotated
+// placement without its free slot -- [group][code][slot] -- so that a slice is staged by a straight, fully coalesced copy; every other geometry keeps [kk][code].
+template <int SLQ>
+__host__ __device__ inline int q16_row_index(int m, int kk, int code) {
+    if (SLQ == 32 && m <= 8) {
+        const int nt0 = m - 1 < 4 ? m - 1 : 4, g = kk >= 4 ? 1 : 0;
+        return g ? nt0 * LSQ_H + code * (m - 1 - nt0) + (kk - 4) : code * nt0 + kk;
+    }
+    return kk * LSQ_H + code;
+}
+
+// which geometry takes the rotated-rows placement
+constexpr bool walkq_rot(int m, int slq, int cpl, int nt, int bpc) { return m <= 8 && slq == 32 && cpl == 8 && nt == 1024 && bpc == 1; }
 
 
 }  // namespace

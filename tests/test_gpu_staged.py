@@ -159,7 +159,7 @@ def test_cfg5_chunk_walk(lsq, oracle):
         assert torch.equal(dBs, dBs2) and np.allclose(sums, sums2, rtol=1e-9) and np.array_equal(stats, stats2)
         K = dK.cpu().numpy()
         rng = np.random.default_rng(9)
-        rows = [0, n - 1] + [c * (256 * 4032) + o for c in (1, 2) for o in (-1, 0, 1)] + list(rng.choice(n, size=20, replace=False))
+        rows = [0, n - 1] + [c * (256 * 3968) + o for c in (1, 2) for o in (-1, 0, 1)] + list(rng.choice(n, size=20, replace=False))
         rows = np.array(sorted(set(int(r) for r in rows)))
         idx = torch.from_numpy(rows).to(dX.device)
         Xs = dX[idx].cpu().numpy()
@@ -180,12 +180,12 @@ def test_cfg5_chunk_walk(lsq, oracle):
 
 def test_cfg5_full_per_gpu_share(lsq, oracle):
     """BASELINE configs[4] exactly as ONE GPU of the 8-GPU weak-scaling job runs it (missing #4): 12.5 M x 128 vectors generated ON THE
-    DEVICE at rank 1's offset, default chunking (13 resident chunks of 256 x 4032: X = 6.4 GB, byte offsets pass 2^32), 2 ILS iterations.  Rows on both sides
+    DEVICE at rank 1's offset, default chunking (13 resident chunks of 256 x 3968: X = 6.4 GB, byte offsets pass 2^32), 2 ILS iterations.  Rows on both sides
     of EVERY chunk boundary + 32 random rows == the oracle on exactly those vectors (P8); every chunk ran the filtered walk; objective = mean cost
     on one whole chunk (the last full one)."""
     import torch
     d, m, ils, J, npert, seed = 128, 8, [2], 4, 4, 5
-    n, goff, chunk = 12_500_000, 12_500_000, 256 * 4032
+    n, goff, chunk = 12_500_000, 12_500_000, 256 * 3968
     with lsq.Engine(0) as eng:
         dX = eng.synth_data_u8_dev(1234, n, d, global_offset=goff)
         assert dX.numel() * 4 > (1 << 32)
