@@ -839,11 +839,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
         }
         for (int nu = 0; nu < nodes.count; ++nu) {
             const int j = nodes.j[nu];
+            // the thread's index as the node update sees it: opaque, so that the per-thread LDS addresses derived from it (keys, list, mirror) are computed
+            // where they are used -- as loop invariants they are hoisted out of the node loop, spilled, and every phase then opens with scratch reloads
+            int tix = (int)threadIdx.x;
+            asm volatile("" : "+v"(tix));
 #ifdef LSQ_TUNING
             if (dbgp && threadIdx.x == 0 && pass == (int64_t)blockIdx.x && nu < 64) dbgp[24 + nu] = wall_clock64();
 #endif
             {
-                const int base = (int)threadIdx.x * EPT;
+                const int base = tix * EPT;
                 int f[EPT], c = 0;
 #pragma unroll
                 for (int e = 0; e < EPT; ++e) {
@@ -885,7 +889,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
                 __syncthreads();
                 continue;
             }
-            for (int ci = threadIdx.x; ci < nact; ci += NT) { *keyA(ci) = 0xffffffffu; bestB[ci] = 0xffffffffu; }
+            for (int ci = tix; ci < nact; ci += NT) { *keyA(ci) = 0xffffffffu; bestB[ci] = 0xffffffffu; }
             DBG_STAMP(2);
             walk_slices(j, lo, nact, nact == cnt);
             DBG_STAMP(11);
@@ -911,7 +915,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
                 const bool have_ref = ref_rec && ref_valid;
 #pragma unroll
                 for (int e = 0; e < EPD; ++e) {
-                    const int ci = (int)threadIdx.x + e * NT;
+                    const int ci = tix + e * NT;
                     vi[e] = lo; kA[e] = 0; kB[e] = 0; vo[e] = 0; rv[e] = 0; fl[e] = 0;
 #pragma unroll
                     for (int w2 = 0; w2 < RW; ++w2) { rw[e][w2] = 0; rr[e][w2] = 0; }
@@ -933,7 +937,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
                 }
 #pragma unroll
                 for (int e = 0; e < EPD; ++e) {
-                    const int ci = (int)threadIdx.x + e * NT;
+                    const int ci = tix + e * NT;
                     von[e] = false; vamb[e] = false; vf32[e] = false; vcode[e] = 0; vkey[e] = 0; vlim[e] = 0;
                     if (ci < nact) {
                         vcode[e] = kA[e] & 0xffffu;
