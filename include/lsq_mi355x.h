@@ -98,7 +98,7 @@ LSQ_API int lsq_destroy(lsq_ctx *ctx);
 /* Launch on the caller's hipStream_t (e.g. torch's current stream).  NULL = HIP's default (null)
  * stream; option "own_stream" switches back to the context's private non-blocking stream. */
 LSQ_API int lsq_set_stream(lsq_ctx *ctx, void *hip_stream);
-/* Options: "chunk" (vectors per resident chunk, default 1032192 = 256 blocks x 4032 vectors: one pass of the walk kernel per block), "profile" (0/1), "own_stream",
+/* Options: "chunk" (vectors per resident chunk, default 1015808 = 256 blocks x 3968 vectors: one pass of the walk kernel per block), "profile" (0/1), "own_stream",
  *   "schedule" -- how the ICM node updates run; all give bit-identical codes:
  *        6 (default) 16-bit FILTERED walk, one launch per ILS iteration: every term of a conditioned sum is also held as a 16-bit level
  *                    on a common step (u16 unary planes written by the unary GEMM's epilogue, u16 pair-table slices staged in LDS); a

@@ -69,7 +69,7 @@ struct WalkqTab {
         return v > 4096 / bpc ? 4096 / bpc : v;
     }
     // Round 5: the block keeps a MIRROR of its vectors' validity words in LDS (2 more bytes per vector) so that the compaction at the head of every node
-    // update reads LDS instead of waiting for L2 -- where that costs at most 1/64 of the vectors per pass (m = 8: 4032 instead of 4096; m = 16 would drop
+    // update reads LDS instead of waiting for L2 -- where that costs at most 1/64 of the vectors per pass (plain placement, m = 8: 4032 instead of 4096; m = 16 would drop
     // from 3968 to 3328 and need a second pass per 10^6-vector chunk: no mirror there)
     static constexpr bool mirror(int m, int bpc) { return pp_for(m, bpc, 12) * 64 >= pp_for(m, bpc, 10) * 63; }
     static constexpr int pp(int m, int bpc) { return mirror(m, bpc) ? pp_for(m, bpc, 12) : pp_for(m, bpc, 10); }
