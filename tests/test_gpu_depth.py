@@ -151,3 +151,23 @@ def test_host_upload_pipeline_gives_the_same_codes(lsq, oracle, n, d, m, forced)
     assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0)
     if forced:
         assert tm["filtered_blocks"] > 0 and tm["filter_f32"] > 0, tm             # the scaled rows went through the f32 routine
+
+
+@pytest.mark.parametrize("m", list(range(1, 17)))
+def test_every_codebook_count_through_the_filtered_walk(lsq, oracle, m):
+    """Every instantiation of the filtered walk kernel, one by one: m = 1 .. 8 use the rotated-rows slice table (lsq_q16.h, WalkqRot: one or two table groups, with
+    and without the free slot that holds the smallest keys), m = 9 .. 16 the plain placement.  The filter is forced onto every block (no light blocks, no probe, no
+    fallback); several blocks hold a ragged number of vectors; every vector against the oracle."""
+    from conftest import make_problem
+    d, n, ils, J, npert, seed = 24, 21_013, [2], 3, min(m, 3), 11
+    X, K, B0 = make_problem(d, n, m, seed=100 + m, kind="gauss")
+    ref, objs_ref = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, True, seed)
+    with lsq.Engine(0) as eng:
+        for k, v in (("q16_min", 0), ("light", 0), ("filter_probe_div", 0), ("filter_fallback_div", 0)):
+            eng.set_option(k, v)
+        Bs, objs = eng.encode_icm(X, B0, K, m, ils, J, npert, True, seed=seed)
+        tm = eng.timings()
+    assert np.array_equal(Bs, ref), "%d codes differ at m = %d" % ((Bs != ref).sum(), m)
+    assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0)
+    if m > 1:
+        assert tm["filtered_blocks"] > 0 and tm["light_blocks"] == 0, tm
