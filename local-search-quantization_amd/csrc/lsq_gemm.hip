@@ -292,12 +292,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
-__global__ __launch_bounds__(256) void sqnorms_kernel(const float *__restrict__ Kb, int rows, int d, float *__restrict__ sci) {
+__global__ __launch_bounds__(64) void sqnorms_kernel(const float *__restrict__ Kb, int rows, int d, float *__restrict__ sci) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
     const float *p = Kb + (int64_t)r * d;
     float acc = 0.0f;
-    for (int t = 0; t < d; ++t) acc = fmaf(p[t], p[t], acc);
+    // the chain itself is canonical (k ascending, one fmaf per term: oracle parity); only its operands are fetched ahead, 16 bytes at a time
+    if ((d & 3) == 0 && (((uintptr_t)Kb) & 15) == 0) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 *p4 = reinterpret_cast<const f4 *>(p);
+        int t = 0;
+        for (; t + 8 <= d / 4; t += 8) {
+            f4 v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = p4[t + e];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { acc = fmaf(v[e].x, v[e].x, acc); acc = fmaf(v[e].y, v[e].y, acc); acc = fmaf(v[e].z, v[e].z, acc); acc = fmaf(v[e].w, v[e].w, acc); }
+        }
+        for (; t < d / 4; ++t) { const f4 v = p4[t]; acc = fmaf(v.x, v.x, acc); acc = fmaf(v.y, v.y, acc); acc = fmaf(v.z, v.z, acc); acc = fmaf(v.w, v.w, acc); }
+    } else {
+        for (int t = 0; t < d; ++t) acc = fmaf(p[t], p[t], acc);
+    }
     sci[r] = acc;
 }
 
@@ -362,7 +377,7 @@ int lsq_launch_chain_gemm(hipStream_t s, const float *A, const float *Bm, const 
 
 int lsq_launch_sqnorms(hipStream_t s, const float *Kb, int rows, int d, float *sci) {
     if (rows <= 0) return LSQ_OK;
-    hipLaunchKernelGGL(sqnorms_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, Kb, rows, d, sci);
+    hipLaunchKernelGGL(sqnorms_kernel, dim3((rows + 15) / 16), dim3(16), 0, s, Kb, rows, d, sci);      // one row per thread, a long dependent chain: spread over the CUs
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }

@@ -135,10 +135,12 @@ __global__ __launch_bounds__(256) void codebook_means_kernel(const float *__rest
 // bound (optional; with qflag, P): the level parameters were derived from a SAMPLE's max |sigma| (the host-buffer pipeline: the sample is uploaded ahead
 // of the panels); a vector whose |sigma| exceeds the bound the parameters assumed gets every node flagged -- it takes the f32 routine, like a unary
 // outside the sampled level range -- so the window stays rigorous for every vector the filter decides.  flag_row0: the row of sigma[0] in qflag.
+// LONGV: the instantiation for d > 256 (its m running sums would cost the short-vector path a quarter of its occupancy: 265 -> 365 us at 10^6 x 128)
+template <bool LONGV>
 __global__ __launch_bounds__(256) void unary_shift_kernel(const float *__restrict__ X, const float *__restrict__ R, int64_t n, int d, int m,
                                                           float *__restrict__ sigma, unsigned *__restrict__ sigmax,
-                                                          const unsigned *__restrict__ bound = nullptr, unsigned short *__restrict__ qflag = nullptr,
-                                                          int64_t flag_row0 = 0, lsq_q16_params *__restrict__ P = nullptr) {
+                                                          const unsigned *__restrict__ bound, unsigned short *__restrict__ qflag,
+                                                          int64_t flag_row0, lsq_q16_params *__restrict__ P) {
     const int lane = threadIdx.x & 63, lp = lane & 15;
     const int64_t nrows = (int64_t)gridDim.x * 16;
     const bool vec = (d & 3) == 0 && ((((uintptr_t)X | (uintptr_t)R) & 15) == 0);
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void unary_shift_kernel(const float *__restric
         float rmax = 0.0f;
         bool rnan = false;
         const float *x = X + (live ? i : 0) * (int64_t)d;
-        if (vec && d <= 256) {                                      // the vector stays in registers (16 floats per lane) while the m means pass by (L1)
+        if (!LONGV && vec && d <= 256) {                            // the vector stays in registers (16 floats per lane) while the m means pass by (L1)
             f32x4 xr[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(256) void unary_shift_kernel(const float *__restric
                 for (int t = 0; t < 4; ++t)
                     if (4 * lp + 64 * t < d) {
                         const f32x4 rv = *reinterpret_cast<const f32x4 *>(r + 64 * t);
-                        acc += xr[t].x * rv.x + xr[t].y * rv.y + xr[t].z * rv.z + xr[t].w * rv.w;
+                        acc = fmaf(xr[t].w, rv.w, fmaf(xr[t].z, rv.z, fmaf(xr[t].y, rv.y, fmaf(xr[t].x, rv.x, acc))));      // (sigma is a shift, not a result: any rounding serves)
                     }
                 acc = acc + dpp_self<DPP_XOR1, 0xf>(acc);
                 acc = acc + dpp_self<DPP_XOR2, 0xf>(acc);
@@ -181,6 +183,45 @@ __global__ __launch_bounds__(256) void unary_shift_kernel(const float *__restric
                 const float sg = 2.0f * acc;
                 if (live && lp == 0) sigma[i * m + j] = sg;
                 if (live) { amax = fmaxf(amax, fabsf(sg)); rmax = fmaxf(rmax, fabsf(sg)); if (!(sg == sg)) rnan = true; }
+            }
+            flag_row(i, live, rmax, rnan);
+            continue;
+        }
+        if (LONGV && vec) {
+            // long vectors: x passes through the registers ONCE, in pieces of 256 floats, against all m means (the m sums live side by side).  Before: x was re-read from L1 / L2 for every node (0.52 ms at 125 000 x 960)
+            float accj[LSQ_MAX_M];
+#pragma unroll
+            for (int j = 0; j < LSQ_MAX_M; ++j) accj[j] = 0.0f;
+            for (int c0 = 0; c0 < d; c0 += 256) {
+                f32x4 xr[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    xr[t] = c0 + 4 * lp + 64 * t < d ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(x + c0 + 4 * lp + 64 * t)) : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int j = 0; j < LSQ_MAX_M; ++j) {
+                    if (j < m) {
+                        const float *r = R + (int64_t)j * d + c0 + 4 * lp;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            if (c0 + 4 * lp + 64 * t < d) {
+                                const f32x4 rv = *reinterpret_cast<const f32x4 *>(r + 64 * t);
+                                accj[j] = fmaf(xr[t].w, rv.w, fmaf(xr[t].z, rv.z, fmaf(xr[t].y, rv.y, fmaf(xr[t].x, rv.x, accj[j]))));
+                            }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < LSQ_MAX_M; ++j) {
+                if (j < m) {
+                    float acc = accj[j];
+                    acc = acc + dpp_self<DPP_XOR1, 0xf>(acc);
+                    acc = acc + dpp_self<DPP_XOR2, 0xf>(acc);
+                    acc = acc + dpp_self<DPP_HALF_MIRROR, 0xf>(acc);
+                    acc = acc + dpp_self<DPP_MIRROR, 0xf>(acc);
+                    const float sg = 2.0f * acc;
+                    if (live && lp == 0) sigma[i * m + j] = sg;
+                    if (live) { amax = fmaxf(amax, fabsf(sg)); rmax = fmaxf(rmax, fabsf(sg)); if (!(sg == sg)) rnan = true; }
+                }
             }
             flag_row(i, live, rmax, rnan);
             continue;
@@ -210,6 +251,18 @@ __global__ __launch_bounds__(256) void unary_shift_kernel(const float *__restric
     for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
     if (lane == 0 && __float_as_uint(amax) > __hip_atomic_load(sigmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(sigmax, __float_as_uint(amax));
 }
+
+__global__ __launch_bounds__(64) void q16_range_init_kernel(unsigned *__restrict__ qrange, int m) {
+    const int t = threadIdx.x;
+    if (t < 2 * LSQ_MAX_M + 4) qrange[t] = (t < 2 * m && !(t & 1)) ? 0xffffffffu : 0u;
+}
+
+static void launch_unary_shift(dim3 grid, hipStream_t s, const float *X, const float *R, int64_t n, int d, int m, float *sigma, unsigned *sigmax,
+                               const unsigned *bound = nullptr, unsigned short *qflag = nullptr, int64_t flag_row0 = 0, lsq_q16_params *P = nullptr) {
+    if (d > 256) hipLaunchKernelGGL(unary_shift_kernel<true>, grid, dim3(256), 0, s, X, R, n, d, m, sigma, sigmax, bound, qflag, flag_row0, P);
+    else hipLaunchKernelGGL(unary_shift_kernel<false>, grid, dim3(256), 0, s, X, R, n, d, m, sigma, sigmax, bound, qflag, flag_row0, P);
+}
+#define LSQ_SHIFT_LAUNCH(D_, GRID_, S_, ...) launch_unary_shift(GRID_, S_, __VA_ARGS__)
 
 // One block: value ranges -> lsq_q16_params (in double).
 //   U_j: the minimum / maximum over a SAMPLE of the chunk's vectors (range-only GEMM pass, qrange = order-preserving keys), widened by 1/8 of
@@ -1099,7 +1152,7 @@ int lsq_launch_unary_shift_panel(hipStream_t s, const float *Xp, int64_t rows, i
     if (rows <= 0) return LSQ_OK;
     const int64_t shift_blocks = (rows * 16 + 255) / 256;
     // the chunk maximum is not collected here (a scratch word takes it): the parameters were fixed from the sample
-    hipLaunchKernelGGL(unary_shift_kernel, dim3((unsigned)(shift_blocks < 2048 ? shift_blocks : 2048)), dim3(256), 0, s, Xp, means, rows, d, m, sigma_p,
+    LSQ_SHIFT_LAUNCH(d, dim3((unsigned)(shift_blocks < 2048 ? shift_blocks : 2048)), s, Xp, means, rows, d, m, sigma_p,
                        qrange + 2 * LSQ_MAX_M + 3, qrange + 2 * LSQ_MAX_M + 2, qflag, row0, P);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
@@ -1126,20 +1179,19 @@ int lsq_launch_q16_prepare(hipStream_t s, const float *X, int64_t n, int d, cons
         hipLaunchKernelGGL(codebook_means_kernel, dim3((unsigned)((d + 63) / 64), (unsigned)m), dim3(256), 0, s, K, m, d, means);
     }
     // sampled range of the SHIFTED unaries: about 16 384 vectors at d <= 128 (every rts-th panel of 128 consecutive ones) through the range-only GEMM pass
-    LSQ_HIP(hipMemsetAsync(qrange, 0, sizeof(unsigned) * (2 * LSQ_MAX_M + 4), s));
-    for (int j = 0; j < m; ++j) LSQ_HIP(hipMemsetAsync(qrange + 2 * j, 0xff, sizeof(unsigned), s));      // min slots start at the largest key
+    hipLaunchKernelGGL(q16_range_init_kernel, dim3(1), dim3(64), 0, s, qrange, m);      // zeros; min slots start at the largest key (one launch: m + 1 fills cost 5 us each)
     if (Xsample) {
         // host-buffer pipeline: the sample (the same rows the strided pass would read) was uploaded ahead of the panels, compacted; sigma of the sample,
         // its maximum (widened below) and the value ranges come from it alone; the panels' own sigma follow panel by panel (lsq_launch_unary_shift_panel)
         const int64_t shift_blocks = (nsample_rows * 16 + 255) / 256;
-        hipLaunchKernelGGL(unary_shift_kernel, dim3((unsigned)(shift_blocks < 2048 ? shift_blocks : 2048)), dim3(256), 0, s, Xsample, means, nsample_rows, d, m,
+        LSQ_SHIFT_LAUNCH(d, dim3((unsigned)(shift_blocks < 2048 ? shift_blocks : 2048)), s, Xsample, means, nsample_rows, d, m,
                            sigma_sample, qrange + 2 * LSQ_MAX_M + 1);
         LSQ_TRY(lsq_launch_chain_gemm(s, Xsample, K, sci, -2.0f, nsample_rows, m * LSQ_H, d, LSQ_H, 0, 0, nullptr, 0, nsample_rows, 0, nullptr, 0, nullptr, 0, nullptr,
                                       qrange, 1, sigma_sample, colshift));
         LSQ_HIP(hipMemsetAsync(qflag, 0, sizeof(unsigned short) * (size_t)((n + 1) & ~(int64_t)1), s));
     } else if (n > 0) {
         const int64_t shift_blocks = (n * 16 + 255) / 256;           // 16 vectors per block per pass, at most 8 blocks per CU in flight
-        hipLaunchKernelGGL(unary_shift_kernel, dim3((unsigned)(shift_blocks < 2048 ? shift_blocks : 2048)), dim3(256), 0, s, X, means, n, d, m, sigma,
+        LSQ_SHIFT_LAUNCH(d, dim3((unsigned)(shift_blocks < 2048 ? shift_blocks : 2048)), s, X, means, n, d, m, sigma,
                            qrange + 2 * LSQ_MAX_M + 1);
         int64_t rts64 = 1;
         (void)lsq_q16_sample_rows(n, d, &rts64);
