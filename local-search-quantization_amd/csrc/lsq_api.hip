@@ -40,6 +40,12 @@ extern "C" int lsq_device_count(int *count) {
 
 enum { CAT_TABLES = 0, CAT_UNARIES, CAT_PERTURB, CAT_ICM, CAT_COST, CAT_OTHER, CAT_COUNT };
 
+// layout of the context's block of small per-call words (bytes; [0, SMALL_READ_END) is what a call zeroes and reads back)
+enum : size_t { SMALL_COUNTERS = 0, SMALL_OBJ = 8192, SMALL_BAD = 8704, SMALL_XSERR = 8768, SMALL_QP = 8832, SMALL_ACTIVE = 10240, SMALL_ROAD = 11008,
+                SMALL_READ_END = 11072, SMALL_PROBE = 11264, SMALL_BYTES = 12288 };
+static_assert(sizeof(lsq_q16_params) <= SMALL_ACTIVE - SMALL_QP && sizeof(unsigned long long) * LSQ_WALK_COUNTERS <= SMALL_ROAD - SMALL_ACTIVE &&
+              sizeof(unsigned long long) * LSQ_WALK_COUNTERS <= SMALL_BYTES - SMALL_PROBE, "the per-call block's windows");
+
 struct lsq_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -80,6 +86,9 @@ struct lsq_ctx {
     int64_t xs_min = 32768;                            // option "xs_min": smaller chunks take the block-per-range walk (schedule 6's kernels)
     int64_t xs_launches = 0;
     int64_t xs_fallback_launches = 0;                  // launches whose start barrier said no (the predicated icm_walkq_kernel launch did the work)
+    DevBuf small;                                              // one block for the small per-call words below (counters, obj, bad, xsErr, qp, active, road, probe are windows into it)
+    char *small_host = nullptr;                                // its pinned mirror
+    bool small_packed = false;                                 // this call: every window still in place (an outgrown one gets an allocation of its own)
     DevBuf Uq, Tq, qp, qscratch, qflag, qsigma;                // 16-bit filtered walk: u16 unary planes, u16 slice tables, lsq_q16_params, bound scratch, per-vector out-of-range flags
     bool chunk_q16 = false;                            // the resident chunk runs the filtered walk (set by build_unaries from the chunk's verdict)
     // option "async" (lsq_encode_icm_dev only): no host round trip inside the call and none at its end -- the chunk's road (verdict after the unary
@@ -181,6 +190,24 @@ extern "C" int lsq_create(lsq_ctx **out, int device) {
     if (e != hipSuccess) { delete c; lsq_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return LSQ_EHIP; }
     c->stream = c->own_stream;
     c->xs_dev_ok = prop.multiProcessorCount == 256;
+    // the small per-call words (counters, sums, flags, level parameters) share ONE block: a call zeroes it with one fill and reads it back with one copy into
+    // pinned memory (they were seven fills and four pageable copies of a few bytes each, 5 - 20 us apiece: a quarter of a 10 000-vector call)
+    if (hipMalloc(&c->small.p, SMALL_BYTES) != hipSuccess || hipHostMalloc(reinterpret_cast<void **>(&c->small_host), SMALL_BYTES, hipHostMallocDefault) != hipSuccess) {
+        if (c->small.p) (void)hipFree(c->small.p);
+        (void)hipStreamDestroy(c->own_stream);
+        delete c;
+        lsq_set_error("lsq_create: no memory for the per-call block");
+        return LSQ_ENOMEM;
+    }
+    c->small.cap = SMALL_BYTES;
+    c->counters.window(c->small.p, SMALL_COUNTERS, SMALL_OBJ - SMALL_COUNTERS);
+    c->obj.window(c->small.p, SMALL_OBJ, SMALL_BAD - SMALL_OBJ);
+    c->bad.window(c->small.p, SMALL_BAD, SMALL_XSERR - SMALL_BAD);
+    c->xsErr.window(c->small.p, SMALL_XSERR, SMALL_QP - SMALL_XSERR);
+    c->qp.window(c->small.p, SMALL_QP, SMALL_ACTIVE - SMALL_QP);
+    c->active.window(c->small.p, SMALL_ACTIVE, SMALL_ROAD - SMALL_ACTIVE);
+    c->road.window(c->small.p, SMALL_ROAD, SMALL_READ_END - SMALL_ROAD);
+    c->probe.window(c->small.p, SMALL_PROBE, SMALL_BYTES - SMALL_PROBE);
     *out = c;
     return LSQ_OK;
 }
@@ -194,6 +221,8 @@ extern "C" int lsq_destroy(lsq_ctx *c) {
     DevBuf *bufs[] = {&c->road, &c->xsPart, &c->xsSync, &c->xsErr, &c->probe, &c->Uq, &c->Tq, &c->qp, &c->qscratch, &c->qflag, &c->qsigma, &c->sci, &c->T, &c->Ts, &c->U, &c->vCur, &c->vNew, &c->active, &c->recCur, &c->recNew, &c->prev, &c->counters, &c->obj, &c->bad,
                       &c->sX, &c->sX2, &c->sK, &c->sB16, &c->sOut16, &c->sTight, &c->sF32, &c->sSample, &c->sSigmaS};
     for (DevBuf *b : bufs) b->release();
+    c->small.release();
+    if (c->small_host) (void)hipHostFree(c->small_host);
     for (auto e : c->panel_ev) (void)hipEventDestroy(e);
     lsq_adc_free(c->adc);
     lsq_lsqr_free(c->lsqr);
@@ -457,7 +486,7 @@ static int q16_prepare_chunk(lsq_ctx *c, const float *dX, const float *dK, int d
         LSQ_TRY(c->qsigma.ensure(sizeof(float) * (size_t)cn * m));      // per-(vector, node) unary shift: levels only (lsq_icmq.hip)
         LSQ_TRY(c->qflag.ensure(sizeof(unsigned short) * (size_t)(cn + 2)));
         LSQ_TRY(c->qp.ensure(sizeof(lsq_q16_params)));
-        if (c->new_call) LSQ_HIP(hipMemsetAsync(c->qp.p, 0, sizeof(lsq_q16_params), c->stream));      // first chunk of a call: ok = 0, oor = 0
+        if (c->new_call && !c->small_packed) LSQ_HIP(hipMemsetAsync(c->qp.p, 0, sizeof(lsq_q16_params), c->stream));      // first chunk of a call: ok = 0, oor = 0 (packed: begin_call's fill)
         c->new_call = 0;
         char *sc = c->qscratch.as<char>();
         if (Xsample) LSQ_TRY(c->sSigmaS.ensure(sizeof(float) * (size_t)nsample_rows * m));
@@ -804,14 +833,22 @@ static int begin_call(lsq_ctx *c, int64_t I, int nr) {
     LSQ_TRY(c->bad.ensure(sizeof(int)));
     LSQ_TRY(c->active.ensure(sizeof(unsigned long long) * LSQ_WALK_COUNTERS));
     LSQ_TRY(c->road.ensure(2 * sizeof(unsigned)));
+    LSQ_TRY(c->xsErr.ensure(2 * sizeof(unsigned)));
+    LSQ_TRY(c->qp.ensure(sizeof(lsq_q16_params)));
     if (!c->async_mode) LSQ_TRY(fold_pending(c));             // statistics an earlier async call left on the device (synchronises)
+    c->walk_counters = c->active.as<unsigned long long>();
+    c->call_q16_chunks = 0;
+    c->new_call = 1;
+    c->small_packed = c->counters.view && c->obj.view && c->bad.view && c->xsErr.view && c->qp.view && c->active.view && c->road.view;
+    if (c->small_packed) {
+        // one fill: counters, sums, flags, schedule-7 words, level parameters (+ the walk counters and the road words unless async calls are still accumulating)
+        LSQ_HIP(hipMemsetAsync(c->small.p, 0, c->pending_fold ? SMALL_ACTIVE : SMALL_READ_END, c->stream));
+        return LSQ_OK;
+    }
     if (!c->pending_fold) {                                  // consecutive async calls accumulate: folded by the next synchronising entry point
         LSQ_HIP(hipMemsetAsync(c->active.p, 0, sizeof(unsigned long long) * LSQ_WALK_COUNTERS, c->stream));
         LSQ_HIP(hipMemsetAsync(c->road.p, 0, 2 * sizeof(unsigned), c->stream));
     }
-    c->walk_counters = c->active.as<unsigned long long>();
-    c->call_q16_chunks = 0;
-    c->new_call = 1;
     LSQ_HIP(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long) * 2 * (size_t)std::max<int64_t>(I, 1), c->stream));
     LSQ_HIP(hipMemsetAsync(c->obj.p, 0, sizeof(double) * (size_t)std::max(nr, 1), c->stream));
     LSQ_HIP(hipMemsetAsync(c->bad.p, 0, sizeof(int), c->stream));
@@ -852,6 +889,22 @@ static int finish_call(lsq_ctx *c, int64_t I, int nr, double *obj_sums, int64_t 
         LSQ_HIP(hipMemcpyAsync(obj_sums, c->obj.p, sizeof(double) * (size_t)nr, hipMemcpyDefault, c->stream));
         if (stats) LSQ_HIP(hipMemcpyAsync(stats, c->counters.p, sizeof(unsigned long long) * 2 * (size_t)I, hipMemcpyDefault, c->stream));      // counts < 2^63: the same bits as int64
         c->pending_fold = true;
+        return LSQ_OK;
+    }
+    if (c->small_packed) {                                   // one copy of the block into pinned memory
+        LSQ_HIP(hipMemcpyAsync(c->small_host, c->small.p, SMALL_READ_END, hipMemcpyDeviceToHost, c->stream));
+        LSQ_HIP(hipStreamSynchronize(c->stream));
+        memcpy(obj_sums, c->small_host + SMALL_OBJ, sizeof(double) * (size_t)nr);
+        unsigned long long act[LSQ_WALK_COUNTERS];
+        memcpy(act, c->small_host + SMALL_ACTIVE, sizeof(act));
+        unsigned xs_err[2];
+        memcpy(xs_err, c->small_host + SMALL_XSERR, sizeof(xs_err));
+        fold_walk_counters(c, act);
+        LSQ_TRY(xs_verdict(c, xs_err));
+        if (stats) {
+            const unsigned long long *cnt = reinterpret_cast<const unsigned long long *>(c->small_host + SMALL_COUNTERS);
+            for (int64_t q = 0; q < 2 * I; ++q) stats[q] = (int64_t)cnt[q];
+        }
         return LSQ_OK;
     }
     std::vector<unsigned long long> cnt(2 * (size_t)std::max<int64_t>(I, 1));

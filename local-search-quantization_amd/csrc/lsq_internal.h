@@ -43,15 +43,18 @@ void lsq_set_error(const char *fmt, ...);
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    bool view = false;          // a window into another allocation (the context's block of small per-call words): never freed here; outgrown -> an allocation of its own
     int ensure(size_t bytes) {
         if (bytes <= cap) return LSQ_OK;
+        if (view) { p = nullptr; cap = 0; view = false; }
         if (p) { LSQ_HIP(hipFree(p)); p = nullptr; cap = 0; }
         if (bytes == 0) return LSQ_OK;
         LSQ_HIP(hipMalloc(&p, bytes));
         cap = bytes;
         return LSQ_OK;
     }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+    void release() { if (p && !view) (void)hipFree(p); p = nullptr; cap = 0; view = false; }
+    void window(void *base, size_t off, size_t bytes) { release(); p = static_cast<char *>(base) + off; cap = bytes; view = true; }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
