@@ -649,6 +649,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
             }
         }
         const uint32_t v4 = (uint32_t)v * 4u;
+        constexpr uint32_t LIST_BYTE0 = (uint32_t)(ROT ? RT::TAB_BYTES + PP * RT::KEY_BYTES : 0);      // byte address of list[] under the rotated placement
+        const int limv = q == 0 ? nact - v : -0x7fffffff;      // c0 < limv  <=>  q == 0 and c0 + v < nact: one compare per item
         // staging of a slice: global rows are [group][code][slot] (q16_row_index) -- a straight copy for a group of four tables; a group of nt < 4 tables
         // leaves 4 - nt slots of every 256-byte LDS line free
         constexpr bool GROT = (SLQ == 32 && M <= 8);          // the global layout of this geometry
@@ -680,7 +682,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
             int ci = wave * VPW + lit * step + v;
             ci = ci < nact ? ci : nact - 1;
             uint32_t li = (uint32_t)ci;
-            if (!dense) li = list[ci];
+            if (!dense) {
+                if constexpr (ROT) li = *reinterpret_cast<lds_u16 *>(LIST_BYTE0 + 2u * (uint32_t)ci);      // (LDS by number: no segment-base add)
+                else li = list[ci];
+            }
 #ifdef LSQ_TUNING
             const uint32_t uo = ((abl & 32) ? (li & 63u) : li) * (uint32_t)(SLQ * 2) + (uint32_t)q * 16u;      // ablation: the level stream from L2 instead of HBM
 #else
@@ -799,7 +804,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
             l0 += base; h0 += base;                                          // candidate < 256: never carries into the level
             if (LPV >= 2) top2_merge(l0, h0, dpp_u32<DPP_XOR1>(l0), dpp_u32<DPP_XOR1>(h0));
             if (LPV >= 4) top2_merge(l0, h0, dpp_u32<DPP_XOR2>(l0), dpp_u32<DPP_XOR2>(h0));
-            if ((q == 0) & (c0 + v < nact)) {
+            if (c0 < limv) {                                 // the vector's first lane, vector c0 + v inside the active list
                 if constexpr (HOLE) {      // c0 is a multiple of 16 and v < 16: the smallest key of vector c0 + v sits at byte 16 c0 + 4 v of the free slot
                     const uint32_t sA = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)RT::HOLE_BYTE0 + (uint32_t)c0 * 16u));      // scalar parts: one add per address
                     const uint32_t sB = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)RT::TAB_BYTES + (uint32_t)c0 * 4u));
@@ -1230,6 +1235,15 @@ static int launch_walkq_t(hipStream_t s, const float *U, const uint16_t *Uq, con
     const int skip = (use_skip && valid) ? 1 : 0;
     static LdsOptIn optin;
     LSQ_TRY(optin_lds(optin, &icm_walkq_kernel<M, SLQ, CPL, DEPTH, NT, BPC>, LDS_BYTES));
+    if (ROT) {      // the rotated placement addresses LDS by number: the kernel must have been compiled without static LDS (it also traps at entry otherwise)
+        static int static_lds = -1;
+        if (static_lds < 0) {
+            hipFuncAttributes fa;
+            LSQ_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&icm_walkq_kernel<M, SLQ, CPL, DEPTH, NT, BPC>)));
+            static_lds = (int)fa.sharedSizeBytes;
+        }
+        if (static_lds != 0) { lsq_set_error("icm_walkq_kernel<%d>: %d bytes of static LDS in a kernel that addresses LDS from 0", M, static_lds); return LSQ_EHIP; }
+    }
     const unsigned grid = (unsigned)(npass < NBLK ? npass : NBLK);
     hipLaunchKernelGGL((icm_walkq_kernel<M, SLQ, CPL, DEPTH, NT, BPC>), dim3(grid), dim3(NT), LDS_BYTES, s, U, Uq, Tq, T, rec, valid, n, nodes, per_pass, skip,
                        direct_max, active_total, skip ? ref_rec : nullptr, skip ? ref_valid : nullptr, P, lsq_walk_slice_width(M), qflag, LSQ_KNOB("LSQ_Q16_ABL", 0), gate

@@ -12,6 +12,7 @@ namespace {
 // LDS addressed by number (address space 3 pointers made from integers)
 typedef const u32x4 __attribute__((address_space(3))) lds_cu32x4;
 typedef uint32_t __attribute__((address_space(3))) lds_u32;
+typedef const unsigned short __attribute__((address_space(3))) lds_u16;
 typedef char __attribute__((address_space(3))) lds_char;
 
 
