@@ -30,6 +30,8 @@
 
 #include <type_traits>
 
+#include <atomic>
+
 #include "lsq_q16.h"
 #ifdef LSQ_TUNING
 #include "lsq_cost.h"      // the fused cost phase (tuning build only)
@@ -711,9 +713,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
             for (int r = 0; r < NR; ++r) s[r] = cur.u[r];
             // The two 16-bit halves of a word never carry into each other (the sum of the m levels of a candidate stays below 65536: lsq_q16_node::hiq),
             // so plain 32-bit adds are exact on the packed levels -- and v_add3_u32 takes two table rows per instruction where v_pk_add_u16 takes one.
-            uint32_t code[M > 1 ? M - 1 : 1];
+            uint32_t code[M > 1 ? M - 1 : 1];                // (plain placement only)
 #pragma unroll
-            for (int w = 0; w < CW; ++w) {
+            for (int w = 0; w < (ROT ? 0 : CW); ++w) {
                 const uint32_t hiw = (w + 1 < RW) ? cur.r[w + 1] : 0u;
                 const uint32_t cw = __builtin_amdgcn_perm(hiw, cur.r[w], sel[w]);
 #pragma unroll
@@ -1236,11 +1238,13 @@ static int launch_walkq_t(hipStream_t s, const float *U, const uint16_t *Uq, con
     static LdsOptIn optin;
     LSQ_TRY(optin_lds(optin, &icm_walkq_kernel<M, SLQ, CPL, DEPTH, NT, BPC>, LDS_BYTES));
     if (ROT) {      // the rotated placement addresses LDS by number: the kernel must have been compiled without static LDS (it also traps at entry otherwise)
-        static int static_lds = -1;
+        static std::atomic<int> static_lds_known{-1};      // (lsq_multi_* runs one host thread per device through here)
+        int static_lds = static_lds_known.load(std::memory_order_relaxed);
         if (static_lds < 0) {
             hipFuncAttributes fa;
             LSQ_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&icm_walkq_kernel<M, SLQ, CPL, DEPTH, NT, BPC>)));
             static_lds = (int)fa.sharedSizeBytes;
+            static_lds_known.store(static_lds, std::memory_order_relaxed);
         }
         if (static_lds != 0) { lsq_set_error("icm_walkq_kernel<%d>: %d bytes of static LDS in a kernel that addresses LDS from 0", M, static_lds); return LSQ_EHIP; }
     }

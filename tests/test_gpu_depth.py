@@ -171,3 +171,18 @@ def test_every_codebook_count_through_the_filtered_walk(lsq, oracle, m):
     assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0)
     if m > 1:
         assert tm["filtered_blocks"] > 0 and tm["light_blocks"] == 0, tm
+
+
+def test_more_ils_iterations_than_the_per_call_block_holds(lsq, oracle):
+    """The per-call words (counters, sums, flags) live in one 12 KB block whose counter window holds 512 ILS iterations; a longer call gives the counters an
+    allocation of their own and goes back to separate fills / copies.  600 iterations on a small problem: codes, objective and the per-iteration counters against
+    the oracle, then a short call on the same context (the window must not be used half-way)."""
+    from conftest import make_problem
+    d, n, m, J, npert, seed = 16, 300, 4, 2, 2, 9
+    X, K, B0 = make_problem(d, n, m, seed=21, kind="gauss")
+    with lsq.Engine(0) as eng:
+        for ils in ([600], [3]):
+            ref, objs_ref = oracle.encode_icm(X, B0, K, m, H, ils, J, npert, True, seed)
+            Bs, objs = eng.encode_icm(X, B0, K, m, ils, J, npert, True, seed=seed)
+            assert np.array_equal(Bs, ref), "ils = %s: %d codes differ" % (ils, (Bs != ref).sum())
+            assert np.allclose(objs, objs_ref, rtol=1e-5, atol=0)
