@@ -59,8 +59,8 @@ PMC_GLOB = "r[0-9][0-9]*_pmc_per_kernel.json"      # committed PMC passes; `traf
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=3)
-    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--vectors", dest="n", type=int, default=1_000_000, help="vectors per GPU (weak scaling)")
     p.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     p.add_argument("--total", type=int, default=1_000_000, help="strong scaling: total vectors, split with splitarray over the ranks")
