@@ -35,4 +35,4 @@ with lsq.Engine(0, profile=True, tuning=bool(tuning)) as eng:
     print(json.dumps(dict(n=n, d=d, m=m, tuning=tuning, opts=opts, knobs=knobs, ms=round(dt * 1e3, 3), Mvps=round(n / dt / 1e6, 3),
                           icm_ms=round(tm["icm_ms"] / steps, 3), unaries_ms=round(tm["unaries_ms"] / steps, 3), cost_ms=round(tm["cost_ms"] / steps, 3),
                           tables_ms=round(tm["tables_ms"] / steps, 3), light=tm["light_blocks"] // steps, filtered=tm["filtered_blocks"] // steps,
-                          staged=tm["staged_blocks"] // steps, obj=float(sums[0] / n), codes_sum=int(out.to(torch.int64).sum().item()))), flush=True)
+                          staged=tm["staged_blocks"] // steps, node_updates_per_launch=tm["icm_node_updates"] / max(tm["icm_launches"], 1), obj=float(sums[0] / n), codes_sum=int(out.to(torch.int64).sum().item()))), flush=True)
