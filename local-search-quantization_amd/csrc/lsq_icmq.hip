@@ -371,7 +371,7 @@ template <int M, int SLQ, int NT>
 __device__ inline int q16_refine(const float *__restrict__ U, const uint16_t *__restrict__ Uq, const uint16_t *__restrict__ Tq,
                                  const float *__restrict__ T, uint8_t *__restrict__ rec, unsigned short *__restrict__ valid,
                                  const uint8_t *__restrict__ ref_rec, const unsigned short *__restrict__ ref_valid, int64_t n, int j,
-                                 int64_t lo, const unsigned short *list, const uint32_t *arec, int namb, int SLF, int abl, unsigned short *vmir) {
+                                 int64_t lo, const unsigned short *list, const uint32_t *arec, int namb, int SLF, int abl, unsigned short *vmir, bool list_hole = false) {      // list_hole: 16 entries in every 128 (WalkqRot::LHOLE)
     constexpr int CS = (M <= 8) ? 8 : 16;
     constexpr int RW = CS / 4;
     constexpr int AREC = 2 + RW;
@@ -396,7 +396,7 @@ __device__ inline int q16_refine(const float *__restrict__ U, const uint16_t *__
 #pragma unroll
         for (int w2 = 0; w2 < RW; ++w2) rw[w2] = ar[2 + w2];
         const int ci = (int)(key & 0xffffu), a1 = (int)((key >> 16) & 0xffu), a2 = (int)(key >> 24);
-        const int64_t i = lo + list[ci];
+        const int64_t i = lo + (list_hole ? list[((ci >> 4) << 7) + (ci & 15)] : list[ci]);
         // ---- the one round trip: unary levels, table levels, bookkeeping (lane 0), speculative exact terms (one per lane)
         const u32x4 *up = reinterpret_cast<const u32x4 *>(Uqj + ((int64_t)sl * n + ((abl & 2) ? (int64_t)0 : i)) * SLQ + off);
         u32x4 s0 = (u32x4){0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, s1 = s0;
@@ -573,17 +573,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
         if ((uint32_t)(uintptr_t)(lds_char *)lds_walkq != 0u) __builtin_trap();      // the rotated placement addresses LDS by number: the segment must start at 0
     }
     u32x4 *tab = lds_walkq;
-    constexpr bool HOLE = ROT && RT::HOLE;                                                       // bestA in the free slot of the table's second group
+    constexpr bool HOLE = ROT && RT::HOLE;                                                       // bestA in the free slot of the table's second group (m <= 8)
+    constexpr bool LHOLE = ROT && RT::LHOLE;                                                     // the active list in the free slot of the second group (m > 8)
+    constexpr bool ROT8 = ROT && M <= 8, ROT16 = ROT && M > 8;
     constexpr int TABE = ROT ? RT::TAB_BYTES / 16 : LTAB;
     uint32_t *bestA = HOLE ? reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(lds_walkq) + RT::HOLE_BYTE0)
                            : reinterpret_cast<uint32_t *>(lds_walkq + TABE);                     // [PP] smallest key (Q << 16 | candidate); HOLE: 16 words in every 64 (keyA())
     uint32_t *bestB = HOLE ? reinterpret_cast<uint32_t *>(lds_walkq + TABE) : bestA + PP;        // [PP] second smallest key
-    unsigned short *list = reinterpret_cast<unsigned short *>(bestB + PP);                     // [PP] active local indices
+    unsigned short *list = LHOLE ? reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(lds_walkq) + RT::HOLE_BYTE0)
+                                 : reinterpret_cast<unsigned short *>(bestB + PP);             // [PP] active local indices; LHOLE: 16 entries in every 128 (listp())
+    auto listp = [&](int i) -> unsigned short * { return LHOLE ? list + ((i >> 4) << 7) + (i & 15) : list + i; };
     constexpr bool MIRROR = ROT ? RT::mirror() : TL::mirror(M, BPC);
     auto keyA = [&](int ci) -> uint32_t * { return HOLE ? bestA + ((ci >> 4) << 6) + (ci & 15) : bestA + ci; };
     // the f32-path list (16-bit entries) reuses bestA's storage after the decide phase has read the keys
     auto f32slot = [&](int i) -> unsigned short * { return reinterpret_cast<unsigned short *>(keyA(i >> 1)) + (i & 1); };
-    unsigned short *vmir = (MIRROR && valid) ? list + PP : nullptr;                              // [PP] mirror of valid[lo ..): read by the compaction, written with every store to valid[]
+    unsigned short *vmir = (MIRROR && valid) ? list + PP : nullptr;      // (never with LHOLE)                              // [PP] mirror of valid[lo ..): read by the compaction, written with every store to valid[]
     int *wave_tot = misc;                                // [16]
     int &nact_s = misc[16];
     int &redo_s = misc[17];
@@ -634,7 +638,28 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
         // (slot (t + v) mod tables-of-the-group, table kk = 4 group + slot, code k = kk + (kk >= j)); base0 / base1 hold the matching slot | lane_q address bytes
         // (byte 3 of base1 = 1: the second group starts at 65536).
         uint32_t selC0 = 0x0c0c0c0cu, selC1 = 0x0c0c0c0cu, base0 = 0u, base1 = 0x01000000u;
-        if constexpr (ROT) {
+        // m > 8: the record's 15 code bytes are first compressed (the node's own code dropped: sel[], uniform) into four words; rotA / rotB (rot1A / rot1B) then pick
+        // group 0's (group 1's) bytes in the lane's read order -- the t-th read of a group goes to slot (t + v) mod tables-of-the-group -- and b0a .. b1b hold the
+        // matching slot | lane_q address bytes.  Group 1 is addressed as (line + slot + 16 bytes) + 0xfff0: its base 65536 does not fit the 16-bit offset field.
+        uint32_t rotA = 0x0c0c0c0cu, rotB = 0x0c0c0c0cu, rot1A = 0x0c0c0c0cu, rot1B = 0x0c0c0c0cu, b0a = 0u, b0b = 0u, b1a = 0u, b1b = 0u;
+        if constexpr (ROT16) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (t < RT::NT0) {
+                    const uint32_t slot = (uint32_t)(t + v) % (uint32_t)RT::NT0;
+                    const uint32_t ab = ((slot << 5) | ((uint32_t)q << 4)) << (8 * (t & 3));
+                    if (t < 4) { rotA = (rotA & ~(0xffu << (8 * t))) | (slot << (8 * t)); b0a |= ab; }
+                    else { rotB = (rotB & ~(0xffu << (8 * (t - 4)))) | (slot << (8 * (t - 4))); b0b |= ab; }
+                }
+                if (t < RT::NT1) {
+                    const uint32_t slot = (uint32_t)(t + v) % (uint32_t)(RT::NT1 ? RT::NT1 : 1);
+                    const uint32_t ab = ((slot << 5) + (((uint32_t)q + 1u) << 4)) << (8 * (t & 3));
+                    if (t < 4) { rot1A = (rot1A & ~(0xffu << (8 * t))) | (slot << (8 * t)); b1a |= ab; }
+                    else { rot1B = (rot1B & ~(0xffu << (8 * (t - 4)))) | (slot << (8 * (t - 4))); b1b |= ab; }
+                }
+            }
+        }
+        if constexpr (ROT8) {
 #pragma unroll
             for (int t = 0; t < RT::NT0; ++t) {
                 const uint32_t slot = (uint32_t)(t + v) % (uint32_t)(RT::NT0 ? RT::NT0 : 1);
@@ -651,17 +676,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
             }
         }
         const uint32_t v4 = (uint32_t)v * 4u;
-        constexpr uint32_t LIST_BYTE0 = (uint32_t)(ROT ? RT::TAB_BYTES + PP * RT::KEY_BYTES : 0);      // byte address of list[] under the rotated placement
+        constexpr uint32_t LIST_BYTE0 = (uint32_t)(ROT && !LHOLE ? RT::TAB_BYTES + PP * RT::KEY_BYTES : 0);      // byte address of list[] under the rotated placement
         const int limv = q == 0 ? nact - v : -0x7fffffff;      // c0 < limv  <=>  q == 0 and c0 + v < nact: one compare per item
         // staging of a slice: global rows are [group][code][slot] (q16_row_index) -- a straight copy for a group of four tables; a group of nt < 4 tables
         // leaves 4 - nt slots of every 256-byte LDS line free
-        constexpr bool GROT = (SLQ == 32 && M <= 8);          // the global layout of this geometry
+        constexpr bool GROT = (SLQ == 32 && M <= 8) || (SLQ == 16 && M > 8);          // the global layout of this geometry
         auto rot_entry = [&](auto R_) -> int {
             constexpr int r = decltype(R_)::value;
-            constexpr int g = r >= RT::NT0 ? 1 : 0, nt = g ? RT::NT1 : RT::NT0, e0 = (r - g * RT::NT0) * NT;
+            constexpr int g = r * NT >= RT::G0_ENTRIES ? 1 : 0, nt = g ? RT::NT1 : RT::NT0, e0 = r * NT - g * RT::G0_ENTRIES;      // (group 0 is a whole number of rounds)
             const int eg = e0 + (int)threadIdx.x;             // entry inside the group
-            if constexpr (nt == 4) return g * 4096 + eg;
-            else { const int code = eg / (4 * (nt ? nt : 1)); return g * 4096 + code * 16 + (eg - code * 4 * nt); }
+            if constexpr (nt == RT::SPL) return g * 4096 + eg;
+            else { const int code = eg / (RT::EPS * (nt ? nt : 1)); return g * 4096 + code * 16 + (eg - code * RT::EPS * nt); }
         };
         auto prefetch_tab = [&](int sl) {
             const u32x4 *src = reinterpret_cast<const u32x4 *>(Tqj) + (int64_t)sl * TAB;
@@ -685,8 +710,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
             ci = ci < nact ? ci : nact - 1;
             uint32_t li = (uint32_t)ci;
             if (!dense) {
-                if constexpr (ROT) li = *reinterpret_cast<lds_u16 *>(LIST_BYTE0 + 2u * (uint32_t)ci);      // (LDS by number: no segment-base add)
-                else li = list[ci];
+                if constexpr (ROT && !LHOLE) li = *reinterpret_cast<lds_u16 *>(LIST_BYTE0 + 2u * (uint32_t)ci);      // (LDS by number: no segment-base add)
+                else li = *listp(ci);
             }
 #ifdef LSQ_TUNING
             const uint32_t uo = ((abl & 32) ? (li & 63u) : li) * (uint32_t)(SLQ * 2) + (uint32_t)q * 16u;      // ablation: the level stream from L2 instead of HBM
@@ -727,7 +752,48 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
                     }
                 }
             }
-            if constexpr (ROT) {
+#ifdef LSQ_TUNING
+            if (!ROT && (abl & 1024)) {                      // timing only: rows whose bank position depends on the vector's place in the wave, not on its codes (no conflicts)
+#pragma unroll
+                for (int kk = 0; kk < M - 1; ++kk) code[kk] = (code[kk] & ~(uint32_t)(64 / (LPV * 16) * 4 - 1)) | (uint32_t)((v + kk) & (256 / (LPV * 16) - 1));
+            }
+#endif
+            if constexpr (ROT16) {
+                uint32_t dw[4] = {0u, 0u, 0u, 0u};               // the compressed code bytes kk = 0 .. m - 2
+#pragma unroll
+                for (int w = 0; w < CW; ++w) dw[w] = __builtin_amdgcn_perm((w + 1 < RW) ? cur.r[w + 1] : 0u, cur.r[w], sel[w]);
+                const uint32_t cw4[4] = {__builtin_amdgcn_perm(dw[1], dw[0], rotA), __builtin_amdgcn_perm(dw[1], dw[0], rotB),
+                                         __builtin_amdgcn_perm(dw[3], dw[2], rot1A), __builtin_amdgcn_perm(dw[3], dw[2], rot1B)};
+                const uint32_t bw4[4] = {b0a, b0b, b1a, b1b};
+                // four reads at a time (16 registers in flight), summed before the next four are requested
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int cnt = g4 < 2 ? (RT::NT0 - 4 * g4 < 4 ? RT::NT0 - 4 * g4 : 4) : (RT::NT1 - 4 * (g4 - 2) < 4 ? RT::NT1 - 4 * (g4 - 2) : 4);
+                    if (cnt <= 0) continue;
+                    u32x4 rd[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (t < cnt) {
+                            const uint32_t a = __builtin_amdgcn_perm(cw4[g4], bw4[g4], 0x0c0c0400u + 0x0101u * (uint32_t)t);      // [slot | lane_q] [code] [0] [0]
+                            rd[t] = *reinterpret_cast<lds_cu32x4 *>(a + (g4 < 2 ? 0u : 0xfff0u));
+                        }
+#ifdef LSQ_TUNING
+                    if (!(abl & 64))
+#endif
+                    {
+#pragma unroll
+                        for (int t = 0; t < 4; t += 2) {
+                            if (t + 1 < cnt) {
+                                s[0].x = s[0].x + rd[t].x + rd[t + 1].x; s[0].y = s[0].y + rd[t].y + rd[t + 1].y;
+                                s[0].z = s[0].z + rd[t].z + rd[t + 1].z; s[0].w = s[0].w + rd[t].w + rd[t + 1].w;
+                            } else if (t < cnt) {
+                                s[0].x += rd[t].x; s[0].y += rd[t].y; s[0].z += rd[t].z; s[0].w += rd[t].w;
+                            }
+                        }
+                    }
+                    if (g4 < 3) asm volatile("" : "+v"(s[0].x), "+v"(s[0].y), "+v"(s[0].z), "+v"(s[0].w) : : "memory");
+                }
+            } else if constexpr (ROT8) {
                 u32x4 rd[M > 1 ? M - 1 : 1];
                 const uint32_t c0r = __builtin_amdgcn_perm(cur.r[1], cur.r[0], selC0);
                 // LDS addresses as plain numbers (the segment starts at 0, checked at kernel entry): through the segment's symbol every read pays an add of its base
@@ -828,7 +894,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
             if (slice < 8) DBG_STAMP(3 + slice);
 #endif
             if constexpr (ROT) {
-                static_for<NST>([&](auto R_) { tab[rot_entry(R_)] = nxt[decltype(R_)::value]; });
+                static_for<NST>([&](auto R_) {
+                    constexpr int r = decltype(R_)::value;
+                    if ((r + 1) * NT <= TAB || r * NT + (int)threadIdx.x < TAB) tab[rot_entry(R_)] = nxt[r];      // (only the last round can be short)
+                });
             } else {
 #pragma unroll
                 for (int r = 0; r < NST; ++r) {
@@ -929,7 +998,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
                 int pos = wbase + inc - c;
 #pragma unroll
                 for (int e = 0; e < EPT; ++e)
-                    if (f[e]) list[pos++] = (unsigned short)(base + e);
+                    if (f[e]) *listp(pos++) = (unsigned short)(base + e);
                 if (threadIdx.x == NT - 1) { nact_s = wbase + inc; redo_s = 0; f32_s = 0; }
                 __syncthreads();
             }
@@ -945,7 +1014,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
                 stat_s[4 + ((nodes.pos0 + nu) & (LSQ_WALK_TRACE - 1))] += (unsigned)nact;
             }
             if (nact <= direct_max) {                      // light block: full f32 gathers from L2, no staging
-                light_list(j, nact, [&](int r) { return list[r]; });
+                light_list(j, nact, [&](int r) { return *listp(r); });
                 __syncthreads();
                 continue;
             }
@@ -981,7 +1050,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
                     for (int w2 = 0; w2 < RW; ++w2) { rw[e][w2] = 0; rr[e][w2] = 0; }
                     if (ci < nact) {
                         kA[e] = *keyA(ci); kB[e] = bestB[ci];
-                        vi[e] = lo + list[ci];
+                        vi[e] = lo + *listp(ci);
                         fl[e] = qflag[vi[e]];
                         if constexpr (ONE_TRIP) {
 #pragma unroll
@@ -1063,10 +1132,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
             DBG_STAMP(12);
             // ---- exact refinement of the ambiguous vectors
             const int namb = redo_s < ACAP ? redo_s : ACAP;
-            int nexact = q16_refine<M, SLQ, NT>(U, Uq, Tq, T, rec, valid, ref_rec, ref_valid, n, j, lo, list, bestB, namb, SLF, abl, vmir);
+            int nexact = q16_refine<M, SLQ, NT>(U, Uq, Tq, T, rec, valid, ref_rec, ref_valid, n, j, lo, list, bestB, namb, SLF, abl, vmir, LHOLE);
             {   // vectors outside the sampled level range: one wave each, in full f32
                 const int nf32 = f32_s;
-                light_list(j, nf32, [&](int r) { return list[*f32slot(r)]; });
+                light_list(j, nf32, [&](int r) { return *listp(*f32slot(r)); });
                 if (threadIdx.x == 0 && nf32) atomicAdd(&stat_s[4 + LSQ_WALK_TRACE + 2], (unsigned)nf32);
             }
             {

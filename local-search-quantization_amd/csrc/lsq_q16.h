@@ -85,24 +85,31 @@ struct WalkqTab {
 // one v_perm_b32 builds an address from the (rotated) code bytes and a lane constant holding the four slot | lane_q bytes -- 9 VALU instructions per item for
 // the seven addresses instead of 16 (extract, shift-add).  With 5..7 tables the free slot 3 of group 1 (64 bytes in every 256) holds the smallest keys
 // (bestA: word ci at line ci / 16, 16 words per line), so the table costs no more LDS than the plain placement: 128 KiB + 8 bytes per vector.
+// Above m = 8 (slices of 16 candidates, two lanes of 16 bytes per vector: 32-byte rows) a line holds EIGHT slots: group 0 = tables 0..7, group 1 = tables 8..m-2
+// (at most seven: slot 7 of its lines is free and holds the active list, 16 entries per line); the eight vectors of a 16-lane group read eight different slots.
 template <int M>
 struct WalkqRot {
     static constexpr int NTAB = M - 1;
-    static constexpr int NT0 = NTAB < 4 ? NTAB : 4, NT1 = NTAB - NT0;                      // tables of group 0 / group 1
+    static constexpr int SPL = M <= 8 ? 4 : 8;                                               // slots per 256-byte line
+    static constexpr int SLOT_BYTES = 256 / SPL, EPS = SLOT_BYTES / 16;                      // bytes / 16-byte entries per slot (= per table row of a slice)
+    static constexpr int NT0 = NTAB < SPL ? NTAB : SPL, NT1 = NTAB - NT0;                    // tables of group 0 / group 1
     static constexpr int NG = NT1 > 0 ? 2 : (NT0 > 0 ? 1 : 0);
     static constexpr int TAB_BYTES = NG * 65536;
-    static constexpr bool HOLE = NT1 > 0;                                                    // bestA lives in slot 3 of group 1
-    static constexpr int HOLE_BYTE0 = 65536 + 192;
+    static constexpr int G0_ENTRIES = NT0 * LSQ_H * EPS;                                     // 16-byte entries of group 0 (global and LDS)
+    static constexpr bool HOLE = M <= 8 && NT1 > 0;                                          // m <= 8: bestA lives in slot 3 of group 1
+    static constexpr bool LHOLE = M > 8 && NT1 > 0;                                          // m > 8: the active list lives in slot 7 of group 1
+    static constexpr int HOLE_BYTE0 = 65536 + 256 - SLOT_BYTES;
     static constexpr int pp_for(int bytes_per_vector) {
         const int avail = 160 * 1024 - 768 - TAB_BYTES;
         const int v = avail / bytes_per_vector / 64 * 64;
         return v > 4096 ? 4096 : v;
     }
     static constexpr int KEY_BYTES = HOLE ? 4 : 8;                                           // per vector outside the table: bestB (+ bestA)
+    static constexpr int LIST_BYTES = LHOLE ? 0 : 2;                                         // ... and the active list
     // validity mirror (2 bytes per vector, see WalkqTab::mirror): kept where a block pass still holds 10^6 / 256 vectors (BASELINE configs[1] in one pass)
-    static constexpr bool mirror() { return pp_for(KEY_BYTES + 4) * 256 >= 1000000; }
-    static constexpr int pp() { return mirror() ? pp_for(KEY_BYTES + 4) : pp_for(KEY_BYTES + 2); }
-    static constexpr int lds_bytes() { return TAB_BYTES + pp() * (KEY_BYTES + 2 + (mirror() ? 2 : 0)); }
+    static constexpr bool mirror() { return M <= 8 && pp_for(KEY_BYTES + LIST_BYTES + 2) * 256 >= 1000000; }
+    static constexpr int pp() { return pp_for(KEY_BYTES + LIST_BYTES + (mirror() ? 2 : 0)); }
+    static constexpr int lds_bytes() { return TAB_BYTES + pp() * (KEY_BYTES + LIST_BYTES + (mirror() ? 2 : 0)); }
 };
 
 template <int N, class F, int I = 0>
@@ -111,18 +118,20 @@ __device__ inline void static_for(F &&f) {
 }
 
 // Row (kk, code) of a slice table in GLOBAL memory, in rows of SLQ levels.  Slices of 32 candidates up to m = 8 are stored as the LDS image of the rotated
-// placement without its free slot -- [group][code][slot] -- so that a slice is staged by a straight, fully coalesced copy; every other geometry keeps [kk][code].
+// placement without its free slot -- [group][code][slot] -- so that a slice is staged by a straight, fully coalesced copy; so are slices of 16 above m = 8
+// (eight slots per line); every other geometry keeps [kk][code].
 template <int SLQ>
 __host__ __device__ inline int q16_row_index(int m, int kk, int code) {
-    if (SLQ == 32 && m <= 8) {
-        const int nt0 = m - 1 < 4 ? m - 1 : 4, g = kk >= 4 ? 1 : 0;
-        return g ? nt0 * LSQ_H + code * (m - 1 - nt0) + (kk - 4) : code * nt0 + kk;
+    if ((SLQ == 32 && m <= 8) || (SLQ == 16 && m > 8)) {
+        const int spl = SLQ == 32 ? 4 : 8;
+        const int nt0 = m - 1 < spl ? m - 1 : spl, g = kk >= spl ? 1 : 0;
+        return g ? nt0 * LSQ_H + code * (m - 1 - nt0) + (kk - spl) : code * nt0 + kk;
     }
     return kk * LSQ_H + code;
 }
 
 // which geometry takes the rotated-rows placement
-constexpr bool walkq_rot(int m, int slq, int cpl, int nt, int bpc) { return m <= 8 && slq == 32 && cpl == 8 && nt == 1024 && bpc == 1; }
+constexpr bool walkq_rot(int m, int slq, int cpl, int nt, int bpc) { return ((m <= 8 && slq == 32) || (m > 8 && slq == 16)) && cpl == 8 && nt == 1024 && bpc == 1; }
 
 
 }  // namespace
