@@ -52,7 +52,20 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (~6.3 TB/s achievable)
 HBM_ACHIEVABLE_GBS = 6300.0
 LDS_PEAK_GBS = 150000.0        # same guide, section LDS: ds_read_b64/b128 aggregate with every CU streaming (reproduced: profiles/r05_ubench_lds.txt)
-LDS_PATTERN_GBS = LDS_PEAK_GBS / 2.125      # 16 random 64-byte rows per ds_read_b128 (four per 16-lane group): E[max rows per bank quarter] = 2.125 cycles per group
+LDS_PATTERN_GBS = LDS_PEAK_GBS / 2.125      # 16 random 64-byte rows per ds_read_b128 (four per 16-lane group): E[max rows per bank quarter] = 2.125 cycles per group (the ADC scan; the walk before its rotated placement)
+
+
+def walk_conflict_factor(m):
+    """LDS cycles per 16-lane group and table read of the filtered walk's ROTATED slice table (lsq_q16.h, WalkqRot): a line holds spl slots (4 up to m = 8, 8 above);
+    the reads of a full group of spl tables are conflict-free, a group of nt < spl tables rotates modulo nt: ceil(spl / nt) vectors share a slot."""
+    ntab = m - 1
+    if ntab <= 0:
+        return 1.0
+    spl = 4 if m <= 8 else 8
+    nt0 = min(spl, ntab)
+    nt1 = ntab - nt0
+    cyc = nt0 * -(-spl // nt0) + (nt1 * -(-spl // nt1) if nt1 else 0)
+    return cyc / ntab
 PMC_GLOB = "r[0-9][0-9]*_pmc_per_kernel.json"      # committed PMC passes; `traffic` is read from the newest one whose build hash matches
 
 
@@ -530,6 +543,7 @@ def main():
         total_nu = n * args.ils * args.icmiter * m           # node updates one step resolves on this rank
         m1_bytes = n * (4 * d + 2 * m + 2 * m + 4 + 4 * m * h + 4 * m * h + 4 * d)      # SURVEY 8(d) model M1 per step
         step_s = dt / args.steps
+        walk_ceiling = LDS_PEAK_GBS / walk_conflict_factor(m)      # the filtered walk's own pattern (schedule 6; the f32 walk and schedule 7 keep plain rows)
         roof = {
             "kernel": ("icm_walkq_kernel<%d,SLQ> (16-bit filtered walk, exact f32 refinement)" if filtered else "icm_walk_kernel<%d,SL> (f32 walk)") % m,
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -552,10 +566,13 @@ def main():
                          "m1_compulsory.  The filtered walk's slice loop was bound by VALU issue (removing every LDS read changed nothing, removing VALU work shortened it); after the instruction-count work of round 2 its measured traffic moves at ~5.1 TB/s of the ~6.3 TB/s a streaming kernel reaches on this part (traffic_rate below): the launch is HBM-bound on the bytes it creates, 1.5x the algorithmic ones (DESIGN 4.2).",
             "gather": {"achieved": table_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0, "peak": LDS_PEAK_GBS, "unit": "GB/s",
                        "frac": (table_bytes / avg_launch_s / 1e9 / LDS_PEAK_GBS) if avg_launch_s > 0 else 0.0,
-                       "pattern_ceiling": LDS_PATTERN_GBS,
-                       "frac_of_pattern_ceiling": (table_bytes / avg_launch_s / 1e9 / LDS_PATTERN_GBS) if avg_launch_s > 0 else 0.0,
+                       "pattern_ceiling": walk_ceiling,
+                       "frac_of_pattern_ceiling": (table_bytes / avg_launch_s / 1e9 / walk_ceiling) if avg_launch_s > 0 else 0.0,
+                       "conflict_factor": walk_conflict_factor(m),
                        "note": "(m-1) pair-table rows per recomputed node update (512 B each as u16 levels, 1 KiB as f32), read from LDS-staged slices with "
-                               "ds_read_b128 (16 random 64-byte rows per wave read: ~2.1-way bank conflicts are intrinsic to the lookup); peak = guide's aggregate"},
+                               "ds_read_b128; rotated placement (round 5): the vectors of a 16-lane group read different slots of their 256-byte lines -- conflict-free "
+                               "for a full group of tables, ceil(slots / tables) cycles for the short second group; pattern_ceiling = 150 TB/s / conflict_factor "
+                               "(the plain placement of earlier rounds: / 2.125)"},
             "m1_compulsory": {"bytes_per_step": m1_bytes, "achieved": m1_bytes / step_s / 1e9, "unit": "GB/s",
                               "frac": m1_bytes / step_s / 1e9 / HBM_PEAK_GBS,
                               "note": "SURVEY 8(d) model M1 (X once, codes in/out, unaries written once and read once, X re-read for the cost) / whole step time"},
@@ -565,9 +582,10 @@ def main():
         roof["utilisation"] = util
         if util["lds"] > util["hbm"]:
             roof.update({"bound": "lds", "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "frac": achieved / HBM_PEAK_GBS},
-                         "achieved": roof["gather"]["achieved"], "peak": LDS_PATTERN_GBS, "frac": util["lds"],
-                         "bound_note": "m = %d: %d table rows per node update -- the LDS gathers run closer to their ceiling (150 TB/s / 2.125 for 16 random 64-byte rows per "
-                                       "ds_read_b128) than the level stream to HBM's; achieved / peak / frac are the gather's, the HBM figures are under `hbm`" % (m, m - 1)})
+                         "achieved": roof["gather"]["achieved"], "peak": walk_ceiling, "frac": util["lds"],
+                         "bound_note": "m = %d: %d table rows per node update -- the LDS gathers run closer to their ceiling (150 TB/s / %.3f: the rotated placement's "
+                                       "conflict factor) than the level stream to HBM's; achieved / peak / frac are the gather's, the HBM figures are under `hbm`"
+                                       % (m, m - 1, walk_conflict_factor(m))})
         tr = pmc_traffic(lib_sha)
         if tr is not None:
             roof["traffic"] = tr["bytes_per_icm_launch"]
