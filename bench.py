@@ -543,7 +543,7 @@ def main():
         total_nu = n * args.ils * args.icmiter * m           # node updates one step resolves on this rank
         m1_bytes = n * (4 * d + 2 * m + 2 * m + 4 + 4 * m * h + 4 * m * h + 4 * d)      # SURVEY 8(d) model M1 per step
         step_s = dt / args.steps
-        walk_ceiling = LDS_PEAK_GBS / walk_conflict_factor(m)      # the filtered walk's own pattern (schedule 6; the f32 walk and schedule 7 keep plain rows)
+        walk_ceiling = LDS_PEAK_GBS / walk_conflict_factor(m)      # the filtered walk's own pattern (schedule 6; the f32 walk keeps plain rows)
         roof = {
             "kernel": ("icm_walkq_kernel<%d,SLQ> (16-bit filtered walk, exact f32 refinement)" if filtered else "icm_walk_kernel<%d,SL> (f32 walk)") % m,
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

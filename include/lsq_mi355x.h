@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define LSQ_VERSION 500
+#define LSQ_VERSION 600
 
 #if defined(__GNUC__)
 #define LSQ_API __attribute__((visibility("default")))
@@ -81,9 +81,8 @@ typedef struct lsq_timings {
     int64_t filter_fallback_chunks; /* resident chunks the filter handed to the f32 walk: non-finite / degenerate value ranges, more than 1/64 of the
                                 * (vector, node) pairs outside the sampled level range, or a first ILS iteration in which the filter decided too
                                 * little (since v300)                                                                   */
-    int64_t xs_launches;     /* schedule 7: launches of the XCD-cooperative kernel (since v400)                                  */
-    int64_t xs_fallback_launches; /* ... of which the start barrier turned away (the device was shared: not all 256 blocks resident, or the blocks
-                                * were not spread 32 per XCD): the block-per-range filtered walk did that launch's work instead (since v400) */
+    int64_t xs_launches;     /* reserved, always 0 (counted launches of round 4's schedule 7, which left the tree in v600; kept for the layout) */
+    int64_t xs_fallback_launches; /* reserved, always 0 (as above)                                                      */
     int64_t table_reuses;    /* host-buffer calls that found their codebooks unchanged since the previous one: no upload of K, no table rebuild (since v500) */
 } lsq_timings;      /* fields are only ever APPENDED: a caller built against an older header passes its own sizeof to lsq_get_timings_sized */
 
@@ -109,8 +108,6 @@ LSQ_API int lsq_set_stream(lsq_ctx *ctx, void *hip_stream);
  *        4           f32 walk, one launch per ILS iteration: the block runs the icmiter x m node updates back to back, walking all LDS-staged
  *                    f32 table slices for each; f32 unaries streamed slice-major from HBM;
  *        3           the f32 walk, one launch per node update;
- *        7           (liblsq_mi355x_tuning.so only) the filtered walk with the slices of a node spread over the CUs of an XCD (csrc/lsq_icmx.hip): a persistent,
- *                    wave-specialised kernel -- bit-exact, measured slower than 6, kept as an independent implementation for cross-checks;
  *   "q16_min" (default 65536): schedule 6 applies to chunks with at least this many vectors (below, every block is "light": nothing to filter);
  *   "per_node" (0/1, default 0): schedule 6 with one launch per node update (profiling: per-sweep timings and counters);
  *   "light" (default 160 in the filtered walk, 256 in the f32 walk: the measured crossovers): a block with at most this many active vectors
@@ -137,7 +134,7 @@ LSQ_API int lsq_set_stream(lsq_ctx *ctx, void *hip_stream);
  *        (starts at 0, advances by one per such call).
  *   (liblsq_mi355x_tuning.so only) "ablation": timing-only kernel variants whose results are garbage. */
 LSQ_API int lsq_set_option(lsq_ctx *ctx, const char *key, int64_t value);
-LSQ_API int lsq_get_timings(lsq_ctx *ctx, lsq_timings *out);      /* writes sizeof(lsq_timings) of THIS header: rebuild the caller with the library, or use: */
+LSQ_API int lsq_get_timings(lsq_ctx *ctx, lsq_timings *out);      /* writes the v400 layout only (everything before table_reuses: a caller built against any header since v400 is never overrun); the fields appended since come through: */
 /* ... the size-checked form: at most `bytes` bytes of the structure are written (the fields a caller compiled against an older header knows about);
  * compare lsq_version() with LSQ_VERSION at load time to learn which fields the library fills. */
 LSQ_API int lsq_get_timings_sized(lsq_ctx *ctx, void *out, size_t bytes);

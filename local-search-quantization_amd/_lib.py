@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LSQ_LIB_PATH") or os.path.join(_HERE, "liblsq_mi355x.so")      # override: A/B builds of the same ABI
-# Same ABI built with -DLSQ_TUNING: + option "ablation", environment knobs, clock stamps, schedule 7 (csrc/lsq_icmx.hip).  Profiling tools and the tests
+# Same ABI built with -DLSQ_TUNING: + option "ablation", environment knobs, clock stamps.  Profiling tools and the tests
 # that cross-check the earlier schedules load it explicitly (Engine(..., tuning=True)); the product path never does.
 TUNING_LIB_PATH = os.environ.get("LSQ_TUNING_LIB_PATH") or os.path.join(_HERE, "liblsq_mi355x_tuning.so")
 

@@ -3,11 +3,13 @@
 // a HIP kernel in lsq_gemm.hip / lsq_icm.hip.  There is NO CPU fallback: without a gfx950 device
 // every compute entry point fails with LSQ_ENODEV / LSQ_EHIP.
 #include <stdarg.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <string.h>
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <string>
 #include <thread>
 #include <vector>
@@ -41,7 +43,7 @@ extern "C" int lsq_device_count(int *count) {
 enum { CAT_TABLES = 0, CAT_UNARIES, CAT_PERTURB, CAT_ICM, CAT_COST, CAT_OTHER, CAT_COUNT };
 
 // layout of the context's block of small per-call words (bytes; [0, SMALL_READ_END) is what a call zeroes and reads back)
-enum : size_t { SMALL_COUNTERS = 0, SMALL_OBJ = 8192, SMALL_BAD = 8704, SMALL_XSERR = 8768, SMALL_QP = 8832, SMALL_ACTIVE = 10240, SMALL_ROAD = 11008,
+enum : size_t { SMALL_COUNTERS = 0, SMALL_OBJ = 8192, SMALL_BAD = 8704, SMALL_QP = 8832, SMALL_ACTIVE = 10240, SMALL_ROAD = 11008,
                 SMALL_READ_END = 11072, SMALL_PROBE = 11264, SMALL_BYTES = 12288 };
 static_assert(sizeof(lsq_q16_params) <= SMALL_ACTIVE - SMALL_QP && sizeof(unsigned long long) * LSQ_WALK_COUNTERS <= SMALL_ROAD - SMALL_ACTIVE &&
               sizeof(unsigned long long) * LSQ_WALK_COUNTERS <= SMALL_BYTES - SMALL_PROBE, "the per-call block's windows");
@@ -54,13 +56,9 @@ struct lsq_ctx {
     int profile = 0;
     int schedule = 6;        // 3: LDS-walk (f32), one launch per node; 4: the same, one launch per ILS iteration; 6 (default): 16-bit filtered walk
                              // with exact refinement, one launch per ILS iteration (chunks below q16_min vectors / non-finite data: schedule 4);
-                             // tuning build only: 0 per-node L2 gathers, 1 fused sweeps, 2 LDS slices + combine
     int64_t q16_min = 65536; // schedule 6: smaller chunks take schedule 4 (every block is light there: nothing to filter)
     int tables_changed = 1;  // schedule 6: the pair tables were rebuilt since the last lsq_launch_q16_prepare
     int new_call = 1;        // schedule 6: no chunk of this call has reset the level parameters' counters yet
-    int fuse_cost = 0;       // option "fuse_cost" (tuning build only; measured, not adopted): the filtered walk's launch that ends an ILS iteration also judges its
-                             // vectors (cost + accept + next perturbation as the closing phase of every block: lsq_cost_phase) -- one launch per iteration instead of two
-    int64_t fused_cost_launches = 0;
     // Host-buffer entry points called again with the SAME codebooks (the trainer's chained encoding_icm, demos/demo_lsq.jl:48-51 / LSQ.jl:54-57 -- the
     // reference rebuilds its binaries in every call, encode_icm.jl:145, with identical results): the uploaded K, ||c||^2, the pair tables and what the
     // filtered walk derives from them are still in this context -- one memcmp of the caller's K against a host copy decides
@@ -81,12 +79,7 @@ struct lsq_ctx {
     unsigned long long *walk_counters = nullptr;       // where the walk launches accumulate their statistics (c->active, or c->probe during that first iteration)
     int64_t probe_div = 8;                             // option "filter_probe_div": after the first iteration the chunk goes to the f32 walk when
                                                        // (refined + f32-routed) * div > recomputed node updates (0 = never)
-    DevBuf xsPart, xsSync, xsErr;                      // schedule 7 (lsq_icmx.hip): ring of partial keys, the launch's sync words, the call's two error words
-    int xs_dev_ok = 0;                                 // the device has the 8 x 32 CUs the kernel's groups are laid out for
-    int64_t xs_min = 32768;                            // option "xs_min": smaller chunks take the block-per-range walk (schedule 6's kernels)
-    int64_t xs_launches = 0;
-    int64_t xs_fallback_launches = 0;                  // launches whose start barrier said no (the predicated icm_walkq_kernel launch did the work)
-    DevBuf small;                                              // one block for the small per-call words below (counters, obj, bad, xsErr, qp, active, road, probe are windows into it)
+    DevBuf small;                                              // one block for the small per-call words below (counters, obj, bad, qp, active, road, probe are windows into it)
     char *small_host = nullptr;                                // its pinned mirror
     bool small_packed = false;                                 // this call: every window still in place (an outgrown one gets an allocation of its own)
     DevBuf Uq, Tq, qp, qscratch, qflag, qsigma;                // 16-bit filtered walk: u16 unary planes, u16 slice tables, lsq_q16_params, bound scratch, per-vector out-of-range flags
@@ -189,7 +182,6 @@ extern "C" int lsq_create(lsq_ctx **out, int device) {
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; lsq_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return LSQ_EHIP; }
     c->stream = c->own_stream;
-    c->xs_dev_ok = prop.multiProcessorCount == 256;
     // the small per-call words (counters, sums, flags, level parameters) share ONE block: a call zeroes it with one fill and reads it back with one copy into
     // pinned memory (they were seven fills and four pageable copies of a few bytes each, 5 - 20 us apiece: a quarter of a 10 000-vector call)
     if (hipMalloc(&c->small.p, SMALL_BYTES) != hipSuccess || hipHostMalloc(reinterpret_cast<void **>(&c->small_host), SMALL_BYTES, hipHostMallocDefault) != hipSuccess) {
@@ -202,8 +194,7 @@ extern "C" int lsq_create(lsq_ctx **out, int device) {
     c->small.cap = SMALL_BYTES;
     c->counters.window(c->small.p, SMALL_COUNTERS, SMALL_OBJ - SMALL_COUNTERS);
     c->obj.window(c->small.p, SMALL_OBJ, SMALL_BAD - SMALL_OBJ);
-    c->bad.window(c->small.p, SMALL_BAD, SMALL_XSERR - SMALL_BAD);
-    c->xsErr.window(c->small.p, SMALL_XSERR, SMALL_QP - SMALL_XSERR);
+    c->bad.window(c->small.p, SMALL_BAD, 64);
     c->qp.window(c->small.p, SMALL_QP, SMALL_ACTIVE - SMALL_QP);
     c->active.window(c->small.p, SMALL_ACTIVE, SMALL_ROAD - SMALL_ACTIVE);
     c->road.window(c->small.p, SMALL_ROAD, SMALL_READ_END - SMALL_ROAD);
@@ -218,7 +209,7 @@ extern "C" int lsq_destroy(lsq_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : c->pool) (void)hipEventDestroy(e);
-    DevBuf *bufs[] = {&c->road, &c->xsPart, &c->xsSync, &c->xsErr, &c->probe, &c->Uq, &c->Tq, &c->qp, &c->qscratch, &c->qflag, &c->qsigma, &c->sci, &c->T, &c->Ts, &c->U, &c->vCur, &c->vNew, &c->active, &c->recCur, &c->recNew, &c->prev, &c->counters, &c->obj, &c->bad,
+    DevBuf *bufs[] = {&c->road, &c->probe, &c->Uq, &c->Tq, &c->qp, &c->qscratch, &c->qflag, &c->qsigma, &c->sci, &c->T, &c->Ts, &c->U, &c->vCur, &c->vNew, &c->active, &c->recCur, &c->recNew, &c->prev, &c->counters, &c->obj, &c->bad,
                       &c->sX, &c->sX2, &c->sK, &c->sB16, &c->sOut16, &c->sTight, &c->sF32, &c->sSample, &c->sSigmaS};
     for (DevBuf *b : bufs) b->release();
     c->small.release();
@@ -235,6 +226,7 @@ extern "C" int lsq_destroy(lsq_ctx *c) {
 
 extern "C" int lsq_set_stream(lsq_ctx *c, void *hip_stream) {
     LSQ_TRY(use_device(c));
+    if (c->stream != reinterpret_cast<hipStream_t>(hip_stream)) c->tables_valid = false;      // cached tables were built on the old stream: nothing orders them before work on the new one
     c->stream = reinterpret_cast<hipStream_t>(hip_stream);      // NULL = HIP's default (null) stream, e.g. torch's default
     return LSQ_OK;
 }
@@ -245,7 +237,7 @@ extern "C" int lsq_set_option(lsq_ctx *c, const char *key, int64_t value) {
         if (value < 1) { lsq_set_error("chunk must be >= 1"); return LSQ_EINVAL; }
         c->chunk = value;
     } else if (!strcmp(key, "profile")) c->profile = value != 0;
-    else if (!strcmp(key, "own_stream")) c->stream = c->own_stream;
+    else if (!strcmp(key, "own_stream")) { if (c->stream != c->own_stream) c->tables_valid = false; c->stream = c->own_stream; }
     else if (!strcmp(key, "skip")) c->skip = value != 0;
 #ifdef LSQ_TUNING
     else if (!strcmp(key, "ablation")) c->ablation = (int)value;      // timing-only kernel variants: tuning build only
@@ -254,12 +246,8 @@ extern "C" int lsq_set_option(lsq_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "wave_max")) c->wave_max = (int)value;
     else if (!strcmp(key, "fallback")) c->fallback = (int)value;
     else if (!strcmp(key, "q16_min")) c->q16_min = value;
-    else if (!strcmp(key, "xs_min")) c->xs_min = value;
     else if (!strcmp(key, "async")) c->async_mode = value != 0;
     else if (!strcmp(key, "per_node")) c->per_node = value != 0;
-#ifdef LSQ_TUNING
-    else if (!strcmp(key, "fuse_cost")) c->fuse_cost = value != 0;
-#endif
     else if (!strcmp(key, "upload_panel_bytes")) {
         if (value < 1) { lsq_set_error("upload_panel_bytes must be >= 1"); return LSQ_EINVAL; }
         c->panel_bytes = value;
@@ -286,11 +274,7 @@ extern "C" int lsq_set_option(lsq_ctx *c, const char *key, int64_t value) {
         c->auto_it = (uint32_t)value;
     }
     else if (!strcmp(key, "schedule")) {
-#ifdef LSQ_TUNING
-        if (value != 3 && value != 4 && value != 6 && value != 7) { lsq_set_error("schedule must be 3, 4, 6 or 7"); return LSQ_EINVAL; }
-#else
-        if (value != 3 && value != 4 && value != 6) { lsq_set_error("schedule must be 3, 4 or 6 (schedule 7 -- a measured, not adopted experiment -- exists in the tuning build only)"); return LSQ_EINVAL; }
-#endif
+        if (value != 3 && value != 4 && value != 6) { lsq_set_error("schedule must be 3, 4 or 6"); return LSQ_EINVAL; }
         c->schedule = (int)value;
     } else { lsq_set_error("unknown option '%s'", key); return LSQ_EINVAL; }
     return LSQ_OK;
@@ -300,7 +284,12 @@ static int fill_timings(lsq_ctx *c, lsq_timings *out);
 
 extern "C" int lsq_get_timings(lsq_ctx *c, lsq_timings *out) {
     if (!out) { lsq_set_error("lsq_get_timings: null out"); return LSQ_EINVAL; }
-    return fill_timings(c, out);
+    // This symbol writes the v400 layout only -- a caller compiled against the v400 header and loading a newer library must not have its struct overrun
+    // (ADVICE r5); the fields appended since (table_reuses, ...) are reached through lsq_get_timings_sized, which is told the caller's sizeof.
+    lsq_timings t;
+    LSQ_TRY(fill_timings(c, &t));
+    memcpy(out, &t, offsetof(lsq_timings, table_reuses));
+    return LSQ_OK;
 }
 
 extern "C" int lsq_get_timings_sized(lsq_ctx *c, void *out, size_t bytes) {
@@ -330,8 +319,8 @@ static int fill_timings(lsq_ctx *c, lsq_timings *out) {
     out->filter_exact = c->filter_exact;
     out->filter_f32 = c->filter_f32;
     out->filter_fallback_chunks = c->filter_fallback_chunks;
-    out->xs_launches = c->xs_launches;
-    out->xs_fallback_launches = c->xs_fallback_launches;
+    out->xs_launches = 0;               // (schedule 7 left the tree in v600: the fields stay for the ABI)
+    out->xs_fallback_launches = 0;
     out->table_reuses = c->table_reuses;
     return LSQ_OK;
 }
@@ -349,7 +338,6 @@ extern "C" int lsq_reset_timings(lsq_ctx *c) {
     for (double &v : c->cat_ms) v = 0.0;
     c->icm_launches = c->icm_node_updates = c->staged_blocks = c->light_blocks = c->filtered_blocks = c->filter_refined = c->filter_exact = c->filter_f32 = 0;
     c->filter_fallback_chunks = 0;
-    c->xs_launches = c->xs_fallback_launches = 0;
     c->table_reuses = 0;
     for (int64_t &v : c->trace) v = 0;
     c->adc_stats = lsq_linscan_stats{};
@@ -587,7 +575,9 @@ static int build_unaries_from_host(lsq_ctx *c, const float *Xh, float *dXc, cons
     LSQ_TRY(c->U.ensure(sizeof(float) * (size_t)m * (size_t)cn * LSQ_H));
     std::atomic<int> landed{0};
     hipError_t herr = hipSuccess;
-    std::thread feeder([&]() {
+    std::thread feeder;
+    try {
+    feeder = std::thread([&]() {
         hipError_t e = hipSetDevice(c->device);
         for (int p = 0; p < npan && e == hipSuccess; ++p) {
             const int64_t r0 = (int64_t)p * prow, rows = std::min<int64_t>(prow, cn - r0);
@@ -598,11 +588,22 @@ static int build_unaries_from_host(lsq_ctx *c, const float *Xh, float *dXc, cons
         herr = e;
         if (e != hipSuccess) landed.store(npan + 1, std::memory_order_release);      // release the consumer: it checks herr after the join
     });
+    } catch (...) {      // no thread to be had: nothing may escape the C ABI -- one-piece upload on the compute stream, then the ordinary build
+        LSQ_HIP(hipMemcpyAsync(dXc, Xh, (size_t)cn * row_bytes, hipMemcpyHostToDevice, c->stream));
+        if (q16) {      // the flags / counters the sample-mode prepare left behind are rebuilt by the full-chunk prepare inside build_unaries
+            c->call_q16_chunks -= 1;
+            c->tables_changed = 1;
+        }
+        return build_unaries(c, dXc, dK, d, cn, m, slice, 0, cn);
+    }
     int rc = LSQ_OK;
     uint16_t *dq = q16 ? c->Uq.as<uint16_t>() : nullptr;
     char *sc = q16 ? c->qscratch.as<char>() : nullptr;
     for (int p = 0; p < npan && rc == LSQ_OK; ++p) {
-        while (landed.load(std::memory_order_acquire) <= p) std::this_thread::yield();
+        for (int spins = 0; landed.load(std::memory_order_acquire) <= p; ++spins) {      // a panel takes ~1 ms to go up: poll briefly, then sleep instead of burning the core
+            if (spins < 64) std::this_thread::yield();
+            else std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
         if (landed.load(std::memory_order_acquire) > npan) break;                    // the feeder failed
         const int64_t r0 = (int64_t)p * prow, rows = std::min<int64_t>(prow, cn - r0);
         if (hipStreamWaitEvent(c->stream, c->panel_ev[(size_t)p], 0) != hipSuccess) { lsq_set_error("hipStreamWaitEvent failed"); rc = LSQ_EHIP; break; }
@@ -622,11 +623,8 @@ static int build_unaries_from_host(lsq_ctx *c, const float *Xh, float *dXc, cons
 
 // ref_rec / ref_valid: the vectors' current records and validity masks (read-only during the sweeps), or nullptr
 // first_sweep: position of the first of the nsweeps sweeps inside its ILS iteration (the per-position trace counters only)
-// cost (optional): the closing phase of the LAST launch -- honoured on the filtered walk's host-decided road only (*cost_done tells the caller)
 static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t cn, int m, const int32_t *order, int nsweeps,
-                      const uint8_t *ref_rec = nullptr, const unsigned short *ref_valid = nullptr, int first_sweep = 0,
-                      const lsq_cost_phase *cost = nullptr, bool *cost_done = nullptr) {
-    if (cost_done) *cost_done = false;
+                      const uint8_t *ref_rec = nullptr, const unsigned short *ref_valid = nullptr, int first_sweep = 0) {
     if (nsweeps <= 0) return LSQ_OK;
     const int pos_base = first_sweep * m;
     Timer t(c, CAT_ICM);
@@ -639,33 +637,12 @@ static int run_sweeps(lsq_ctx *c, uint8_t *rec, unsigned short *valid, int64_t c
             // 16-bit filtered walk on the level planes of this chunk (build_unaries read the chunk's verdict); 64 node updates per launch
             const lsq_q16_params *P = c->qp.as<lsq_q16_params>();
             const size_t per_launch = c->per_node ? 1 : 64;
-            // schedule 7: the slices of a node spread over the CUs of an XCD (lsq_icmx.hip).  Its start barrier may turn a launch away (another
-            // process' kernels on the device: not all 256 blocks resident): the filtered walk behind it is predicated on that verdict.
-#ifdef LSQ_TUNING
-            // (not with option "async": there the stand-in launch is predicated on the road word, not on the xs launch's verdict -- ADVICE r4)
-            const bool xs = c->schedule == 7 && c->xs_dev_ok && cn >= c->xs_min && lsq_icm_xs_applies(cn, m) && !c->per_node && !c->chunk_road_dev;
-#else
-            const bool xs = false;
-#endif
+            const unsigned *gate = c->chunk_road_dev ? c->road.as<unsigned>() : nullptr;      // option "async": runs iff road[0] == 2
             for (size_t done = 0; done < seq.size(); done += per_launch) {
                 const int cntn = (int)std::min<size_t>(per_launch, seq.size() - done);
-                const unsigned *gate = nullptr;
-#ifdef LSQ_TUNING
-                if (xs)
-                    LSQ_TRY(lsq_launch_icm_xs(c->stream, c->U.as<float>(), c->Uq.as<uint16_t>(), c->Tq.as<uint16_t>(), c->T.as<float>(), rec, valid, cn, m,
-                                              seq.data() + done, cntn, pos_base + (int)done, c->skip, c->walk_counters, c->fallback ? ref_rec : nullptr,
-                                              c->fallback ? ref_valid : nullptr, P, c->qflag.as<unsigned short>(), &c->xsPart, &c->xsSync,
-                                              c->xsErr.as<unsigned>(), &gate));
-#endif
-                if (xs) c->xs_launches += 1;
-                if (c->chunk_road_dev) gate = c->road.as<unsigned>();      // option "async": runs iff road[0] == 2
-                const bool last = done + per_launch >= seq.size();
-                const bool fuse = cost && last && !xs && !c->chunk_road_dev && !c->per_node;
                 LSQ_TRY(lsq_launch_icm_walkq(c->stream, c->U.as<float>(), c->Uq.as<uint16_t>(), c->Tq.as<uint16_t>(), c->T.as<float>(), rec, valid, cn, m,
                                              seq.data() + done, cntn, pos_base + (int)done, c->skip, c->walk_counters, c->light,
-                                             c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr, P, c->qflag.as<unsigned short>(), gate,
-                                             fuse ? cost : nullptr));
-                if (fuse) { if (cost_done) *cost_done = true; c->fused_cost_launches += 1; }
+                                             c->fallback ? ref_rec : nullptr, c->fallback ? ref_valid : nullptr, P, c->qflag.as<unsigned short>(), gate));
             }
             c->icm_launches += ((int64_t)seq.size() + (int64_t)per_launch - 1) / (int64_t)per_launch;
             if (c->chunk_road_dev) {      // ... and the f32 walk behind it idles on the same word (road[0] != 0) or does the work (road[0] == 0)
@@ -721,7 +698,7 @@ static int encode_chunk(lsq_ctx *c, const float *dXc, const float *dK, int64_t c
     if (!unaries_ready) LSQ_TRY(build_unaries(c, dXc, dK, P.d, cn, P.m, u_slice_width(c, P.m), 0, cn));
     LSQ_TRY(c->recNew.ensure((size_t)cn * cs));
     LSQ_TRY(c->prev.ensure(sizeof(float) * (size_t)cn));
-    LSQ_TRY(c->vCur.ensure(sizeof(unsigned short) * (size_t)(cn + 8)));      // + 8: icm_xs_kernel's lister reads the words four at a time
+    LSQ_TRY(c->vCur.ensure(sizeof(unsigned short) * (size_t)(cn + 8)));
     LSQ_TRY(c->vNew.ensure(sizeof(unsigned short) * (size_t)(cn + 8)));
     LSQ_HIP(hipMemsetAsync(c->vCur.p, 0, sizeof(unsigned short) * (size_t)cn, c->stream));      // nothing is known to be an argmin yet
     unsigned short *vcur = c->vCur.as<unsigned short>(), *vnew = c->vNew.as<unsigned short>();
@@ -753,16 +730,7 @@ static int encode_chunk(lsq_ctx *c, const float *dXc, const float *dK, int64_t c
             LSQ_HIP(hipMemsetAsync(c->probe.p, 0, sizeof(unsigned long long) * LSQ_WALK_COUNTERS, c->stream));
             c->walk_counters = c->probe.as<unsigned long long>();
         }
-        // the cost + accept + perturbation of this iteration as the closing phase of its last walk launch (filtered road, d a multiple of 4, aligned)
-        lsq_cost_phase cph = {};
-        cph.on = 1; cph.d = P.d; cph.X = dXc; cph.K = dK; cph.cur = cur; cph.prev = prev; cph.counters = counters + 2 * it; cph.vcur = vcur;
-        cph.pn = pn;
-        cph.pn.it = P.it0 + (uint32_t)it + 1u;
-        cph.pn.on = it + 1 < I ? 1 : 0;
-        const bool may_fuse = c->fuse_cost && c->schedule == 6 && P.d % 4 == 0 && (((uintptr_t)dXc | (uintptr_t)dK) % 16) == 0 && (int64_t)P.m * LSQ_H * P.d < (1ll << 31);
-        bool cost_done = false;
-        const bool whole = !probing || probe_sweeps == P.icmiter;       // this run_sweeps call holds the iteration's last node update
-        LSQ_TRY(run_sweeps(c, nw, vnew, cn, P.m, order, probing ? probe_sweeps : P.icmiter, cur, vcur, 0, (may_fuse && whole && !probing) ? &cph : nullptr, &cost_done));
+        LSQ_TRY(run_sweeps(c, nw, vnew, cn, P.m, order, probing ? probe_sweeps : P.icmiter, cur, vcur, 0));
         if (probing && c->chunk_road_dev) {
             // option "async": the same probe by a one-thread kernel (it also adds the probed launches' statistics to the call's)
             c->walk_counters = c->active.as<unsigned long long>();
@@ -783,9 +751,9 @@ static int encode_chunk(lsq_ctx *c, const float *dXc, const float *dK, int64_t c
                 c->chunk_q16 = false;
                 c->filter_fallback_chunks += 1;
             }
-            LSQ_TRY(run_sweeps(c, nw, vnew, cn, P.m, order, P.icmiter - probe_sweeps, cur, vcur, probe_sweeps, may_fuse ? &cph : nullptr, &cost_done));      // the rest of a single-iteration call
+            LSQ_TRY(run_sweeps(c, nw, vnew, cn, P.m, order, P.icmiter - probe_sweeps, cur, vcur, probe_sweeps));      // the rest of a single-iteration call
         }
-        if (!cost_done) {
+        {
             Timer t(c, CAT_COST);
             pn.it = P.it0 + (uint32_t)it + 1u;
             LSQ_TRY(lsq_launch_cost(c->stream, dXc, dK, nw, cur, prev, counters + 2 * it, cn, P.d, P.m, 1, vnew, vcur, it + 1 < I ? &pn : nullptr));
@@ -812,36 +780,20 @@ static int validate_encode(const char *fn, int d, int64_t n, int m, int h, const
     return LSQ_OK;
 }
 
-// schedule 7's per-call error words: [0] = give-up code of any icm_xs_kernel launch, [1] = launches its start barrier turned away
-static int xs_begin(lsq_ctx *c) {
-    LSQ_TRY(c->xsErr.ensure(2 * sizeof(unsigned)));
-    LSQ_HIP(hipMemsetAsync(c->xsErr.p, 0, 2 * sizeof(unsigned), c->stream));
-    return LSQ_OK;
-}
-static int xs_verdict(lsq_ctx *c, const unsigned (&xs_err)[2]) {      // after the stream has been synchronised
-    c->xs_fallback_launches += (int64_t)xs_err[1];
-    if (xs_err[0] != 0u) {        // never silently: a wait inside a schedule-7 launch gave up (a lost block, a protocol fault): this call's codes are invalid
-        lsq_set_error("the schedule-7 kernel gave up waiting (code %u): the codes of this call are invalid; option \"schedule\" = 6 avoids the kernel", xs_err[0]);
-        return LSQ_EHIP;
-    }
-    return LSQ_OK;
-}
-
 static int begin_call(lsq_ctx *c, int64_t I, int nr) {
     LSQ_TRY(c->counters.ensure(sizeof(unsigned long long) * 2 * (size_t)std::max<int64_t>(I, 1)));
     LSQ_TRY(c->obj.ensure(sizeof(double) * (size_t)std::max(nr, 1)));
     LSQ_TRY(c->bad.ensure(sizeof(int)));
     LSQ_TRY(c->active.ensure(sizeof(unsigned long long) * LSQ_WALK_COUNTERS));
     LSQ_TRY(c->road.ensure(2 * sizeof(unsigned)));
-    LSQ_TRY(c->xsErr.ensure(2 * sizeof(unsigned)));
     LSQ_TRY(c->qp.ensure(sizeof(lsq_q16_params)));
     if (!c->async_mode) LSQ_TRY(fold_pending(c));             // statistics an earlier async call left on the device (synchronises)
     c->walk_counters = c->active.as<unsigned long long>();
     c->call_q16_chunks = 0;
     c->new_call = 1;
-    c->small_packed = c->counters.view && c->obj.view && c->bad.view && c->xsErr.view && c->qp.view && c->active.view && c->road.view;
+    c->small_packed = c->counters.view && c->obj.view && c->bad.view && c->qp.view && c->active.view && c->road.view;
     if (c->small_packed) {
-        // one fill: counters, sums, flags, schedule-7 words, level parameters (+ the walk counters and the road words unless async calls are still accumulating)
+        // one fill: counters, sums, flags, level parameters (+ the walk counters and the road words unless async calls are still accumulating)
         LSQ_HIP(hipMemsetAsync(c->small.p, 0, c->pending_fold ? SMALL_ACTIVE : SMALL_READ_END, c->stream));
         return LSQ_OK;
     }
@@ -852,7 +804,6 @@ static int begin_call(lsq_ctx *c, int64_t I, int nr) {
     LSQ_HIP(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long) * 2 * (size_t)std::max<int64_t>(I, 1), c->stream));
     LSQ_HIP(hipMemsetAsync(c->obj.p, 0, sizeof(double) * (size_t)std::max(nr, 1), c->stream));
     LSQ_HIP(hipMemsetAsync(c->bad.p, 0, sizeof(int), c->stream));
-    LSQ_TRY(xs_begin(c));
     return LSQ_OK;
 }
 
@@ -897,10 +848,7 @@ static int finish_call(lsq_ctx *c, int64_t I, int nr, double *obj_sums, int64_t 
         memcpy(obj_sums, c->small_host + SMALL_OBJ, sizeof(double) * (size_t)nr);
         unsigned long long act[LSQ_WALK_COUNTERS];
         memcpy(act, c->small_host + SMALL_ACTIVE, sizeof(act));
-        unsigned xs_err[2];
-        memcpy(xs_err, c->small_host + SMALL_XSERR, sizeof(xs_err));
         fold_walk_counters(c, act);
-        LSQ_TRY(xs_verdict(c, xs_err));
         if (stats) {
             const unsigned long long *cnt = reinterpret_cast<const unsigned long long *>(c->small_host + SMALL_COUNTERS);
             for (int64_t q = 0; q < 2 * I; ++q) stats[q] = (int64_t)cnt[q];
@@ -912,11 +860,8 @@ static int finish_call(lsq_ctx *c, int64_t I, int nr, double *obj_sums, int64_t 
     LSQ_HIP(hipMemcpyAsync(cnt.data(), c->counters.p, sizeof(unsigned long long) * cnt.size(), hipMemcpyDeviceToHost, c->stream));
     unsigned long long act[LSQ_WALK_COUNTERS] = {0};
     LSQ_HIP(hipMemcpyAsync(act, c->active.p, sizeof(act), hipMemcpyDeviceToHost, c->stream));
-    unsigned xs_err[2] = {0u, 0u};
-    LSQ_HIP(hipMemcpyAsync(xs_err, c->xsErr.p, sizeof(xs_err), hipMemcpyDeviceToHost, c->stream));
     LSQ_HIP(hipStreamSynchronize(c->stream));
     fold_walk_counters(c, act);
-    LSQ_TRY(xs_verdict(c, xs_err));
     if (stats) for (int64_t q = 0; q < 2 * I; ++q) stats[q] = (int64_t)cnt[(size_t)q];
     return LSQ_OK;
 }
@@ -955,6 +900,7 @@ static int host_codebooks(lsq_ctx *c, const float *K, int d, int m) {
         c->table_reuses += 1;
         return LSQ_OK;
     }
+    c->tables_valid = false;        // from here on sK / the tables are in flux: a failure below must not leave the cache claiming the OLD codebooks
     LSQ_TRY(c->sK.ensure(kbytes));
     LSQ_HIP(hipMemcpyAsync(c->sK.p, K, kbytes, hipMemcpyHostToDevice, c->stream));
     LSQ_TRY(prepare_tables(c, c->sK.as<float>(), d, m));
@@ -993,9 +939,9 @@ static int encode_host(lsq_ctx *c, const char *fn, const float *X, const int16_t
     }
     const EncodeParams P{d, m, ilsiters, nr, icmiter, npert, randord, seed, it0};
     const int cs = lsq_code_stride(m);
-    // Chunk c+1's X is uploaded on a second stream under the ILS iterations of chunk c (double-buffered staging).  The first
-    // chunk goes through the compute stream in one piece: a pageable copy on another stream costs ~7 ms more, and splitting it
-    // into panels whose unary GEMMs start early was measured slower (tools/ubench_h2d.hip, tools/host_api_rate.py).
+    // Chunk c+1's X is uploaded on a second stream under the ILS iterations of chunk c (double-buffered staging).  The FIRST
+    // chunk of a call goes up panel by panel under its own unary GEMM when it is at least upload_pipeline_min_bytes long
+    // (build_unaries_from_host, round 5), else through the compute stream in one piece.
     if (n > c->chunk) {
         if (!c->copy_stream) LSQ_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         if (!c->copy_done) LSQ_HIP(hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming));
@@ -1255,7 +1201,6 @@ extern "C" int lsq_encode_icm_fully(lsq_ctx *c, int16_t *B, const float *X, cons
     if (autoit) it = c->auto_it;
     if (n == 0) return LSQ_OK;
     if (n > c->chunk) { lsq_set_error("lsq_encode_icm_fully: n = %lld exceeds the resident chunk (%lld); raise option \"chunk\"", (long long)n, (long long)c->chunk); return LSQ_EINVAL; }
-    LSQ_TRY(xs_begin(c));
     LSQ_TRY(upload_xk(c, X, K, d, n, m));
     LSQ_TRY(upload_codes(c, B, n, m, h, c->recCur));
     LSQ_TRY(prepare_tables(c, c->sK.as<float>(), d, m));
@@ -1272,10 +1217,7 @@ extern "C" int lsq_encode_icm_fully(lsq_ctx *c, int16_t *B, const float *X, cons
     LSQ_TRY(run_sweeps(c, c->recNew.as<uint8_t>(), c->vNew.as<unsigned short>(), n, m, order, niter));
     LSQ_TRY(lsq_launch_codes_to_i16(c->stream, c->recNew.as<uint8_t>(), n, m, c->sB16.as<int16_t>()));
     LSQ_HIP(hipMemcpyAsync(B, c->sB16.p, sizeof(int16_t) * (size_t)n * m, hipMemcpyDeviceToHost, c->stream));
-    unsigned xs_err[2] = {0u, 0u};
-    LSQ_HIP(hipMemcpyAsync(xs_err, c->xsErr.p, sizeof(xs_err), hipMemcpyDeviceToHost, c->stream));
     LSQ_HIP(hipStreamSynchronize(c->stream));
-    LSQ_TRY(xs_verdict(c, xs_err));
     if (autoit && c->auto_it < LSQ_IT_AUTO - 1u) ++c->auto_it;
     return LSQ_OK;
 }

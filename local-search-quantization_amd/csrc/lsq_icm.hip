@@ -24,6 +24,8 @@
 #include <type_traits>
 
 #include "lsq_wave.h"
+#include <atomic>
+
 #include "lsq_cost.h"
 
 namespace {
@@ -953,11 +955,13 @@ int lsq_launch_cost(hipStream_t s, const float *X, const float *K, const uint8_t
         const int64_t want = (n + 255) / 256;
 #define LSQ_COST4(KERN_, MODE_, HASV_, NQ_)                                                                                                        \
         LSQ_DISPATCH_M(m, {                                                                                                                 \
-            static int per_cu = 0;                                                                                                          \
+            static std::atomic<int> per_cu_known{0};      /* (lsq_multi_* runs one host thread per device through here) */                  \
+            int per_cu = per_cu_known.load(std::memory_order_relaxed);                                                                      \
             if (per_cu == 0) {                                                                                                              \
                 int nb = 0;                                                                                                                 \
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, KERN_<M_, MODE_, HASV_, NQ_>, 256, 0) != hipSuccess || nb < 1) nb = 4;   \
                 per_cu = nb > 8 ? 8 : nb;                                                                                                   \
+                per_cu_known.store(per_cu, std::memory_order_relaxed);                                                                      \
             }                                                                                                                               \
             const int64_t cap = 256 * (int64_t)per_cu;                                                                                      \
             hipLaunchKernelGGL((KERN_<M_, MODE_, HASV_, NQ_>), dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, s, X, K, rec, cur, prev, counters, n, d, vnew, vcur, pn); \

@@ -34,10 +34,6 @@
 
 #include "lsq_q16.h"
 #ifdef LSQ_TUNING
-#include "lsq_cost.h"      // the fused cost phase (tuning build only)
-#endif
-
-#ifdef LSQ_TUNING
 __device__ unsigned long long *g_walkq_dbg = nullptr;      // [launch slot][block][16] timestamps (tools only)
 __device__ unsigned int g_walkq_dbg_slot = 0;
 __device__ unsigned long long *g_walkq_dbg_cur = nullptr;   // block 0's record of the running launch (for q16_refine's stamps)
@@ -491,20 +487,6 @@ __device__ inline int q16_refine(const float *__restrict__ U, const uint16_t *__
     return nexact;
 }
 
-#ifdef LSQ_TUNING
-// (tuning build only: measured, not adopted -- DESIGN 4.4.)  The closing phase as a REAL function call: inlined, its 128-register body joined the walk's register allocation and cost the slice loop 4.7 %
-// (17 -> 53 spilled VGPRs); as a call the walk is compiled as before and pays a handful of saves once per pass.
-template <int M>
-__device__ __attribute__((noinline)) void walkq_cost_phase(const uint32_t *cp_words, uint8_t *rec, unsigned short *valid, int64_t lo, int64_t hi, int wave, int nw, unsigned *cnt) {
-    constexpr int CPW = (int)((sizeof(lsq_cost_phase) + 3) / 4);
-    lsq_cost_phase c2;
-#pragma unroll
-    for (int e = 0; e < CPW; ++e) reinterpret_cast<uint32_t *>(&c2)[e] = (uint32_t)__builtin_amdgcn_readfirstlane((int)cp_words[e]);      // uniform: back into SGPRs
-    if (M <= 8 && c2.d > 64) cost4_body<M, 1, 1, 2, true>(c2.X, c2.K, rec, c2.cur, c2.prev, c2.counters, lo, hi, wave, nw, c2.d, valid, c2.vcur, c2.pn, cnt);
-    else cost4_body<M, 1, 1, 1, true>(c2.X, c2.K, rec, c2.cur, c2.prev, c2.counters, lo, hi, wave, nw, c2.d, valid, c2.vcur, c2.pn, cnt);
-}
-#endif
-
 // dynamic LDS of icm_walkq_kernel: the arrays (table, keys, active list, validity mirror), then the block's scalars
 template <int M, int SLQ, int CPL, int NT, int BPC>
 constexpr int walkq_main_bytes() {
@@ -512,7 +494,7 @@ constexpr int walkq_main_bytes() {
     const int pp = WalkqTab<SLQ, CPL>::pp(M, BPC);
     return WalkqTab<SLQ, CPL>::lds_entries(M) * 16 + pp * 8 + pp * 2 + (WalkqTab<SLQ, CPL>::mirror(M, BPC) ? pp * 2 : 0);
 }
-constexpr int WALKQ_MISC_BYTES = (20 + LSQ_WALK_COUNTERS + 2 + (int)((sizeof(lsq_cost_phase) + 3) / 4)) * 4;
+constexpr int WALKQ_MISC_BYTES = (20 + LSQ_WALK_COUNTERS) * 4;
 
 // ---- the filtered walk ----------------------------------------------------------------------------------------------------------
 // Block / pass / node structure, compaction of the active vectors, light blocks and the validity bookkeeping are those of
@@ -525,11 +507,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
                                                        unsigned long long *__restrict__ active_total,
                                                        const uint8_t *__restrict__ ref_rec, const unsigned short *__restrict__ ref_valid,
                                                        const lsq_q16_params *__restrict__ P, int SLF, const unsigned short *__restrict__ qflag, int abl,
-                                                       const unsigned *__restrict__ gate
-#ifdef LSQ_TUNING
-                                                       , const lsq_cost_phase cp
-#endif
-                                                       ) {
+                                                       const unsigned *__restrict__ gate) {
     constexpr int CS = (M <= 8) ? 8 : 16;
     constexpr int NS = LSQ_H / SLQ;
     using TL = WalkqTab<SLQ, CPL>;
@@ -545,7 +523,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
     constexpr bool ROT = walkq_rot(M, SLQ, CPL, NT, BPC);   // rotated-rows placement of the slice table (lsq_q16.h): the default geometry up to m = 8
     constexpr int PP = ROT ? RT::pp() : TL::pp(M, BPC);  // BPC = 1: the f32 walk's geometry (4096 up to m = 14); BPC = 2: two 512-thread blocks share a CU
     if (P->ok == 0) return;                              // never launched in that case (the host read the verdict after the GEMM); kept as a guard
-    if (gate && *gate != 2u) return;                     // stand-in of an icm_xs_kernel launch (lsq_icmx.hip): runs only when that launch's start barrier said no
+    if (gate && *gate != 2u) return;                     // option "async": the chunk's road word (q16_road_kernel) names the f32 walk
 #ifdef LSQ_TUNING
     unsigned long long *dbgp = nullptr;
     extern __shared__ u32x4 lds_walkq[];
@@ -596,13 +574,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
     // words sat in front of every node update's first barrier (5-9 us per node, profiles/r02j_walkq_phases.txt "pre")
     unsigned *stat_s = reinterpret_cast<unsigned *>(misc) + 20;      // [LSQ_WALK_COUNTERS]
     for (int e = threadIdx.x; e < LSQ_WALK_COUNTERS; e += NT) stat_s[e] = 0u;
-#ifdef LSQ_TUNING
-    // the closing phase's arguments wait in LDS: as kernel arguments they would sit in ~30 SGPRs through every node update (the kernel spills SGPRs as it is)
-    constexpr int CPW = (int)((sizeof(lsq_cost_phase) + 3) / 4);
-    uint32_t *cp_s = reinterpret_cast<uint32_t *>(misc) + 20 + LSQ_WALK_COUNTERS + 2;      // [CPW]; the two words before it: the closing phase's block counters
-    if (threadIdx.x < CPW) cp_s[threadIdx.x] = reinterpret_cast<const uint32_t *>(&cp)[threadIdx.x];
-    const int cost_on = cp.on;
-#endif
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -1150,14 +1121,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
             if (dbgp && threadIdx.x == 0) { dbgp[14] = (unsigned long long)nact; dbgp[15] = (unsigned long long)namb; }
 #endif
         }
-        // ---- the closing phase of the pass (the launch that ends an ILS iteration): cost of the candidates, accept, perturbation for the next iteration --
-        // by the block that owns the vectors, with its 16 waves as the "grid" of lsq_cost.h's routine.  Everything a node update stored went through this CU.
-#ifdef LSQ_TUNING
-        if (cost_on) {
-            __syncthreads();
-            walkq_cost_phase<M>(cp_s, rec, valid, lo, hi, wave, NW, reinterpret_cast<unsigned *>(misc) + 20 + LSQ_WALK_COUNTERS);
-        }
-#endif
     }
     __syncthreads();
 #ifdef LSQ_TUNING
@@ -1291,8 +1254,7 @@ int lsq_launch_q16_prepare(hipStream_t s, const float *X, int64_t n, int d, cons
 template <int M, int SLQ, int CPL, int DEPTH, int NT, int BPC>
 static int launch_walkq_t(hipStream_t s, const float *U, const uint16_t *Uq, const uint16_t *Tq, const float *T, uint8_t *rec, unsigned short *valid,
                           int64_t n, const WalkNodes &nodes, int use_skip, unsigned long long *active_total, int light,
-                          const uint8_t *ref_rec, const unsigned short *ref_valid, const lsq_q16_params *P, const unsigned short *qflag, const unsigned *gate,
-                          const lsq_cost_phase &cp) {
+                          const uint8_t *ref_rec, const unsigned short *ref_valid, const lsq_q16_params *P, const unsigned short *qflag, const unsigned *gate) {
     constexpr bool ROT = walkq_rot(M, SLQ, CPL, NT, BPC);
     constexpr int PP = ROT ? WalkqRot<M>::pp() : WalkqTab<SLQ, CPL>::pp(M, BPC);
     constexpr int LDS_BYTES = walkq_main_bytes<M, SLQ, CPL, NT, BPC>() + WALKQ_MISC_BYTES;      // slice table + two smallest keys + active list (+ validity mirror) + the block's scalars
@@ -1319,12 +1281,7 @@ static int launch_walkq_t(hipStream_t s, const float *U, const uint16_t *Uq, con
     }
     const unsigned grid = (unsigned)(npass < NBLK ? npass : NBLK);
     hipLaunchKernelGGL((icm_walkq_kernel<M, SLQ, CPL, DEPTH, NT, BPC>), dim3(grid), dim3(NT), LDS_BYTES, s, U, Uq, Tq, T, rec, valid, n, nodes, per_pass, skip,
-                       direct_max, active_total, skip ? ref_rec : nullptr, skip ? ref_valid : nullptr, P, lsq_walk_slice_width(M), qflag, LSQ_KNOB("LSQ_Q16_ABL", 0), gate
-#ifdef LSQ_TUNING
-                       , cp
-#endif
-                       );
-    (void)cp;
+                       direct_max, active_total, skip ? ref_rec : nullptr, skip ? ref_valid : nullptr, P, lsq_walk_slice_width(M), qflag, LSQ_KNOB("LSQ_Q16_ABL", 0), gate);
     LSQ_HIP(hipGetLastError());
     return LSQ_OK;
 }
@@ -1332,8 +1289,7 @@ static int launch_walkq_t(hipStream_t s, const float *U, const uint16_t *Uq, con
 // the filtered counterpart of lsq_launch_icm_walk (the caller has read the chunk's verdict on the host)
 int lsq_launch_icm_walkq(hipStream_t s, const float *U, const uint16_t *Uq, const uint16_t *Tq, const float *T, uint8_t *rec, unsigned short *valid,
                          int64_t n, int m, const int32_t *order, int nnodes, int pos0, int use_skip, unsigned long long *active_total, int light,
-                         const uint8_t *ref_rec, const unsigned short *ref_valid, const lsq_q16_params *P, const unsigned short *qflag, const unsigned *gate,
-                         const lsq_cost_phase *cost) {
+                         const uint8_t *ref_rec, const unsigned short *ref_valid, const lsq_q16_params *P, const unsigned short *qflag, const unsigned *gate) {
     if (n <= 0 || nnodes <= 0) return LSQ_OK;
     if (m < 1 || m > LSQ_MAX_M) { lsq_set_error("m = %d out of range 1..16", m); return LSQ_EINVAL; }
     for (int done = 0; done < nnodes; done += LSQ_WALK_MAX_NODES) {
@@ -1345,9 +1301,7 @@ int lsq_launch_icm_walkq(hipStream_t s, const float *U, const uint16_t *Uq, cons
             if (j < 0 || j >= m) { lsq_set_error("node %d out of range 0..%d", j, m - 1); return LSQ_EINVAL; }
             nodes.j[t] = (uint8_t)j;
         }
-        lsq_cost_phase cp = {};
-        if (cost && done + LSQ_WALK_MAX_NODES >= nnodes) cp = *cost;      // the launch that holds the last node update of the sequence
-#define LSQ_WQ_ARGS s, U, Uq, Tq, T, rec, valid, n, nodes, use_skip, active_total, light, ref_rec, ref_valid, P, qflag, gate, cp
+#define LSQ_WQ_ARGS s, U, Uq, Tq, T, rec, valid, n, nodes, use_skip, active_total, light, ref_rec, ref_valid, P, qflag, gate
 #define LSQ_WQ_CASE(MM, SLL, CPLL, DD, NTT) case MM: LSQ_TRY((launch_walkq_t<MM, SLL, CPLL, DD, NTT, 1>(LSQ_WQ_ARGS))); break;
 #define LSQ_WQ_CASE2(MM, SLL, CPLL, DD, NTT) case MM: LSQ_TRY((launch_walkq_t<MM, SLL, CPLL, DD, NTT, 2>(LSQ_WQ_ARGS))); break;
         // m <= 8: slices of 32 candidates, four lanes per vector (8 candidates per lane); above: slices of 16, two lanes of 8

@@ -163,7 +163,6 @@ int lsq_launch_icm_walk(hipStream_t s, const float *U, const float *Ts, const fl
                         const int32_t *order, int nnodes, int pos0, int use_skip, unsigned long long *active_total, int ablation, int light,
                         const uint8_t *ref_rec, const unsigned short *ref_valid, const int *idle_if_set = nullptr);
 // idle_if_set (optional, device): the launch does nothing when *idle_if_set != 0 (the filtered walk handled it)
-struct lsq_cost_phase;
 // 16-bit filtered walk (lsq_icmq.hip).  lsq_launch_q16_prepare: per chunk, after the pair tables and before the unary GEMM -- bounds,
 // parameters P and the 16-bit slice tables Tq [m][256/SLQ][m-1][256][SLQ]; tables_changed = 1 on the first chunk of a call.
 // bad (1 int), trange (3 m m floats), qrange (2 * 16 + 2 u32): scratch.  lsq_launch_icm_walkq: same contract as lsq_launch_icm_walk plus
@@ -183,19 +182,11 @@ int lsq_launch_unary_shift_panel(hipStream_t s, const float *Xp, int64_t rows, i
 int lsq_launch_icm_walkq(hipStream_t s, const float *U, const uint16_t *Uq, const uint16_t *Tq, const float *T, uint8_t *rec, unsigned short *valid,
                          int64_t n, int m, const int32_t *order, int nnodes, int pos0, int use_skip, unsigned long long *active_total, int light,
                          const uint8_t *ref_rec, const unsigned short *ref_valid, const lsq_q16_params *P, const unsigned short *qflag,
-                         const unsigned *gate = nullptr, const lsq_cost_phase *cost = nullptr);      // cost: appended to the LAST launch of the node sequence
+                         const unsigned *gate = nullptr);
 // option "async": the chunk's road decided on the device (lsq_icmq.hip): road[0] = 2 filtered walk / 0 f32 walk, road[1] = chunks handed over
 int lsq_launch_q16_road(hipStream_t s, const lsq_q16_params *P, unsigned *road, int64_t pairs, int64_t fallback_div);
 int lsq_launch_q16_probe(hipStream_t s, const unsigned long long *probe, unsigned long long *totals, unsigned *road, int64_t probe_div);
-// gate (optional, device): the launch is the stand-in of an icm_xs_kernel launch and runs only when *gate == 2 (that launch's start barrier said no)
-// Schedule 7 (lsq_icmx.hip): the slices of a node spread over the CUs of an XCD, walker / lister / merger waves.  Same contract as
-// lsq_launch_icm_walkq for <= LSQ_WALK_MAX_NODES (64) node updates; part / syncb: work buffers owned by the context; err: two words zeroed
-// at the start of the call ([0] = give-up code of any launch, [1] = launches turned away by their start barrier); *gate_word: see above.
-bool lsq_icm_xs_applies(int64_t n, int m);
-int lsq_launch_icm_xs(hipStream_t s, const float *U, const uint16_t *Uq, const uint16_t *Tq, const float *T, uint8_t *rec, unsigned short *valid,
-                      int64_t n, int m, const int32_t *order, int nnodes, int pos0, int use_skip, unsigned long long *active_total,
-                      const uint8_t *ref_rec, const unsigned short *ref_valid, const lsq_q16_params *P, const unsigned short *qflag,
-                      DevBuf *part, DevBuf *syncb, unsigned *err, const unsigned **gate_word);
+// gate (optional, device; option "async"): the launch runs only when *gate == 2 (the road word names the filtered walk)
 // ref_rec / ref_valid (optional, read-only): the vectors' current records and their validity masks; a candidate that becomes
 // equal to its current record inherits those bits (exact: validity depends on the code tuple only)
 // light: blocks with <= light active vectors gather table columns from L2 instead of staging slices (-1 = default 256)
@@ -204,10 +195,6 @@ int lsq_launch_icm_xs(hipStream_t s, const float *U, const uint16_t *Uq, const u
 // perturbation for the NEXT ILS iteration fused into the cost kernel's exit (on = 0: none): dst / vdst receive the perturbed copy of every vector's
 // final record / validity word (dst may be the candidate array the kernel has just judged)
 struct lsq_perturb_next { int on; int m, npert; uint32_t it; uint64_t seed, goff; uint8_t *dst; unsigned short *vdst; int abl; };      // abl: timing-only ablations of the cost kernel (tuning build; 0 in the shipped library)
-// cost + accept + next perturbation as the CLOSING PHASE of a filtered-walk launch (lsq_launch_icm_walkq): a block that has finished the node updates of its
-// vectors judges them itself (the same routine as cost4_kernel, lsq_cost.h) -- no second launch, no launch gap, and the blocks that finish their sweeps
-// early do not idle.  d % 4 == 0, X / K 16-byte aligned (the launcher's caller checks); cur / vcur: the vectors' current records / validity words.
-struct lsq_cost_phase { int on; int d; const float *X, *K; uint8_t *cur; float *prev; unsigned long long *counters; unsigned short *vcur; lsq_perturb_next pn; };
 int lsq_launch_cost(hipStream_t s, const float *X, const float *K, const uint8_t *rec, uint8_t *cur, float *prev,
                     unsigned long long *counters, int64_t n, int d, int m, int mode,
                     const unsigned short *vnew, unsigned short *vcur,

@@ -1,5 +1,5 @@
-// lsq_q16.h -- pieces shared by the two 16-bit FILTERED node-update kernels (lsq_icmq.hip: one block walks all slices of its vectors;
-// lsq_icmx.hip: the slices of a node are spread over the CUs of an XCD).  gfx950 only; not a public header.
+// lsq_q16.h -- level arithmetic and LDS placements of the 16-bit FILTERED node-update kernel (lsq_icmq.hip: one block walks all slices of its
+// vectors).  gfx950 only; not a public header.  (Round 4's XCD-cooperative variant, schedule 7, lives under the tag r05-schedule7-and-fused-launch.)
 #pragma once
 
 #include "lsq_wave.h"

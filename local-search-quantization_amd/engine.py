@@ -23,7 +23,7 @@ def _np(a, dtype):
 
 class Engine:
     def __init__(self, device=0, chunk=None, profile=False, schedule=None, skip=None, tuning=False):
-        """tuning=True loads liblsq_mi355x_tuning.so (same ABI + option "ablation", environment knobs, clock stamps, schedule 7)."""
+        """tuning=True loads liblsq_mi355x_tuning.so (same ABI + option "ablation", environment knobs, clock stamps)."""
         self._L = _lib.load(tuning=tuning)
         h = C.c_void_p()
         self._check(self._L.lsq_create(C.byref(h), int(device)))

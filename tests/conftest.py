@@ -12,23 +12,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "tuning: cross-checks of the NON-SHIPPED schedule 7 (csrc/lsq_icmx.hip, liblsq_mi355x_tuning.so only); they run only "
-                                       "with LSQ_TEST_TUNING=1 so that they never count toward the product's green total")
 
 
-def pytest_collection_modifyitems(config, items):
-    if os.environ.get("LSQ_TEST_TUNING") == "1":
-        return
-    skip = pytest.mark.skip(reason="tuning-build cross-check of a non-shipped schedule (set LSQ_TEST_TUNING=1 to run it)")
-    for item in items:
-        if "tuning" in item.keywords:
-            item.add_marker(skip)
-
-
-# How the encode is run in the parity tests.  The FIRST entries are the shipped library: its plain defaults (what a caller gets),
+# How the encode is run in the parity tests, all through the shipped library: its plain defaults (what a caller gets),
 # schedule 6 forced onto every chunk with every block staged and both hand-overs to the f32 walk switched off (the 16-bit filtered walk
-# is then the kernel that produces every code, whatever n and whatever the data), the f32 walk in both launch shapes.  Schedule 7 (the XCD-cooperative
-# kernel of round 4: bit-exact, measured slower, not adopted) exists in the tuning build only and is marked `tuning`.
+# is then the kernel that produces every code, whatever n and whatever the data), the f32 walk in both launch shapes.
 def _variant(name, marks=(), **options):
     return pytest.param(options, id=name, marks=list(marks))
 
@@ -39,9 +27,6 @@ ENCODE_VARIANTS = [
     _variant("s6_light", schedule=6, q16_min=0),
     _variant("s4", schedule=4),
     _variant("s3", schedule=3),
-    _variant("xs7", marks=[pytest.mark.tuning], schedule=7, tuning=1, q16_min=0, xs_min=0, filter_probe_div=0, filter_fallback_div=0),
-    # round 5's fused launch (cost + accept + perturbation as the closing phase of the walk kernel's blocks): bit-exact, measured slower, tuning build only
-    _variant("fused", marks=[pytest.mark.tuning], schedule=6, tuning=1, q16_min=0, light=0, filter_probe_div=0, filter_fallback_div=0, fuse_cost=1),
 ]
 
 

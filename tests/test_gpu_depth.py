@@ -62,6 +62,98 @@ def test_cfg2_full_size_full_depth_rows_vs_oracle(lsq, oracle, codebooks):
     assert np.isfinite(sums[0]) and sums[0] > 0
 
 
+def _check_rows(oracle, dX, dB0, dBs0, dK, rows, m, ils, J, npert, seed, goff0=0):
+    """Re-encode the listed row ranges with the oracle (global index = goff0 + row) and count the rows that differ."""
+    import torch
+    idx = np.concatenate([np.arange(a, b) for a, b in rows])
+    t_idx = torch.from_numpy(idx).to(dX.device)
+    Xr, Br, got_r = dX[t_idx].cpu().numpy(), dB0[t_idx].cpu().numpy().astype(np.int16) + 1, dBs0[t_idx].cpu().numpy().astype(np.int16) + 1
+    K = dK.cpu().numpy()
+    bad, pos = 0, 0
+    for a, b in rows:
+        w = b - a
+        ref, _ = oracle.encode_icm(Xr[pos:pos + w], Br[pos:pos + w], K, m, H, ils, J, npert, True, seed, global_offset=goff0 + a)
+        bad += int((ref[0] != got_r[pos:pos + w]).any(axis=1).sum())
+        pos += w
+    return bad, len(idx)
+
+
+def _rows_small(n, width=48, scattered=32, extra=()):
+    rng = np.random.default_rng(6)
+    blocks = [(0, width), (n // 2 - width // 2, n // 2 + width // 2), (n - width, n)] + list(extra)
+    singles = [(int(i), int(i) + 1) for i in np.sort(rng.choice(n, size=scattered, replace=False))]
+    return blocks + singles
+
+
+@pytest.mark.parametrize("codebooks", ["synthetic", "trained"])
+def test_cfg3_full_size_full_depth_rows_vs_oracle(lsq, oracle, codebooks):
+    """BASELINE configs[2] (10^6 x 128, m = 16) at its stated depth (16 ILS iterations x 4 sweeps): the only place the m = 16 memoisation state (validity
+    bits, fall-back to the current tuple, 16-byte records) is aged over 16 iterations.  176 rows re-encoded by the oracle (VERDICT r5, next #3)."""
+    import torch
+    n, d, m, ils, J, npert, seed = 1_000_000, 128, 16, [16], 4, 4, 42
+    with lsq.Engine(0) as eng:
+        dX = eng.synth_data_u8_dev(1234, n, d)
+        dB0 = eng.randinit_dev(7, n, m)
+        if codebooks == "synthetic":
+            dK = eng.synth_codebooks_dev(4321, m, d)
+        else:
+            ns = 50_000
+            with lsq.Engine(0) as e2:
+                dK, _, _, _, obj = lsq.train_lsq_dev(dX[:ns].contiguous(), m, H, dB0[:ns].contiguous(), 4, 4, J, True, npert, seed=42, engine=e2,
+                                                     norm_codebook=False)
+            assert obj[-1] < obj[0]
+        dBs, sums, stats = eng.encode_icm_dev(dX, dB0, dK, m, ils, J, npert, True, seed=seed)
+        torch.cuda.synchronize()
+        tm = eng.timings()
+        assert tm["filtered_blocks"] > 0, tm
+        bad, cnt = _check_rows(oracle, dX, dB0, dBs[0], dK, _rows_small(n), m, ils, J, npert, seed)
+    assert cnt >= 96 and bad == 0, "%d of %d checked rows differ from the oracle (m = 16, %s codebooks)" % (bad, cnt, codebooks)
+    assert stats.shape == (16, 2) and np.isfinite(sums[0]) and sums[0] > 0
+
+
+def test_cfg4_share_full_depth_rows_vs_oracle(lsq, oracle):
+    """BASELINE configs[3]: rank 3's splitarray shard of the 10^6 x 960 GIST-shaped set (125 000 vectors at global offset 375 000), m = 8, at the stated
+    depth of 16 ILS iterations: every block holds 489 vectors, so every node update runs in the sparse regime.  176 rows re-encoded by the oracle at
+    their GLOBAL indices."""
+    import torch
+    ntot, d, m, ils, J, npert, seed = 1_000_000, 960, 8, [16], 4, 4, 42
+    start, stop = lsq.distributed.shard_range(ntot, 8, 3)
+    n = stop - start
+    assert (start, n) == (375_000, 125_000)
+    with lsq.Engine(0) as eng:
+        dX = eng.synth_data_u8_dev(1234, n, d, global_offset=start)
+        dX.mul_(0.3 / 255.0)                                                  # GIST-like range (SURVEY 8(d)), as bench.py
+        dB0 = eng.randinit_dev(7, n, m, global_offset=start)
+        dK = eng.synth_codebooks_dev(4321, m, d)
+        dK.mul_(0.3 / 255.0)
+        dBs, sums, stats = eng.encode_icm_dev(dX, dB0, dK, m, ils, J, npert, True, seed=seed, global_offset=start)
+        torch.cuda.synchronize()
+        tm = eng.timings()
+        assert tm["filtered_blocks"] > 0, tm
+        bad, cnt = _check_rows(oracle, dX, dB0, dBs[0], dK, _rows_small(n), m, ils, J, npert, seed, goff0=start)
+    assert cnt >= 96 and bad == 0, "%d of %d checked rows differ from the oracle (125 000 x 960 at offset 375 000)" % (bad, cnt)
+    assert stats.shape == (16, 2) and np.isfinite(sums[0]) and sums[0] > 0
+
+
+def test_cfg5_chunk_boundary_full_depth_rows_vs_oracle(lsq, oracle):
+    """BASELINE configs[4] walks 13 resident chunks per GPU: one chunk boundary at the stated depth -- 1 115 808 vectors = one full default chunk
+    (256 x 3968) + 100 000, at a non-zero global offset; rows on both sides of the boundary, in the short second chunk and scattered."""
+    import torch
+    d, m, ils, J, npert, seed, goff = 128, 8, [16], 4, 4, 42, 25_000_000
+    chunk = 256 * 3968
+    n = chunk + 100_000
+    with lsq.Engine(0) as eng:
+        dX = eng.synth_data_u8_dev(1234, n, d, global_offset=goff)
+        dB0 = eng.randinit_dev(7, n, m, global_offset=goff)
+        dK = eng.synth_codebooks_dev(4321, m, d)
+        dBs, sums, stats = eng.encode_icm_dev(dX, dB0, dK, m, ils, J, npert, True, seed=seed, global_offset=goff)
+        torch.cuda.synchronize()
+        rows = _rows_small(n, extra=[(chunk - 24, chunk + 24)])
+        bad, cnt = _check_rows(oracle, dX, dB0, dBs[0], dK, rows, m, ils, J, npert, seed, goff0=goff)
+    assert cnt >= 96 and bad == 0, "%d of %d checked rows differ from the oracle (two chunks, offset %d)" % (bad, cnt, goff)
+    assert stats.shape == (16, 2) and np.isfinite(sums[0]) and sums[0] > 0
+
+
 def test_fuzz_filter_fixed_seed_slice():
     """50 cases of the randomised campaign for the filtered walk (random shapes / scales / offsets / duplicated codewords / heavy tails, every block
     staged, every vector compared with the oracle), fixed seed."""
@@ -99,6 +191,22 @@ def test_bench_plain_multi_gpu_form_launches_its_own_ranks():
         assert out["config"]["rccl_ranks"] == 2 and out["config"]["collective_backend"] == "rccl"
     else:
         assert out["config"]["collective_backend"] == "gloo"
+
+
+def test_bench_strong_scaling_two_rank_form():
+    """The strong-scaling form of BASELINE configs[3] on two ranks: `python bench.py --gpus 2 --scaling strong --total 250000 --dim 960` -- a FIXED total
+    split into splitarray shards of 125 000 (the per-GPU share of the 8-GPU run), the script starting its own ranks; rank 0 prints ONE line with
+    "scaling": "strong" and the whole job's vectors (VERDICT r5 #9: so that the first 8-GPU run records a curve, not an rc)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scaling", "strong", "--total", "250000", "--dim", "960", "--steps", "1",
+           "--warmup", "1", "--ils", "2", "--no-cpu-baseline", "--no-extra-legs", "--no-sample-parity"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["vectors_total"] == 250000 and len(out["ranks"]) == 2
+    assert out["value"] > 0 and out["config"]["d"] == 960 and sorted(out["config"]["vectors_per_gpu"]) == [125000, 125000]
 
 
 def test_chained_host_calls_reuse_the_tables_of_unchanged_codebooks(lsq, oracle):

@@ -41,11 +41,8 @@ def run(ncases=60, seed0=1, schedule=6, verbose=True):
         B0 = O.randinit(3000 + t, n, m, H)
         ils, J, npert = [int(rng.integers(1, 3))], int(rng.integers(1, 4)), int(rng.integers(0, m + 1))
         ref, objs_ref = O.encode_icm(X, B0, K, m, H, ils, J, npert, True, 11 * t + 3)
-        sched = schedule      # 7: the XCD-cooperative kernel of the tuning build (csrc/lsq_icmx.hip)
-        with lsq.Engine(0, schedule=sched, tuning=(sched == 7)) as eng:
+        with lsq.Engine(0, schedule=schedule) as eng:
             eng.set_option("q16_min", 0); eng.set_option("light", 0); eng.set_option("filter_probe_div", 0); eng.set_option("filter_fallback_div", 0)
-            if sched == 7:
-                eng.set_option("xs_min", 0)
             Bs, objs = eng.encode_icm(X, B0, K, m, ils, J, npert, True, seed=11 * t + 3)
             tm = eng.timings()
         ok = np.array_equal(Bs, ref)
