@@ -877,7 +877,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
                 }
             }
             __syncthreads();
+#ifdef LSQ_TUNING
+            if (slice == 4) DBG_STAMP(20);
+#endif
             if (slice + 1 < NS) prefetch_tab(slice + 1);
+#ifdef LSQ_TUNING
+            if (slice == 4) DBG_STAMP(21);
+#endif
             int c0 = wave * VPW, t = 0;
             auto run = [&](auto P_) {
                 constexpr int PH = decltype(P_)::value;
@@ -902,6 +908,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
             };
             try_phase(std::integral_constant<int, 0>{}); try_phase(std::integral_constant<int, 1>{});
             try_phase(std::integral_constant<int, 2>{}); try_phase(std::integral_constant<int, 3>{});
+#ifdef LSQ_TUNING
+            if (slice == 4) DBG_STAMP(22);
+#endif
         }
         __syncthreads();
     };
@@ -963,7 +972,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
                     if (lane >= off) inc += t;
                 }
                 if (lane == 63) wave_tot[wave] = inc;
+                DBG_STAMP(16);
                 __syncthreads();
+                DBG_STAMP(17);
                 int wbase = 0;
                 for (int w2 = 0; w2 < wave; ++w2) wbase += wave_tot[w2];
                 int pos = wbase + inc - c;
@@ -971,6 +982,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT / 64 * BP
                 for (int e = 0; e < EPT; ++e)
                     if (f[e]) *listp(pos++) = (unsigned short)(base + e);
                 if (threadIdx.x == NT - 1) { nact_s = wbase + inc; redo_s = 0; f32_s = 0; }
+                DBG_STAMP(18);
                 __syncthreads();
             }
             const int nact = nact_s;

@@ -34,8 +34,11 @@ for li, r in enumerate(rows[:72]):
     if st[0] and st[4]:
         rf[3] = (st[4] - st[0]) / 100.0          # whole q16_refine
         rf[0] = (st[0] - int(r[12])) / 100.0     # from the end of the decide phase to the function entry
-    print("%3d nact %5d amb %3d total %7.1f us | compact %5.1f pre %5.1f | slices %s | decide %5.1f refine+ %5.1f [entry +%4.1f, .. %4.1f .. %4.1f, whole refine %4.1f]" %
-          (li, r[14], r[15], (ts[-1] - ts[0]) / 100.0, d[0], d[1], " ".join("%5.1f" % x for x in d[2:11]), d[11], d[12], rf[0], rf[1], rf[2], rf[3]))
+    # round 6: compaction split (scan done / first barrier passed / list written) and slice 4 split (barrier -> LDS stores + barrier -> prefetch issued -> items done -> next barrier)
+    cs = [(int(r[k]) - int(r[0])) / 100.0 if r[k] else -1 for k in (16, 17, 18)]
+    s4 = [(int(r[k]) - int(r[7])) / 100.0 if r[k] else -1 for k in (20, 21, 22)]
+    print("%3d nact %5d amb %3d total %7.1f us | compact %5.1f (scan @%4.1f barrier @%4.1f list @%4.1f) pre %5.1f | slices %s (slice 4: stores+barrier @%4.1f prefetch issued @%4.1f items @%4.1f) | decide %5.1f refine+ %5.1f" %
+          (li, r[14], r[15], (ts[-1] - ts[0]) / 100.0, d[0], cs[0], cs[1], cs[2], d[1], " ".join("%5.1f" % x for x in d[2:11]), s4[0], s4[1], s4[2], d[11], d[12]))
 
 if not per_node:
     # one launch per ILS iteration: block 0's clock at the start of every node update of its first pass (the production schedule)
@@ -46,3 +49,9 @@ if not per_node:
         ends = cl[1:k] + [cl[64]]
         print("launch %d: %d nodes, total %.1f us" % (li, k, (cl[64] - cl[0]) / 100.0))
         print("   " + " ".join("%d:%.0f" % (na[i], (ends[i] - cl[i]) / 100.0) for i in range(k)))
+        # the LAST node update of the launch in detail (stamps 0..23 keep the last node's phases): offsets from the node's start
+        t0 = cl[k - 1]
+        def at(kx): return (int(r[kx]) - t0) / 100.0 if r[kx] else -1.0
+        print("   last node (nact %d): scan @%.1f barrier @%.1f list @%.1f compacted @%.1f keys reset @%.1f | slice starts %s | slice 4: stores+barrier +%.1f prefetch +%.1f items +%.1f | walk end @%.1f decide @%.1f refine @%.1f node end @%.1f" % (
+              na[k - 1], at(16), at(17), at(18), at(1), at(2), " ".join("%.1f" % at(3 + q) for q in range(8)),
+              (int(r[20]) - int(r[7])) / 100.0, (int(r[21]) - int(r[7])) / 100.0, (int(r[22]) - int(r[7])) / 100.0, at(11), at(12), at(13), (cl[64] - t0) / 100.0))
