@@ -307,6 +307,23 @@ LSQ_API int lsq_update_codebooks_gpu(lsq_ctx *ctx, const float *X, const int16_t
 LSQ_API int lsq_update_codebooks_dev(lsq_ctx *ctx, const float *d_X, const uint8_t *d_codes, int d, int64_t n, int m, int h, float *d_K_out,
                                      int *iterations);
 
+/* ---- the initialisers' two data-parallel steps ON THE DEVICE (csrc/lsq_init.hip; since v600) -----------------------------------
+ * encoding_viterbi(X, C) -> B      src/encodings/encode_chain.jl:92-123 (worker encode_viterbi! :2-89): the exact MAP codes of a CHAIN -- unaries
+ * (get_unaries, utils.jl:94-122) plus the binaries 2 C_i' C_{i+1} of consecutive codebooks only (:103-106) -- by dynamic programming: m - 1 min-plus
+ * steps over a 256 x 256 table per vector, first minimum on ties (the reference's strict-'<' scans, :58-66,74), then the trace (:77-83).  K = hcat(C...)
+ * as everywhere (chain codebooks are zero outside the dimensions they cover: codebook_update.jl:88-102); 2 <= m <= 16, h must be 256.
+ * Host form: X d x n, B m x n Int16 1-BASED (the reference's return value).  _dev: device pointers, codes [n][m] uint8 0-BASED. */
+LSQ_API int lsq_encode_viterbi(lsq_ctx *ctx, const float *X, const float *K, int d, int64_t n, int m, int h, int16_t *B);
+LSQ_API int lsq_encode_viterbi_dev(lsq_ctx *ctx, const float *d_X, const float *d_K, int d, int64_t n, int m, int h, uint8_t *d_B);
+/* quantize_pq(X, C) / the assignment step of the k-means behind train_pq and train_opq      src/pq/PQ.jl:12-41, src/opq/kmeans.jl:6-75 (update_assignments!),
+ * src/opq/OPQ.jl:60-66,88-91: per codebook j INDEPENDENTLY the first argmin_a of ||c_ja||^2 - 2 <x, c_ja> (= the sub-space distance minus ||x_sub||^2 when
+ * codebook j is zero outside its sub-space -- PQ / OPQ codebooks padded to d rows -- and the plain nearest codeword of full-dimensional codebooks otherwise).
+ * minval (optional, [n][m] floats, vector-major): the minimum itself; add ||x_sub||^2 for the squared distance the reference's `costs` hold.
+ * PARITY UNPINNED as every initialiser: the reference takes pairwise(SqEuclidean()) from Distances.jl and argmin from its own scan; near-ties may differ.
+ * Host form: B m x n Int16 1-based; _dev: codes [n][m] uint8 0-based.  h must be 256. */
+LSQ_API int lsq_assign_codewords(lsq_ctx *ctx, const float *X, const float *K, int d, int64_t n, int m, int h, int16_t *B, float *minval);
+LSQ_API int lsq_assign_codewords_dev(lsq_ctx *ctx, const float *d_X, const float *d_K, int d, int64_t n, int m, int h, uint8_t *d_B, float *d_minval);
+
 /* ---- (4) device-side generators used by the benchmark harness -----------------------------
  * X[i][t] = float(uniform integer 0..255) (SIFT-like);  codes uniform 0..h-1 (randinit);
  * codebooks: K[j][a][:] = scale * x_{pick(j,a)} for a Philox-picked synthetic vector. */

@@ -87,6 +87,10 @@ SIGNATURES = {
     "lsq_update_codebooks_lsmr": (_i, [_vp, _vp, _i, _i64, _i, _i, _i, _vp]),
     "lsq_update_codebooks_gpu": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _vp, C.POINTER(_i)]),
     "lsq_update_codebooks_dev": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _vp, C.POINTER(_i)]),
+    "lsq_encode_viterbi": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
+    "lsq_encode_viterbi_dev": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
+    "lsq_assign_codewords": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _vp, _vp]),
+    "lsq_assign_codewords_dev": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _vp, _vp]),
     "lsq_synth_data_u8_dev": (_i, [_vp, _u64, _u64, _i64, _i, _vp]),
     "lsq_randinit_dev": (_i, [_vp, _u64, _u64, _i64, _i, _i, _vp]),
     "lsq_synth_codebooks_dev": (_i, [_vp, _u64, _i, _i, _i, _vp]),

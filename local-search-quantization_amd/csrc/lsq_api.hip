@@ -1353,6 +1353,65 @@ extern "C" int lsq_perturb(lsq_ctx *c, int16_t *B, int64_t n, int m, int h, int 
     return LSQ_OK;
 }
 
+// ---- the initialisers' data-parallel steps (lsq_init.hip) ---------------------------------------------------------------------
+// Both are "unaries of a chunk, then one kernel": the unaries are the path's own (row-major f32 planes of the chain GEMM -- the bits lsq_get_unaries
+// returns), so the codes are integer functions of exactly the numbers oracle/init_oracle.py works on.
+static int init_codes_dev(lsq_ctx *c, const char *fn, const float *dX, const float *dK, int d, int64_t n, int m, int h, uint8_t *dB, float *dmin, bool chain) {
+    LSQ_TRY(use_device(c));
+    const AsyncOff sync_here(c);
+    LSQ_TRY(check_shape(fn, d, n, m, h));
+    if (chain && m < 2) { lsq_set_error("%s: a chain needs at least two codebooks", fn); return LSQ_EINVAL; }
+    if (!dK || (n > 0 && (!dX || !dB))) { lsq_set_error("%s: null pointer", fn); return LSQ_EINVAL; }
+    if (n == 0) return LSQ_OK;
+    if (chain) LSQ_TRY(prepare_tables(c, dK, d, m));                  // ||c||^2 and the pair tables (the chain reads the m - 1 adjacent ones)
+    else {
+        c->tables_valid = false;
+        LSQ_TRY(c->sci.ensure(sizeof(float) * (size_t)m * LSQ_H));
+        LSQ_TRY(lsq_launch_sqnorms(c->stream, dK, m * LSQ_H, d, c->sci.as<float>()));
+    }
+    for (int64_t off = 0; off < n; off += c->chunk) {
+        const int64_t cn = std::min<int64_t>(c->chunk, n - off);
+        LSQ_TRY(build_unaries(c, dX + off * d, dK, d, cn, m, 0, 0, cn));
+        Timer t(c, CAT_OTHER);
+        if (chain) LSQ_TRY(lsq_launch_viterbi(c->stream, c->U.as<float>(), c->T.as<float>(), cn, m, dB + off * m));
+        else LSQ_TRY(lsq_launch_unary_argmin(c->stream, c->U.as<float>(), cn, m, dB + off * m, dmin ? dmin + off * m : nullptr));
+    }
+    return LSQ_OK;
+}
+
+static int init_codes_host(lsq_ctx *c, const char *fn, const float *X, const float *K, int d, int64_t n, int m, int h, int16_t *B, float *minval, bool chain) {
+    LSQ_TRY(use_device(c));
+    LSQ_TRY(check_shape(fn, d, n, m, h));
+    if (!K || (n > 0 && (!X || !B))) { lsq_set_error("%s: null pointer", fn); return LSQ_EINVAL; }
+    if (n == 0) return LSQ_OK;
+    LSQ_TRY(upload_xk(c, X, K, d, n, m));
+    LSQ_TRY(c->sTight.ensure((size_t)n * m));
+    LSQ_TRY(c->sB16.ensure(sizeof(int16_t) * (size_t)n * m));
+    float *dmin = nullptr;
+    if (minval) { LSQ_TRY(c->sF32.ensure(sizeof(float) * (size_t)n * m)); dmin = c->sF32.as<float>(); }
+    LSQ_TRY(init_codes_dev(c, fn, c->sX.as<float>(), c->sK.as<float>(), d, n, m, h, c->sTight.as<uint8_t>(), dmin, chain));
+    LSQ_TRY(c->recNew.ensure((size_t)n * lsq_code_stride(m)));
+    LSQ_TRY(lsq_launch_codes_expand(c->stream, c->sTight.as<uint8_t>(), n, m, c->recNew.as<uint8_t>()));
+    LSQ_TRY(lsq_launch_codes_to_i16(c->stream, c->recNew.as<uint8_t>(), n, m, c->sB16.as<int16_t>()));
+    LSQ_HIP(hipMemcpyAsync(B, c->sB16.p, sizeof(int16_t) * (size_t)n * m, hipMemcpyDeviceToHost, c->stream));
+    if (minval) LSQ_HIP(hipMemcpyAsync(minval, dmin, sizeof(float) * (size_t)n * m, hipMemcpyDeviceToHost, c->stream));
+    LSQ_HIP(hipStreamSynchronize(c->stream));
+    return LSQ_OK;
+}
+
+extern "C" int lsq_encode_viterbi_dev(lsq_ctx *c, const float *dX, const float *dK, int d, int64_t n, int m, int h, uint8_t *dB) {
+    return init_codes_dev(c, "lsq_encode_viterbi_dev", dX, dK, d, n, m, h, dB, nullptr, true);
+}
+extern "C" int lsq_encode_viterbi(lsq_ctx *c, const float *X, const float *K, int d, int64_t n, int m, int h, int16_t *B) {
+    return init_codes_host(c, "lsq_encode_viterbi", X, K, d, n, m, h, B, nullptr, true);
+}
+extern "C" int lsq_assign_codewords_dev(lsq_ctx *c, const float *dX, const float *dK, int d, int64_t n, int m, int h, uint8_t *dB, float *d_minval) {
+    return init_codes_dev(c, "lsq_assign_codewords_dev", dX, dK, d, n, m, h, dB, d_minval, false);
+}
+extern "C" int lsq_assign_codewords(lsq_ctx *c, const float *X, const float *K, int d, int64_t n, int m, int h, int16_t *B, float *minval) {
+    return init_codes_host(c, "lsq_assign_codewords", X, K, d, n, m, h, B, minval, false);
+}
+
 // ---- device-side generators ---------------------------------------------------------------------
 extern "C" int lsq_synth_data_u8_dev(lsq_ctx *c, uint64_t seed, uint64_t global_offset, int64_t n, int d, float *dX) {
     LSQ_TRY(use_device(c));

@@ -206,6 +206,11 @@ int lsq_launch_synth_data_u8(hipStream_t s, uint64_t seed, uint64_t global_offse
 int lsq_launch_randinit(hipStream_t s, uint64_t seed, uint64_t global_offset, int64_t n, int m, int h, uint8_t *tight);
 int lsq_launch_synth_codebooks(hipStream_t s, uint64_t seed, int m, int h, int d, float *K);
 
+// ---- the initialisers' two data-parallel kernels (lsq_init.hip) ---------------------------------------------------------------
+// U: row-major f32 unary planes [m][n][256] (the unary GEMM with slice = 0), T: the pair tables of prepare_tables; codes: tight [n][m] u8, 0-based.
+int lsq_launch_viterbi(hipStream_t s, const float *U, const float *T, int64_t n, int m, uint8_t *codes);            // encode_chain.jl:2-89
+int lsq_launch_unary_argmin(hipStream_t s, const float *U, int64_t n, int m, uint8_t *codes, float *minval);     // PQ.jl:12-41, kmeans.jl:6-75; minval optional [n][m]
+
 // ---- device ADC scan (lsq_adc.hip) ----------------------------------------------------------------------------------------------------
 struct lsq_adc_state;      // buffers of the scan, owned by the context
 void lsq_adc_free(lsq_adc_state *st);

@@ -236,6 +236,55 @@ class Engine:
             self._check(self._L.lsq_update_codebooks_dev(self._h, dX.data_ptr(), dcodes.data_ptr(), d, n, m, h, dK.data_ptr(), C.byref(it)))
         return dK, int(it.value)
 
+    # -- the initialisers' data-parallel steps (csrc/lsq_init.hip) ----------------------------------
+    def encode_viterbi(self, X, K, m, h=H):
+        """X (n,d) f32, K (m*h,d) f32 (chain codebooks, zero outside their dimensions) -> B (n,m) int16 1-based: the exact chain optimum
+        (encode_chain.jl:92-123)   [lsq_encode_viterbi]"""
+        X, K = _np(X, np.float32), _np(K, np.float32)
+        n, d = X.shape
+        if K.shape != (m * h, d):
+            raise ValueError("K must be (m*h, d) = (%d, %d), got %s" % (m * h, d, K.shape))
+        B = np.empty((n, m), dtype=np.int16)
+        self._check(self._L.lsq_encode_viterbi(self._h, X.ctypes.data, K.ctypes.data, d, n, m, h, B.ctypes.data))
+        return B
+
+    def encode_viterbi_dev(self, dX, dK, m, h=H):
+        """device tensors -> codes (n,m) uint8 0-based   [lsq_encode_viterbi_dev]"""
+        import torch
+        assert dX.is_cuda and dK.is_cuda and dX.dtype == torch.float32 and dK.dtype == torch.float32 and dX.is_contiguous() and dK.is_contiguous()
+        n, d = dX.shape
+        if dK.shape != (m * h, d):
+            raise ValueError("shape mismatch")
+        dB = torch.empty((n, m), dtype=torch.uint8, device=dX.device)
+        with self._on_torch_stream():
+            self._check(self._L.lsq_encode_viterbi_dev(self._h, dX.data_ptr(), dK.data_ptr(), d, n, m, h, dB.data_ptr()))
+        return dB
+
+    def assign_codewords(self, X, K, m, h=H, want_min=False):
+        """Per codebook independently the first argmin_a ||c||^2 - 2<x,c> (quantize_pq / the k-means assignment step; PQ.jl:12-41, kmeans.jl:6-75).
+        X (n,d), K (m*h,d) -> B (n,m) int16 1-based [, the minima (n,m) f32]   [lsq_assign_codewords]"""
+        X, K = _np(X, np.float32), _np(K, np.float32)
+        n, d = X.shape
+        if K.shape != (m * h, d):
+            raise ValueError("K must be (m*h, d) = (%d, %d), got %s" % (m * h, d, K.shape))
+        B = np.empty((n, m), dtype=np.int16)
+        mv = np.empty((n, m), dtype=np.float32) if want_min else None
+        self._check(self._L.lsq_assign_codewords(self._h, X.ctypes.data, K.ctypes.data, d, n, m, h, B.ctypes.data, mv.ctypes.data if want_min else None))
+        return (B, mv) if want_min else B
+
+    def assign_codewords_dev(self, dX, dK, m, h=H, want_min=False):
+        """device tensors -> codes (n,m) uint8 0-based [, minima (n,m) f32]   [lsq_assign_codewords_dev]"""
+        import torch
+        assert dX.is_cuda and dK.is_cuda and dX.dtype == torch.float32 and dK.dtype == torch.float32 and dX.is_contiguous() and dK.is_contiguous()
+        n, d = dX.shape
+        if dK.shape != (m * h, d):
+            raise ValueError("shape mismatch")
+        dB = torch.empty((n, m), dtype=torch.uint8, device=dX.device)
+        dmin = torch.empty((n, m), dtype=torch.float32, device=dX.device) if want_min else None
+        with self._on_torch_stream():
+            self._check(self._L.lsq_assign_codewords_dev(self._h, dX.data_ptr(), dK.data_ptr(), d, n, m, h, dB.data_ptr(), dmin.data_ptr() if want_min else None))
+        return (dB, dmin) if want_min else dB
+
     def linscan_stats(self):
         t = _lib.LinscanStats()
         self._check(self._L.lsq_get_linscan_stats(self._h, C.byref(t)))

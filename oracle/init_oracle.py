@@ -1,44 +1,100 @@
-"""Initialisers of the LSQ training pipeline: PQ, OPQ and ChainQ.
-
-Mirrors of the reference's trainers with the reference's names, argument order and Julia shapes, so that
-`demos/demo_lsq_gpu.jl` reads the same against this package:
+"""oracle/init_oracle.py -- CHECKER of the initialisers: PQ, OPQ and ChainQ restated in numpy.  TEST INFRASTRUCTURE: only tests/ may
+import it; the product (local-search-quantization_amd/initializers.py) runs its two data-parallel steps -- the nearest-codeword assignment and the
+chain's Viterbi encoder -- as HIP kernels (csrc/lsq_init.hip) and never touches this file.
 
     C, B, R, err = train_opq(x_train, m, h, niter, "natural")        # src/opq/OPQ.jl:21-101
     C, B, R, err = train_chainq(x_train, m, h, R, B, C, niter)       # src/chainq/chainq.jl:10-58
-    C, B, cbnorms, B_norms, obj = train_lsq(x_train, m, h, R, B, C, ...)   # reference_api.train_lsq (GPU encoder)
 
-The two data-parallel steps run ON THE DEVICE through the C-ABI (csrc/lsq_init.hip; round 6): the nearest-codeword assignment of PQ / OPQ and of
-their k-means (`lsq_assign_codewords`: every sub-space of a vector set in one call, codebooks padded to d rows) and ChainQ's Viterbi encoder
-(`lsq_encode_viterbi`).  Like the rest of the engine they need h == 256 and a gfx950 device -- there is no CPU fallback; the numpy restatement of
-these steps lives in oracle/init_oracle.py as the checker (tests only).  What stays on the host is the glue around them: k-means++ seeding, cluster
-means, the Procrustes SVD, the chain's per-dimension LSQR (scipy), and the scalar k-means of the norm codebook (an O(n log h) sorted search).
-PARITY UNPINNED: the reference delegates to Clustering.jl k-means, StatsBase sampling and IterativeSolvers LSQR,
-none vendored or version-pinned, and has no tests for them; what is mirrored is the algorithm and the interfaces.
+Two layers:
+  * `assign_codewords_exact` / `encoding_viterbi_exact`: the arithmetic the device kernels are held to, BIT FOR BIT -- the oracle's own unaries and
+    pair tables (oracle/lsq_oracle.c: k-ascending fmaf chains, the frozen choice (1) of DESIGN 2), then first-minimum scans and plain f32 adds in the
+    reference's order (encode_chain.jl:37-83; PQ.jl:12-41).  h = 256 (what the C restatement and the engine support).
+  * the trainers and their general-h numpy steps (`kmeans`, `train_pq`, `train_opq`, `train_chainq`, ...): the algorithms, property-tested on the CPU
+    with small h; with `exact=True` they take the layer above for their assignment / Viterbi steps, which is how the GPU tests compare whole training
+    runs of the product with this checker.
+PARITY UNPINNED: the reference delegates to Clustering.jl k-means, StatsBase sampling, Distances.jl and IterativeSolvers LSQR, none vendored or
+version-pinned, and has no tests for them; what is mirrored is the algorithm and the interfaces.
 Shapes follow Julia: X is d x n, codes B are m x n Int16 **1-based**, codebooks are lists of (rows x h) matrices.
 """
 import numpy as np
 
-from .engine import splitarray
+from . import oracle as O
 
-__all__ = ["train_pq", "quantize_pq", "qerror_pq", "train_opq", "quantize_opq", "get_cbdims_chain",
-           "update_codebooks_chain", "encoding_viterbi", "train_chainq", "kmeans"]
+
+def splitarray(n, nparts):
+    """utils.jl:152-177 -> list of (start, stop) 0-based half-open ranges (the first n mod nparts one longer)."""
+    per, xtra = divmod(n, nparts)
+    out, s = [], 0
+    for p in range(nparts):
+        ln = per + 1 if p < xtra else per
+        out.append((s, s + ln))
+        s += ln
+    return out
+
+
+def stack_codebooks(C, d=None, dims=None):
+    """list of (rows x h) codebooks -> K (m h, d) = hcat(C...) row-major; `dims` (slices): codebook i lives in rows dims[i] of a d-row zero matrix."""
+    if dims is None:
+        return np.ascontiguousarray(np.concatenate([np.asarray(c, dtype=np.float32).T for c in C], axis=0))
+    h = np.asarray(C[0]).shape[1]
+    K = np.zeros((len(C) * h, d), dtype=np.float32)
+    for i, c in enumerate(C):
+        K[i * h:(i + 1) * h, dims[i]] = np.asarray(c, dtype=np.float32).T
+    return K
+
+
+def assign_codewords_exact(X, K, m, h=256):
+    """X (n, d), K (m h, d) -> codes (n, m) int64 0-based, minima (n, m) f32: per codebook the first argmin of the oracle's unaries."""
+    U = O.unaries(np.ascontiguousarray(X, dtype=np.float32), np.ascontiguousarray(K, dtype=np.float32), m, h)      # (m, n, h)
+    a = U.argmin(axis=2)                                                                                            # first minimum
+    return a.T.copy(), np.take_along_axis(U, a[:, :, None], axis=2)[:, :, 0].T.copy()
+
+
+def encoding_viterbi_exact(X, K, m, h=256, block=128):
+    """X (n, d), K (m h, d) -> codes (n, m) int64 0-based: encode_chain.jl:2-89 on the oracle's unaries and pair tables."""
+    X = np.ascontiguousarray(X, dtype=np.float32)
+    K = np.ascontiguousarray(K, dtype=np.float32)
+    n = X.shape[0]
+    T = O.tables(K, m, h)                                        # T[j, k, b, a] = 2 <c_kb, c_ja>
+    bins = [T[i + 1, i] for i in range(m - 1)]                   # bb_i[k (source, codebook i)][j (target, codebook i + 1)]
+    out = np.zeros((n, m), dtype=np.int64)
+    for lo in range(0, n, block):
+        U = O.unaries(X[lo:lo + block], K, m, h)                 # (m, nb, h)
+        nb = U.shape[1]
+        back = np.zeros((m - 1, nb, h), dtype=np.int64)
+        acc = U[0]
+        for i in range(m - 1):
+            cost = acc[:, :, None] + bins[i][None, :, :]         # f32: (nb, from k, to j)   encode_chain.jl:52-54
+            back[i] = cost.argmin(axis=1)                        # first minimum over k       :58-66
+            acc = U[i + 1] + np.take_along_axis(cost, back[i][:, None, :], axis=1)[:, 0, :]   # :41-45, :70-72
+        path = acc.argmin(axis=1)                                # :74
+        out[lo:lo + nb, m - 1] = path
+        for i in range(m - 2, -1, -1):                           # :77-80
+            path = back[i][np.arange(nb), path]
+            out[lo:lo + nb, i] = path
+    return out
 
 
 def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
-def _eng(engine=None):
-    """The C-ABI context the device steps run on (the package's default one unless the caller brings its own)."""
-    if engine is not None:
-        return engine
-    from .reference_api import default_engine
-    return default_engine()
-
-
 def _subdims(d, m):
     """splitarray(1:d, m) as 0-based slices (src/utils.jl:152-177)."""
     return [slice(lo, hi) for lo, hi in splitarray(d, m)]
+
+
+def _assign_exact(C, X):
+    """One sub-space, h = 256: the device kernel's arithmetic (assign_codewords_exact with m = 1); costs = minimum + ||x||^2."""
+    a, mv = assign_codewords_exact(_f32(X).T, _f32(C).T, 1, C.shape[1])
+    return a[:, 0], (mv[:, 0] + np.einsum("ij,ij->j", _f32(X), _f32(X))).astype(np.float32)
+
+
+def _sqdist(C, X):
+    """pairwise SqEuclidean: (h, n) distances between the columns of C (r x h) and X (r x n)."""
+    cc = np.einsum("ij,ij->j", C, C)[:, None]
+    xx = np.einsum("ij,ij->j", X, X)[None, :]
+    return np.maximum(cc + xx - 2.0 * (C.T @ X), 0.0).astype(np.float32)
 
 
 def _assign_scalar(c, x):
@@ -88,26 +144,15 @@ def _assign_scalar(c, x):
     return idx.astype(np.int64), best.astype(np.float32)
 
 
-def _assign(C, X, engine=None):
-    """Nearest codeword per column of X (r x n) among the columns of C (r x h), lowest index on ties (update_assignments!, src/opq/kmeans.jl:6-75)
-    -> (assignments (n,) 0-based, squared distances (n,) f32).  r >= 2: on the device (lsq_assign_codewords, h == 256)."""
+def _assign(C, X, exact=False):
+    """Nearest codeword per column of X, lowest index on ties (update_assignments!, src/opq/kmeans.jl:6-75).  exact: the device kernel's arithmetic."""
     if X.shape[0] == 1:
         return _assign_scalar(C, X)
-    Xr = np.ascontiguousarray(_f32(X).T)
-    B, mv = _eng(engine).assign_codewords(Xr, np.ascontiguousarray(_f32(C).T), 1, h=C.shape[1], want_min=True)
-    return B[:, 0].astype(np.int64) - 1, np.maximum(mv[:, 0] + np.einsum("ij,ij->i", Xr, Xr), 0.0).astype(np.float32)
-
-
-def _assign_subspaces(C, X, sd, engine=None):
-    """All m sub-spaces of the vector set in ONE device call: codebook i padded to the d rows of X, zero outside sd[i] (quantize_pq, src/pq/PQ.jl:12-41;
-    OPQ's assignment step, src/opq/OPQ.jl:60-66,88-91) -> B (m, n) int64 0-based."""
-    X = _f32(X)
-    d, m, h = X.shape[0], len(C), C[0].shape[1]
-    K = np.zeros((m * h, d), dtype=np.float32)
-    for i in range(m):
-        K[i * h:(i + 1) * h, sd[i]] = _f32(C[i]).T
-    B = _eng(engine).assign_codewords(np.ascontiguousarray(X.T), K, m, h=h)
-    return B.T.astype(np.int64) - 1
+    if exact:
+        return _assign_exact(C, X)
+    dm = _sqdist(C, X)
+    a = dm.argmin(axis=0)
+    return a, dm[a, np.arange(X.shape[1])]
 
 
 def _centers(X, a, h, rng, old=None):
@@ -126,7 +171,7 @@ def _centers(X, a, h, rng, old=None):
     return C
 
 
-def kmeans(X, h, niter=25, seed=0, engine=None):
+def kmeans(X, h, niter=25, seed=0, exact=False):
     """Lloyd k-means with k-means++ seeding on the columns of X (r x n) -> centers (r x h), assignments (n,) 0-based, total cost.
     Stands in for Clustering.jl's `kmeans(X, h, init=:kmpp)` (src/pq/PQ.jl:60)."""
     X = _f32(X)
@@ -140,10 +185,10 @@ def kmeans(X, h, niter=25, seed=0, engine=None):
         idx = rng.integers(n) if tot <= 0 else int(np.searchsorted(np.cumsum(d2), rng.random() * tot))
         C[:, k] = X[:, min(idx, n - 1)]
         d2 = np.minimum(d2, ((X - C[:, k:k + 1]) ** 2).sum(axis=0))
-    a, cost = _assign(C, X, engine)
+    a, cost = _assign(C, X, exact)
     for _ in range(niter):
         C = _centers(X, a, h, rng)
-        a2, cost = _assign(C, X, engine)
+        a2, cost = _assign(C, X, exact)
         if np.array_equal(a2, a):
             break
         a = a2
@@ -151,13 +196,11 @@ def kmeans(X, h, niter=25, seed=0, engine=None):
 
 
 # ---- PQ (src/pq/PQ.jl) ---------------------------------------------------------------------------------------
-def quantize_pq(X, C, V=False, *, engine=None):
-    """quantize_pq(X, C) -> B (m x n Int16, 1-based).  src/pq/PQ.jl:12-41 -- one device call for all sub-spaces."""
+def quantize_pq(X, C, V=False, exact=False):
+    """quantize_pq(X, C) -> B (m x n Int16, 1-based).  src/pq/PQ.jl:12-41"""
     X = _f32(X)
     sd = _subdims(X.shape[0], len(C))
-    if any(s_.stop - s_.start < 2 for s_ in sd):          # width-1 sub-spaces (d == m): the scalar search, as in kmeans()
-        return np.stack([_assign(_f32(C[i]), X[sd[i]], engine)[0] + 1 for i in range(len(C))]).astype(np.int16)
-    return (_assign_subspaces(C, X, sd, engine) + 1).astype(np.int16)
+    return np.stack([_assign(_f32(C[i]), X[sd[i]], exact)[0] + 1 for i in range(len(C))]).astype(np.int16)
 
 
 def qerror_pq(X, B, C):
@@ -170,13 +213,13 @@ def qerror_pq(X, B, C):
     return err / X.shape[1]
 
 
-def train_pq(X, m, h, V=False, *, seed=0, engine=None):
+def train_pq(X, m, h, V=False, *, seed=0, exact=False):
     """train_pq(X, m, h) -> C, B, error.  src/pq/PQ.jl:44-76 (k-means per subspace)."""
     X = _f32(X)
     sd = _subdims(X.shape[0], m)
     C, B = [], []
     for i in range(m):
-        c, a, cost = kmeans(X[sd[i]], h, seed=seed + i, engine=engine)
+        c, a, cost = kmeans(X[sd[i]], h, seed=seed + i, exact=exact)
         C.append(c)
         B.append(a + 1)
         if V:
@@ -186,9 +229,9 @@ def train_pq(X, m, h, V=False, *, seed=0, engine=None):
 
 
 # ---- OPQ (src/opq/OPQ.jl) ------------------------------------------------------------------------------------
-def quantize_opq(X, R, C, V=False, *, engine=None):
+def quantize_opq(X, R, C, V=False, exact=False):
     """quantize_opq(X, R, C) = quantize_pq(R'X, C).  src/opq/OPQ.jl:10-19"""
-    return quantize_pq(_f32(R).T @ _f32(X), C, V, engine=engine)
+    return quantize_pq(_f32(R).T @ _f32(X), C, V, exact)
 
 
 def _procrustes(X, CB):
@@ -197,7 +240,7 @@ def _procrustes(X, CB):
     return (U @ Vt).astype(np.float32)
 
 
-def train_opq(X, m, h, niter, init="natural", V=False, *, seed=0, engine=None):
+def train_opq(X, m, h, niter, init="natural", V=False, *, seed=0, exact=False):
     """train_opq(X, m, h, niter, init) -> C, B, R, obj.  src/opq/OPQ.jl:21-101
     C[i]: (subdim x h) codebooks of the rotated space, B: m x n Int16 1-based, R: d x d, obj: niter+1 errors."""
     X = _f32(X)
@@ -212,16 +255,10 @@ def train_opq(X, m, h, niter, init="natural", V=False, *, seed=0, engine=None):
     RX = R.T @ X
     sd = _subdims(d, m)
     C = [RX[sd[i]][:, rng.choice(n, h, replace=False)].copy() for i in range(m)]     # :46-50
-    wide = all(s_.stop - s_.start >= 2 for s_ in sd)
-
-    def assign_all(RX_):
-        if wide:
-            return _assign_subspaces(C, RX_, sd, engine)
-        return np.stack([_assign(C[i], RX_[sd[i]], engine)[0] for i in range(m)])
-
+    B = np.zeros((m, n), dtype=np.int64)
     CB = np.zeros_like(X)
-    B = assign_all(RX)
     for i in range(m):
+        B[i], _ = _assign(C[i], RX[sd[i]], exact)
         CB[sd[i]] = C[i][:, B[i]]
     obj = np.zeros(niter + 1, dtype=np.float32)
     for it in range(niter + 1):
@@ -230,10 +267,9 @@ def train_opq(X, m, h, niter, init="natural", V=False, *, seed=0, engine=None):
             print("%3d %e" % (it, obj[it]))
         R = _procrustes(X, CB)
         RX = R.T @ X
-        for i in range(m):                                   # update C (:85-86); the sub-spaces are independent, so all centres first ...
-            C[i] = _centers(RX[sd[i]], B[i], h, rng, old=C[i])
-        B = assign_all(RX)                                   # ... then update B for every sub-space in one device call (:88-91)
         for i in range(m):
+            C[i] = _centers(RX[sd[i]], B[i], h, rng, old=C[i])
+            B[i], _ = _assign(C[i], RX[sd[i]], exact)
             CB[sd[i]] = C[i][:, B[i]]
     return C, (B + 1).astype(np.int16), R, obj
 
@@ -275,13 +311,34 @@ def update_codebooks_chain(X, B, h, V=False):
     return [np.ascontiguousarray(K[:, i * h:(i + 1) * h]) for i in range(m)]
 
 
-def encoding_viterbi(X, C, V=False, *, engine=None):
-    """Exact MAP codes of a chain (unaries + binaries between consecutive codebooks only) by dynamic programming ON THE DEVICE
-    (lsq_encode_viterbi, csrc/lsq_init.hip).  src/encodings/encode_chain.jl:1-123; min / argmin take the lowest index on ties as the reference's scans do."""
+def encoding_viterbi(X, C, V=False, *, block=256, exact=False):
+    """Exact MAP codes of a chain (unaries + binaries between consecutive codebooks only) by dynamic programming.
+    src/encodings/encode_chain.jl:1-123; min / argmin take the lowest index on ties as the reference's scans do."""
     X = _f32(X)
-    m, h = len(C), np.asarray(C[0]).shape[1]
-    K = np.ascontiguousarray(np.concatenate([_f32(c).T for c in C], axis=0))          # hcat(C...) as (m h, d)
-    return np.ascontiguousarray(_eng(engine).encode_viterbi(np.ascontiguousarray(X.T), K, m, h=h).T)
+    C = [_f32(c) for c in C]
+    d, n = X.shape
+    m, h = len(C), C[0].shape[1]
+    if exact:
+        return (encoding_viterbi_exact(X.T, stack_codebooks(C), m, h).T + 1).astype(np.int16)
+    bins = [(2.0 * C[i].T @ C[i + 1]).astype(np.float32) for i in range(m - 1)]       # :103-106
+    sq = [np.einsum("ij,ij->j", c, c) for c in C]
+    B = np.zeros((m, n), dtype=np.int16)
+    for lo in range(0, n, block):
+        Xb = X[:, lo:lo + block]
+        nb = Xb.shape[1]
+        U = [(-2.0 * (C[i].T @ Xb) + sq[i][:, None]).T.astype(np.float32) for i in range(m)]      # (nb, h) each; utils.jl:94-122
+        back = np.zeros((m - 1, nb, h), dtype=np.int64)
+        acc = U[0]
+        for i in range(m - 1):                                                       # forward pass :37-68
+            cost = acc[:, :, None] + bins[i][None, :, :]                             # (nb, from k, to j)
+            back[i] = cost.argmin(axis=1)
+            acc = U[i + 1] + np.take_along_axis(cost, back[i][:, None, :], axis=1)[:, 0, :]
+        path = acc.argmin(axis=1)                                                    # :74
+        B[m - 1, lo:lo + nb] = path + 1
+        for i in range(m - 2, -1, -1):                                               # backward trace :77-80
+            path = back[i][np.arange(nb), path]
+            B[i, lo:lo + nb] = path + 1
+    return B
 
 
 def _qerror_full(X, B, C):
@@ -291,7 +348,7 @@ def _qerror_full(X, B, C):
     return float(((X - rec) ** 2).sum()) / X.shape[1]
 
 
-def train_chainq(X, m, h, R, B, C, niter, V=False, *, engine=None):
+def train_chainq(X, m, h, R, B, C, niter, V=False, exact=False):
     """train_chainq(X, m, h, R, B, C, niter) -> C, B, R, obj.  src/chainq/chainq.jl:10-58
     B: initial codes (e.g. OPQ's); the incoming C is only a placeholder, as in the reference (re-fitted at :27)."""
     X = _f32(X)
@@ -299,7 +356,7 @@ def train_chainq(X, m, h, R, B, C, niter, V=False, *, engine=None):
     B = np.asarray(B, dtype=np.int16)
     RX = R.T @ X
     C = update_codebooks_chain(RX, B, h, V)                      # :27
-    B = encoding_viterbi(RX, C, V, engine=engine)                # :31
+    B = encoding_viterbi(RX, C, V, exact=exact)                  # :31
     obj = np.zeros(niter + 1, dtype=np.float32)
     for it in range(niter + 1):
         obj[it] = _qerror_full(RX, B, C)
@@ -311,5 +368,5 @@ def train_chainq(X, m, h, R, B, C, niter, V=False, *, engine=None):
         R = _procrustes(X, CB)                                   # :44-45
         RX = R.T @ X
         C = update_codebooks_chain(RX, B, h, V)
-        B = encoding_viterbi(RX, C, V, engine=engine)
+        B = encoding_viterbi(RX, C, V, exact=exact)
     return C, B, R, obj

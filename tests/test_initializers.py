@@ -1,11 +1,14 @@
-"""Host-side initialisers: PQ / OPQ / ChainQ mirrors.  The reference has no tests for them and
-delegates to unpinned packages (PARITY UNPINNED), so these are property tests of the algorithms:
-k-means / OPQ / ChainQ objectives do not increase, Viterbi is the exact chain optimum (brute force), rotations stay
-orthogonal, the chain's dimension structure is the reference's (src/codebook_update.jl:88-102)."""
+"""The initialisers' CHECKER (oracle/init_oracle.py: PQ / OPQ / ChainQ restated in numpy) and the product's host-side glue.  The reference has
+no tests for these trainers and delegates to unpinned packages (PARITY UNPINNED), so these are property tests of the algorithms: k-means / OPQ / ChainQ
+objectives do not increase, Viterbi is the exact chain optimum (brute force), rotations stay orthogonal, the chain's dimension structure is the
+reference's (src/codebook_update.jl:88-102).  The product runs its assignment and Viterbi steps on the device (csrc/lsq_init.hip); tests/test_gpu_initializers.py
+holds those kernels to this checker bit for bit."""
 import itertools
 
 import numpy as np
 import pytest
+
+import oracle.init_oracle as ini
 
 
 def clustered(d, n, k=12, seed=0, spread=0.15):
@@ -16,8 +19,6 @@ def clustered(d, n, k=12, seed=0, spread=0.15):
 
 
 def test_kmeans_improves_on_its_seeding(lsq):
-    from importlib import import_module
-    ini = import_module("local-search-quantization_amd.initializers")
     X = clustered(6, 800, k=10, seed=1)
     C0, a0, cost0 = ini.kmeans(X, 10, niter=0, seed=3)
     C, a, cost = ini.kmeans(X, 10, niter=25, seed=3)
@@ -30,10 +31,10 @@ def test_kmeans_improves_on_its_seeding(lsq):
 
 def test_train_pq_and_quantize(lsq):
     X = clustered(8, 1200, seed=2)
-    C, B, err = lsq.train_pq(X, 4, 16, seed=0)
+    C, B, err = ini.train_pq(X, 4, 16, seed=0)
     assert len(C) == 4 and C[0].shape == (2, 16) and B.shape == (4, 1200) and B.dtype == np.int16
     assert B.min() >= 1 and B.max() <= 16
-    B2 = lsq.quantize_pq(X, C)
+    B2 = ini.quantize_pq(X, C)
     assert np.array_equal(B, B2)                       # converged k-means assignments are nearest-codeword assignments
     assert err < float((X ** 2).sum() / X.shape[1])    # better than the zero codebook
 
@@ -41,13 +42,13 @@ def test_train_pq_and_quantize(lsq):
 def test_train_opq_monotone_and_orthogonal(lsq):
     X = clustered(12, 1500, seed=3)
     X = (np.linalg.qr(np.random.default_rng(0).standard_normal((12, 12)))[0].astype(np.float32) @ X)   # hide the axis structure
-    C, B, R, obj = lsq.train_opq(X, 4, 16, 6, "natural", seed=1)
+    C, B, R, obj = ini.train_opq(X, 4, 16, 6, "natural", seed=1)
     assert obj.shape == (7,) and B.shape == (4, 1500) and B.min() >= 1 and B.max() <= 16
     assert np.allclose(R.T @ R, np.eye(12), atol=1e-4)
     assert obj[-1] <= obj[0] and np.all(np.diff(obj) <= 1e-3 * obj[0])      # alternating minimisation
-    assert np.array_equal(lsq.quantize_opq(X, R, C), lsq.quantize_pq(R.T @ X, C))
+    assert np.array_equal(ini.quantize_opq(X, R, C), ini.quantize_pq(R.T @ X, C))
     with pytest.raises(ValueError):
-        lsq.train_opq(X, 4, 16, 1, "nope")
+        ini.train_opq(X, 4, 16, 1, "nope")
 
 
 def test_chain_dimension_structure(lsq):
@@ -66,7 +67,7 @@ def test_viterbi_is_the_exact_chain_optimum(lsq):
     d, n, m, h = 6, 40, 4, 5
     X = rng.standard_normal((d, n)).astype(np.float32)
     C = [rng.standard_normal((d, h)).astype(np.float32) for _ in range(m)]
-    B = lsq.encoding_viterbi(X, C, block=7)
+    B = ini.encoding_viterbi(X, C, block=7)
     assert B.shape == (m, n) and B.min() >= 1 and B.max() <= h
 
     def energy(x, code):
@@ -82,8 +83,8 @@ def test_viterbi_is_the_exact_chain_optimum(lsq):
 def test_train_chainq_decreases_error(lsq):
     X = clustered(12, 900, seed=7)
     m, h = 4, 8
-    C0, B0, R0, _ = lsq.train_opq(X, m, h, 2, "natural", seed=2)
-    C, B, R, obj = lsq.train_chainq(X, m, h, R0, B0, C0, 3)
+    C0, B0, R0, _ = ini.train_opq(X, m, h, 2, "natural", seed=2)
+    C, B, R, obj = ini.train_chainq(X, m, h, R0, B0, C0, 3)
     assert len(C) == m and C[0].shape == (12, h) and B.shape == (m, 900) and B.min() >= 1 and B.max() <= h
     assert np.allclose(R.T @ R, np.eye(12), atol=1e-4)
     assert obj[-1] <= obj[0] * 1.001
@@ -99,9 +100,7 @@ def test_kmeans_objective_close_to_sklearn(lsq):
     """The reference delegates to Clustering.jl's kmeans (un-pinned).  Sanity oracle: scikit-learn's Lloyd iterations on the same data
     from the same number of centers -- the objectives of two correct k-means runs on well-clustered data agree within a few percent
     (different seedings), and ours started FROM sklearn's centers must not get worse (Lloyd steps never increase the objective)."""
-    from importlib import import_module
     from sklearn.cluster import KMeans
-    ini = import_module("local-search-quantization_amd.initializers")
     X = clustered(8, 3000, k=16, seed=11, spread=0.2)
     C, a, cost = ini.kmeans(X, 16, niter=30, seed=5)
     km = KMeans(n_clusters=16, n_init=4, max_iter=100, random_state=0, algorithm="lloyd").fit(X.T.astype(np.float64))
@@ -116,8 +115,6 @@ def test_kmeans_objective_close_to_sklearn(lsq):
 def test_procrustes_rotation_matches_numpy_svd(lsq):
     """OPQ's rotation update (src/opq/OPQ.jl: SVD of X * CB') vs the textbook orthogonal-Procrustes solution from numpy's SVD:
     R = U V' maximises trace(R' X CB'), is orthogonal, and no random orthogonal matrix does better."""
-    from importlib import import_module
-    ini = import_module("local-search-quantization_amd.initializers")
     rng = np.random.default_rng(2)
     d, n = 10, 500
     X = rng.standard_normal((d, n)).astype(np.float32)
