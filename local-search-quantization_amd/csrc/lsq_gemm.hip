@@ -375,6 +375,8 @@ int lsq_launch_chain_gemm(hipStream_t s, const float *A, const float *Bm, const 
     return LSQ_OK;
 }
 
+const void *lsq_probe_kernel_gemm() { return reinterpret_cast<const void *>(&sqnorms_kernel); }
+
 int lsq_launch_sqnorms(hipStream_t s, const float *Kb, int rows, int d, float *sci) {
     if (rows <= 0) return LSQ_OK;
     hipLaunchKernelGGL(sqnorms_kernel, dim3((rows + 15) / 16), dim3(16), 0, s, Kb, rows, d, sci);      // one row per thread, a long dependent chain: spread over the CUs

@@ -940,6 +940,8 @@ int lsq_launch_perturb(hipStream_t s, const uint8_t *src, uint8_t *dst, int64_t 
     return LSQ_OK;
 }
 
+const void *lsq_probe_kernel_icm() { return reinterpret_cast<const void *>(&tables_to_slices_kernel<16>); }
+
 int lsq_launch_cost(hipStream_t s, const float *X, const float *K, const uint8_t *rec, uint8_t *cur, float *prev,
                     unsigned long long *counters, int64_t n, int d, int m, int mode, const unsigned short *vnew, unsigned short *vcur,
                     const lsq_perturb_next *next) {

@@ -115,6 +115,12 @@ struct lsq_q16_params {
     lsq_q16_node node[LSQ_MAX_M];
 };
 
+// one kernel of each translation unit of the encode path: lsq_create asks for its attributes, which makes the runtime load that unit's code object
+// THEN (HIP loads a unit's device code at its first use: ~10 ms that the first encode of a process would otherwise pay)
+const void *lsq_probe_kernel_gemm();
+const void *lsq_probe_kernel_icm();
+const void *lsq_probe_kernel_icmq();
+
 // ---- kernel launchers (implemented in the .hip files) ------------------------------------
 // All pointers are device pointers; all launch on `s` and return immediately.
 
