@@ -1191,6 +1191,8 @@ int lsq_launch_q16_probe(hipStream_t s, const unsigned long long *probe, unsigne
     return LSQ_OK;
 }
 
+const void *lsq_probe_kernel_icmq() { return reinterpret_cast<const void *>(&q16_range_init_kernel); }
+
 int lsq_q16_slice_width(int m) {
 #ifdef LSQ_TUNING
     if (m <= 8 && LSQ_KNOB("LSQ_WALKQ_BPC", 1) == 2) return 16;
