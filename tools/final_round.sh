@@ -41,6 +41,13 @@ cp "$(find "$O/linscan_stats" -name '*kernel_stats.csv' | head -1)" "$O/${TAG}_l
 [ -x tools/bin/ubench_gemm ] && tools/bin/ubench_gemm 1000064 128 > "$O/${TAG}_ubench_gemm.txt" 2>&1
 [ -x tools/bin/ubench_write ] && tools/bin/ubench_write > "$O/${TAG}_ubench_write.txt" 2>&1
 [ -x tools/bin/ubench_h2d ] && tools/bin/ubench_h2d > "$O/${TAG}_ubench_h2d.txt" 2>&1
+# round 6: the sparse-read calibration of FETCH_SIZE (timings + one PMC pass), table staging by registers / LDS-DMA / direct gathers, the initialisers' device kernels,
+# the first host-buffer call of a fresh process
+[ -x tools/bin/ubench_sparse ] && { tools/bin/ubench_sparse 5 > "$O/ubench_sparse_timing.txt" 2>&1;
+  ( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$O/ubench_sparse_pmc" -o sp --output-format csv -- "$R/tools/bin/ubench_sparse" 1 > "$O/ubench_sparse_pmc.log" 2>&1 ); }
+[ -x tools/bin/ubench_stage ] && timeout 300 tools/bin/ubench_stage 32 > "$O/${TAG}_ubench_stage_raw.txt" 2>&1
+{ python tools/init_bench.py 100000 128 8; python tools/init_bench.py 1000000 128 8; python tools/init_bench.py 100000 960 8; python tools/init_bench.py 100000 128 16; } 2>&1 | grep "^{" > "$O/${TAG}_init_kernels.jsonl"
+{ echo "== fresh process, cfg2 (10^6 x 128)"; python tools/first_call.py 1000000 128 0 1; echo "== fresh process, cfg4 share (125 000 x 960)"; python tools/first_call.py 125000 960 0 1; } 2>&1 | grep -v amdgpu.ids > "$O/${TAG}_first_call.txt"
 { python tools/e2e_probe.py 1000000 128; python tools/e2e_probe.py 125000 960; } 2>&1 | grep -v amdgpu.ids > "$O/${TAG}_end_to_end_probe.txt"
 python tools/small_call.py 2>&1 | grep -v amdgpu.ids > "$O/${TAG}_small_call.txt"
 R2=$(pwd); ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace -d "$O/timeline" -o bench --output-format csv -- python "$R2/bench.py" --no-cpu-baseline --no-extra-legs --no-sample-parity --steps 1 --warmup 1 > "$O/timeline.log" 2>&1 )
