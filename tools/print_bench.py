@@ -1,8 +1,10 @@
-"""tools/print_bench.py < bench output: one compact line per bench JSON line (value, ms/step, breakdown, filter counters)."""
+"""tools/print_bench.py [file ...] (or < bench output): one compact line per bench JSON line (value, ms/step, breakdown, filter counters)."""
 import json
 import sys
 
-for l in sys.stdin:
+import fileinput
+
+for l in fileinput.input():
     l = l.strip()
     if l.startswith("{"):
         d = json.loads(l)
